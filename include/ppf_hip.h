@@ -1,0 +1,198 @@
+/*
+ * ppf_hip.h — C-ABI of the MI355X-native PPF matching / voting engine (libppf_hip.so).
+ *
+ * This is the drop-in boundary for the one path the reference accelerates badly: everything
+ * /root/reference/include/CloudProcessing.h does through cv::ppf_match_3d::PPF3DDetector.
+ * Plain pointers and sizes only; no C++/torch/OpenCV/PCL types.  The header-only C++ facades
+ * (include/ppf_match_3d.hpp — OpenCV-shaped, what the reference calls; include/ppf_pcl.hpp —
+ * PCL-shaped, what BASELINE.json's north_star names) sit on top of exactly these entry points.
+ *
+ *   entry point                     replaces (reference call site)
+ *   ------------------------------  ---------------------------------------------------------------
+ *   ppf_model_train                 PPF3DDetector(relSampling, relDistance) + trainModel(Mat)
+ *                                   CloudProcessing.h:205,217,234 (ctor), :236 (trainModel)
+ *   ppf_model_retain/_release       by-value detector copies and explicit dtor calls
+ *                                   CloudProcessing.h:81,206,218,240,432,485
+ *   ppf_model_save / ppf_model_load detector.write(FileStorage) :250 / detector.read(FileNode) :112
+ *   ppf_match                       detector.match(scene, results, step, dist) :442  (edge == NULL)
+ *                                   detector.match_S2B(scene, edge, results, step, dist) :495
+ *   ppf_raw_votes                   the per-reference-point argmax inside match() — the bit-exact
+ *                                   parity surface {refIndMax, alphaIndMax, maxVotes}
+ *   ppf_match_device (+workspace)   same as ppf_match with clouds already resident in HBM and an
+ *                                   explicit HIP stream: the entry bench.py times
+ *   ppf_match_batch                 many crops x many models (BASELINE config C5)
+ *   ppf_sample_cloud                samplePCByQuantization inside trainModel/match (A2)
+ *   ppf_transform_pc_pose           transformPCPose, src/YOLO_cropping_ppf_test.cpp:125
+ *   ppf_icp_refine                  ICP(100,0.005f,2.5f,8).registerModelToScene :465-470,:518-523
+ *
+ * Conventions
+ *   - Clouds are float32 rows `x y z nx ny nz` (the N x 6 CV_32FC1 Mat that
+ *     CloudProcessing.h:163-190 builds); `stride` is the row pitch in floats (6 for a Mat,
+ *     12 for pcl::PointNormal), so both host layouts pass without a copy.
+ *   - Every function returns a ppf_status; no exception crosses this boundary.
+ *     ppf_last_error() returns the calling thread's last message.
+ *   - "No pose found" is not an error: *n_out = 0 (the wrapper handles it, :450-454).
+ *   - Matching with an untrained/NULL model fails with PPF_ERR_NOT_TRAINED before any work
+ *     (the wrapper's pre-check, :435-439).
+ *   - Handles are immutable after training and reference counted: concurrent ppf_match calls
+ *     on one model from several host threads / streams are safe; each call (or workspace)
+ *     owns its scratch memory.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point
+ *     returns PPF_ERR_HIP.
+ */
+#ifndef PPF_HIP_H
+#define PPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPF_ABI_VERSION 1
+
+typedef enum ppf_status {
+  PPF_OK = 0,
+  PPF_ERR_INVALID = 1,     /* bad argument (CV_Assert in the reference's library) */
+  PPF_ERR_NOT_TRAINED = 2, /* match on an untrained model */
+  PPF_ERR_HIP = 3,         /* HIP runtime failure / no device */
+  PPF_ERR_NOMEM = 4,
+  PPF_ERR_IO = 5,
+  PPF_ERR_CAPACITY = 6     /* caller's output buffer too small; *n_out holds the needed count */
+} ppf_status;
+
+typedef struct ppf_model ppf_model;         /* opaque, ref-counted, device-resident model table */
+typedef struct ppf_workspace ppf_workspace; /* opaque per-caller scratch + result buffers */
+
+typedef struct ppf_train_params {
+  double relative_sampling_step;  /* PPF3DDetector ctor arg 1 (reference: 0.025, CloudProcessing.h:64) */
+  double relative_distance_step;  /* ctor arg 2 (reference: 0.05, :65; TrainDetector default 0.5, :223) */
+  double num_angles;              /* ctor arg 3, default 30 */
+  int32_t presampled;             /* 1: rows are already the sampled model, skip samplePCByQuantization */
+  int32_t distance_from_distance_step; /* 0 (default): distance step = diameter*relative_sampling_step,
+                                          as the reference's library computes it; 1: use relative_distance_step */
+  int32_t max_tile_refs;          /* 0 = auto: model reference points per LDS accumulator tile */
+  int32_t reserved;
+} ppf_train_params;
+
+typedef struct ppf_match_params {
+  double relative_scene_sample_step; /* match() arg 3: every (int)(1/x)-th sampled scene point is a reference */
+  double relative_scene_distance;    /* match() arg 4: scene sampling step, relative to the scene bbox */
+  double position_threshold;         /* setSearchParams; < 0 = default (relative_sampling_step) */
+  double rotation_threshold;         /* setSearchParams; < 0 = default ((360/angle_step)/180*pi) */
+  int32_t use_weighted_avg;          /* setSearchParams */
+  int32_t presampled;                /* 1: scene (and edge) rows are already sampled: every row votes */
+  int32_t ref_offset;                /* sharding over ranks: vote reference points ref_offset, */
+  int32_t ref_stride;                /*   ref_offset+ref_stride, ... of the reference list (1 = all) */
+  int32_t skip_clustering;           /* 1: stop after per-reference poses */
+  int32_t reserved;
+} ppf_match_params;
+
+/* cv::ppf_match_3d::Pose3D fields the reference reads (src/YOLO_cropping_ppf_test.cpp:124-125). */
+typedef struct ppf_pose {
+  double pose[16]; /* 4x4 row-major, model -> scene */
+  double q[4];     /* quaternion [w x y z] */
+  double t[3];
+  double angle;
+  double alpha;
+  double residual;
+  uint32_t model_index;
+  uint32_t num_votes;
+} ppf_pose;
+
+/* argmax of one scene reference point's accumulator */
+typedef struct ppf_vote {
+  uint32_t ref_ind_max;
+  uint32_t alpha_ind_max;
+  uint32_t max_votes;
+} ppf_vote;
+
+typedef struct ppf_model_info {
+  int32_t n_ref;         /* sampled model points N_m */
+  int32_t num_angles;    /* floor(2*pi/angle_step) */
+  uint32_t slots;        /* next_pow2(N_m^2) hash slots of the reference's table */
+  uint32_t n_buckets;    /* non-empty slots */
+  uint64_t n_entries;    /* N_m*(N_m-1) (+ spill duplicates) */
+  int32_t n_tiles;       /* accumulator tiles */
+  int32_t tile_refs;     /* model reference points per tile */
+  double angle_step;     /* radians */
+  double distance_step;  /* metres (float-rounded like the reference) */
+  double diameter;       /* model bbox diagonal */
+  double position_threshold_default;
+  double rotation_threshold_default;
+  uint64_t device_bytes; /* HBM held by the model */
+} ppf_model_info;
+
+/* counters of the last match executed in a workspace */
+typedef struct ppf_match_stats {
+  int32_t n_scene_sampled; /* rows after scene sampling */
+  int32_t n_paired;        /* rows of the paired cloud (== n_scene_sampled unless S2B) */
+  int32_t n_ref;           /* reference points voted by this call */
+  int32_t n_poses;         /* clustered poses */
+  uint64_t n_pairs;        /* scene pairs hashed and looked up */
+  uint64_t n_votes;        /* accumulator increments == pair-matches */
+  float ms_vote_kernel;    /* device time of the voting kernel(s), when timing is enabled */
+  float ms_pair_kernel;
+  float ms_total_device;   /* first kernel start -> last kernel end */
+  int32_t reserved;
+} ppf_match_stats;
+
+void ppf_default_train_params(ppf_train_params* p);
+void ppf_default_match_params(ppf_match_params* p);
+int ppf_abi_version(void);
+/* copies the calling thread's last error text; returns its length */
+int ppf_last_error(char* buf, int cap);
+/* number of visible HIP devices (0 when there is none); never fails */
+int ppf_device_count(void);
+
+/* ---- model ------------------------------------------------------------------------------ */
+ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train_params* params, ppf_model** out);
+ppf_status ppf_model_retain(ppf_model* m);
+ppf_status ppf_model_release(ppf_model* m);
+ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info);
+/* sampled model cloud (n_ref x 6 floats) */
+ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows);
+/* CSR dump for inspection/tests: any pointer may be NULL. bucket_off has n_tiles*(n_buckets+1) u32,
+ * entries n_entries x {int32 cell_base, float alpha_m}. */
+ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32_t* bucket_off, int32_t* entry_cell,
+                               float* entry_alpha);
+ppf_status ppf_model_save(const ppf_model* m, const char* path);
+ppf_status ppf_model_load(const char* path, ppf_model** out);
+
+/* ---- matching, host buffers ------------------------------------------------------------- */
+ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                     int estride, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
+ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                         int estride, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
+                         int* n_ref, ppf_match_stats* stats);
+
+/* ---- matching, device-resident clouds + explicit stream ---------------------------------- */
+ppf_status ppf_workspace_create(ppf_workspace** out);
+ppf_status ppf_workspace_destroy(ppf_workspace* ws);
+/* record HIP events around the kernels of each call (read back through ppf_workspace_stats) */
+ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);
+/* Enqueue sampling + voting + pose assembly (+ clustering) on `stream` (a hipStream_t, NULL = default
+ * stream).  d_scene/d_edge are DEVICE pointers.  Returns after enqueueing when everything could be
+ * sized without a host round trip (presampled clouds); results stay in the workspace. */
+ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride,
+                            const float* d_edge, int ne, int estride, const ppf_match_params* params, void* stream);
+/* Wait for the workspace's last call and copy results out (any pointer may be NULL). */
+ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* raw_poses, int cap_ref, int* n_ref,
+                                 ppf_pose* poses, int cap_poses, int* n_poses, ppf_match_stats* stats);
+/* device pointer to the per-reference pose records of the last call (n_ref x ppf_pose), for a
+ * collective gather without a host copy */
+ppf_status ppf_workspace_device_poses(ppf_workspace* ws, void** d_raw_poses, int* n_ref);
+/* cluster a caller-supplied pose list (e.g. the all-gathered per-reference poses of all ranks) */
+ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int num_poses,
+                             const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
+
+/* ---- helpers on the path's edges --------------------------------------------------------- */
+/* samplePCByQuantization: returns rows through *n_out (out may be NULL to query) */
+ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
+                            int* n_out);
+ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* pose16, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPF_HIP_H */

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: vote triples, vote totals, pair totals and the model table are BIT-EXACT (integers);
+per-reference raw poses are bit-identical fp64 (assembled from the same integers with the same
+deterministic math); clustered poses within 1e-6 rad / 1e-9 x diameter.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from yolo_ppf_pose_estimation_amd import synth
+from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector, samplePCByQuantization
+
+pytestmark = pytest.mark.gpu
+
+
+def _pose_close(a, b, diameter):
+    dR = a[:3, :3] @ b[:3, :3].T
+    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
+    return ang <= 1e-6 and np.linalg.norm(a[:3, 3] - b[:3, 3]) <= 1e-9 * diameter
+
+
+def _check_against_oracle(det, ora, scene, step, dist, presampled, edge=None):
+    got = det.raw_votes(scene, step, dist, presampled=presampled, edge=edge)
+    want = ora.match(scene, edge=edge, relative_scene_sample_step=step, relative_scene_distance=dist,
+                     presampled=presampled, cluster=True)
+    assert got["n_ref"] == want["n_ref"]
+    assert got["stats"]["n_scene_sampled"] == want["sampled_scene"].shape[0]
+    np.testing.assert_array_equal(got["triples"], want["triples"])
+    assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+    assert got["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum())
+    for g, w in zip(got["raw_poses"], want["raw_poses"]):
+        assert np.array_equal(g.pose, w["pose"]), "raw pose not bit-identical"
+        assert np.array_equal(g.q, w["q"]) and g.angle == w["angle"] and g.numVotes == w["num_votes"]
+    # clustered poses through the full match()
+    poses = det.match(scene, step, dist, presampled=presampled, edge=edge)
+    assert len(poses) == want["n_final"]
+    diameter = det.info()["diameter"]
+    for g, w in zip(poses, want["poses"]):
+        assert g.numVotes == w["num_votes"]
+        assert _pose_close(g.pose, w["pose"], diameter)
+    return got, want
+
+
+def test_model_table_matches_oracle(bottle):
+    """Row A5-train: every model pair lands in the bucket of its hash slot with its alpha_m."""
+    det = PPF3DDetector(0.07, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.07, 0.05).train_model(bottle)
+    info, oinfo = det.info(), ora.info()
+    assert info["n_ref"] == oinfo["n_ref"] and info["slots"] == oinfo["slots"]
+    assert info["num_angles"] == oinfo["num_angles"] == 30
+    assert info["distance_step"] == oinfo["distance_step"] and info["angle_step"] == oinfo["angle_step"]
+    np.testing.assert_array_equal(det.sampled_model(), ora.sampled_model())
+    N, A = info["n_ref"], info["num_angles"]
+    hsh, alp = ora.pairs()
+    tab = det.table()
+    assert info["n_tiles"] == 1
+    # oracle side: (slot, i, alpha bits) triplets, sorted
+    ii, jj = np.nonzero(~np.eye(N, dtype=bool))
+    slot = (hsh[ii, jj] & np.uint32(info["slots"] - 1)).astype(np.uint64)
+    want = np.stack([slot, ii.astype(np.uint64), alp[ii, jj].view(np.uint32).astype(np.uint64)], axis=1)
+    off = tab["bucket_off"][0]
+    bucket_of_entry = np.repeat(np.arange(info["n_buckets"]), np.diff(off))
+    got = np.stack([tab["bucket_slot"][bucket_of_entry].astype(np.uint64),
+                    (tab["entry_cell"] // A).astype(np.uint64),
+                    tab["entry_alpha"].view(np.uint32).astype(np.uint64)], axis=1)
+    assert got.shape == want.shape == (N * (N - 1), 3)
+    want = want[np.lexsort(want.T[::-1])]
+    got = got[np.lexsort(got.T[::-1])]
+    np.testing.assert_array_equal(got, want)
+    assert ora.bucket_stats()["non_empty"] == info["n_buckets"]
+
+
+def test_votes_single_tile_presampled(bottle):
+    det = PPF3DDetector(0.06, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.06, 0.05).train_model(bottle)
+    assert det.info()["n_tiles"] == 1
+    scene, _ = synth.make_scene(bottle, n_points=5000, seed=21)
+    got, _ = _check_against_oracle(det, ora, scene, 1.0 / 25.0, 0.05, True)
+    assert got["n_ref"] == 200 and got["stats"]["n_votes"] > 0
+
+
+def test_votes_two_tiles(bottle):
+    """N_m = 2000 (step 0.036): two accumulator tiles, including the alpha-bin spill across them."""
+    det = PPF3DDetector(0.036, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.036, 0.05).train_model(bottle)
+    assert det.info()["n_ref"] == 2000 and det.info()["n_tiles"] == 2
+    scene, _ = synth.make_scene(bottle, n_points=6000, seed=22)
+    _check_against_oracle(det, ora, scene, 1.0 / 100.0, 0.05, True)
+
+
+def test_votes_many_small_tiles(bottle):
+    """Force 7 tiles of 60 model points: tile merge order and spill mirroring."""
+    det = PPF3DDetector(0.07, 0.05, max_tile_refs=60).trainModel(bottle)
+    ora = O.OracleDetector(0.07, 0.05).train_model(bottle)
+    assert det.info()["n_tiles"] >= 5
+    scene, _ = synth.make_scene(bottle, n_points=3000, seed=23)
+    _check_against_oracle(det, ora, scene, 1.0 / 30.0, 0.05, True)
+
+
+def test_match_with_scene_sampling(bottle):
+    """Full match(): scene voxel sampling (A2) + voting + clustering."""
+    det = PPF3DDetector(0.06, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.06, 0.05).train_model(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=30000, seed=24)
+    np.testing.assert_array_equal(samplePCByQuantization(scene, 0.04), O.sample(scene, 0.04))
+    _check_against_oracle(det, ora, scene, 1.0 / 10.0, 0.04, False)
+
+
+def test_match_s2b(bottle):
+    """match_S2B: edge == scene reduces to match(); a different edge cloud matches the oracle."""
+    det = PPF3DDetector(0.06, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.06, 0.05).train_model(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=4000, seed=25)
+    a = det.raw_votes(scene, 1.0 / 40.0, 0.05, presampled=True)
+    b = det.raw_votes(scene, 1.0 / 40.0, 0.05, presampled=True, edge=scene)
+    # with edge == scene the pair (i, i) is no longer skipped by index; it has |d| = 0 -> key of zeros
+    want = ora.match(scene, edge=scene, relative_scene_sample_step=1.0 / 40.0, presampled=True, cluster=False)
+    np.testing.assert_array_equal(b["triples"], want["triples"])
+    assert a["n_ref"] == b["n_ref"]
+    edge = scene[::3].copy()
+    _check_against_oracle(det, ora, scene, 1.0 / 40.0, 0.05, True, edge=edge)
+
+
+def test_ref_sharding_matches_full(bottle):
+    """ref_offset/ref_stride shards (multi-GPU path) reproduce the full list."""
+    det = PPF3DDetector(0.06, 0.05).trainModel(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=3000, seed=26)
+    full = det.raw_votes(scene, 1.0 / 20.0, 0.05, presampled=True)
+    parts = [det.raw_votes(scene, 1.0 / 20.0, 0.05, presampled=True, ref_offset=k, ref_stride=3) for k in range(3)]
+    merged = np.zeros_like(full["triples"])
+    for k, p in enumerate(parts):
+        merged[k::3] = p["triples"]
+    np.testing.assert_array_equal(merged, full["triples"])
+    assert sum(p["stats"]["n_votes"] for p in parts) == full["stats"]["n_votes"]
+
+
+def test_save_load_roundtrip(bottle, tmp_path):
+    det = PPF3DDetector(0.07, 0.05).trainModel(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=2000, seed=27)
+    a = det.raw_votes(scene, 1.0 / 20.0, 0.05, presampled=True)
+    path = str(tmp_path / "detector_bottle.ppf")
+    det.write(path)
+    det2 = PPF3DDetector(0.07, 0.05).read(path)
+    b = det2.raw_votes(scene, 1.0 / 20.0, 0.05, presampled=True)
+    np.testing.assert_array_equal(a["triples"], b["triples"])
+    assert det2.info()["n_entries"] == det.info()["n_entries"]
+
+
+def test_errors(bottle):
+    from yolo_ppf_pose_estimation_amd._capi import PPFError, PPF_ERR_NOT_TRAINED, PPF_ERR_INVALID
+    det = PPF3DDetector(0.07, 0.05)
+    scene, _ = synth.make_scene(bottle, n_points=500, seed=28)
+    with pytest.raises(PPFError) as e:
+        det.match(scene)
+    assert e.value.status == PPF_ERR_NOT_TRAINED
+    det.trainModel(bottle)
+    with pytest.raises(PPFError) as e:
+        det.match(scene, 1.5, 0.05)
+    assert e.value.status == PPF_ERR_INVALID
+    # fewer sampled rows than the reference stride: one pose voted, zero clustered (reference quirk)
+    tiny = scene[:15]
+    assert det.match(tiny, 1.0 / 20.0, 0.05, presampled=True) == []

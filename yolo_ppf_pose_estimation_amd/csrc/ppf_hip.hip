@@ -1,0 +1,1214 @@
+/*
+ * ppf_hip.hip — MI355X (gfx950) implementation of the C-ABI in include/ppf_hip.h.
+ *
+ * Path: A2 cloud sampling -> A3 pair feature + key hash -> A5-train model table ->
+ * A5-match per-reference-point Hough vote over the discretised alpha -> argmax -> A8 pose assembly ->
+ * A7 pose clustering.  Reference call sites: /root/reference/include/CloudProcessing.h:236
+ * (trainModel), :442 (match), :495 (match_S2B).
+ *
+ * Data layout in HBM:
+ *   clouds        SoA  x[] y[] z[] nx[] ny[] nz[]  (f32, coalesced 256 B per wave-instruction)
+ *   slot map      slots/64 x {u64 occupancy bits, u32 rank, u32 pad}: hash slot -> dense bucket id
+ *                 in one 16-byte load (the reference indexes 2^k slots by hash % slots and never
+ *                 compares keys, so only "which slots are non-empty" has to be kept)
+ *   bucket_off    n_tiles x (n_buckets+1) u32 CSR offsets, one CSR per accumulator tile
+ *   entries       {i32 cell_base = local_model_ref*numAngles, f32 alpha_m}: 8 B per model pair
+ *   accumulator   LDS, tile_refs x numAngles u32 per workgroup (one workgroup = one scene
+ *                 reference point x one tile of model reference points)
+ *
+ * Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+ * No CPU fallback exists: without a HIP device the compute entry points return PPF_ERR_HIP.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/ppf_hip.h"
+#include "ppf_core.h"
+
+/* ============================================================================================ */
+/* errors                                                                                         */
+/* ============================================================================================ */
+namespace {
+
+thread_local std::string g_last_error;
+
+ppf_status fail(ppf_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return st;
+}
+
+#define HIPCHK(expr)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e__ = (expr);                                                                               \
+    if (e__ != hipSuccess)                                                                                 \
+      return fail(PPF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0; /* elements */
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  size_t bytes() const { return cap * sizeof(T); }
+};
+
+constexpr int WAVE = 64;
+constexpr int VOTE_BLOCK = 1024;
+constexpr int LDS_HEADER = 256;                    /* bytes in front of the accumulator: frame + reduce scratch */
+constexpr int LDS_ACC_BUDGET = 128 * 1024;         /* accumulator bytes per workgroup (160 KiB LDS per CU) */
+constexpr float SPILL_ALPHA_MIN = 3.1415f;         /* entries with alpha_m >= this can reach alpha bin == numAngles */
+
+}  // namespace
+
+/* ============================================================================================ */
+/* device code                                                                                    */
+/* ============================================================================================ */
+
+struct CloudSoA {
+  const float *x, *y, *z, *nx, *ny, *nz;
+  int n;
+};
+
+struct SlotWord {
+  uint32_t bits_lo, bits_hi, rank, pad;
+};
+
+__global__ void k_aos_to_soa(const float* __restrict__ src, int n, int stride, float* __restrict__ dst, int pitch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = src + (size_t)i * stride;
+#pragma unroll
+  for (int k = 0; k < 6; k++) dst[(size_t)k * pitch + i] = p[k];
+}
+
+__device__ __forceinline__ ppf_vec3 ld3(const float* a, const float* b, const float* c, int i) {
+  return ppf_mk3((double)a[i], (double)b[i], (double)c[i]);
+}
+
+/* ---- training: one workgroup per model reference point i, threads sweep j (row A5-train) ---- */
+__global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_step, double dist_step,
+                                                     uint32_t slot_mask, uint32_t* __restrict__ pair_slot,
+                                                     float* __restrict__ pair_alpha,
+                                                     unsigned long long* __restrict__ slot_bits) {
+  __shared__ double frame[12];
+  const int i = blockIdx.x;
+  const ppf_vec3 p1 = ld3(m.x, m.y, m.z, i), n1 = ld3(m.nx, m.ny, m.nz, i);
+  if (threadIdx.x == 0) ppf_transform_rt(p1, n1, frame, frame + 9);
+  __syncthreads();
+  double R[9], t[3];
+  for (int k = 0; k < 9; k++) R[k] = frame[k];
+  for (int k = 0; k < 3; k++) t[k] = frame[9 + k];
+  for (int j = threadIdx.x; j < m.n; j += blockDim.x) {
+    const size_t idx = (size_t)i * m.n + j;
+    if (j == i) {
+      pair_slot[idx] = 0xFFFFFFFFu;
+      pair_alpha[idx] = 0.f;
+      continue;
+    }
+    const ppf_vec3 p2 = ld3(m.x, m.y, m.z, j), n2 = ld3(m.nx, m.ny, m.nz, j);
+    double f[4] = {0, 0, 0, 0};
+    ppf_pair_feature(p1, n1, p2, n2, f);
+    const uint32_t h = ppf_hash_feature(f, angle_step, dist_step);
+    const uint32_t slot = h & slot_mask; /* hash % slots, slots a power of two */
+    pair_slot[idx] = slot;
+    pair_alpha[idx] = (float)ppf_model_alpha(R, t, p2);
+    atomicOr(&slot_bits[slot >> 6], 1ull << (slot & 63));
+  }
+}
+
+__global__ void k_popcount_words(const unsigned long long* __restrict__ bits, uint32_t* __restrict__ cnt, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cnt[i] = (uint32_t)__popcll(bits[i]);
+}
+
+__global__ void k_pack_slotmap(const unsigned long long* __restrict__ bits, const uint32_t* __restrict__ rank,
+                               SlotWord* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long b = bits[i];
+  SlotWord w;
+  w.bits_lo = (uint32_t)b; w.bits_hi = (uint32_t)(b >> 32); w.rank = rank[i]; w.pad = 0;
+  out[i] = w;
+}
+
+__device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotmap, uint32_t slot) {
+  const SlotWord w = slotmap[slot >> 6];
+  const unsigned long long bits = (unsigned long long)w.bits_lo | ((unsigned long long)w.bits_hi << 32);
+  const uint32_t bit = slot & 63;
+  if (!((bits >> bit) & 1ull)) return -1;
+  return (int)(w.rank + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)));
+}
+
+/* phase 0: count entries per (tile, bucket); phase 1: scatter through cursors */
+__global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
+                            const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int n_tiles,
+                            int num_angles, uint32_t* __restrict__ counts_or_cursor, uint2* __restrict__ entries,
+                            uint32_t* __restrict__ bucket_slot, int phase) {
+  const size_t total = (size_t)n_model * n_model;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const uint32_t slot = pair_slot[idx];
+  if (slot == 0xFFFFFFFFu) return;
+  const int i = (int)(idx / n_model);
+  const int b = slot_to_bucket(slotmap, slot);
+  const int tile = i / tile_refs;
+  const float am = pair_alpha[idx];
+  if (phase == 0) {
+    atomicAdd(&counts_or_cursor[(size_t)tile * n_buckets + b], 1u);
+    if (bucket_slot) bucket_slot[b] = slot;
+  } else {
+    uint32_t pos = atomicAdd(&counts_or_cursor[(size_t)tile * n_buckets + b], 1u);
+    entries[pos] = make_uint2((uint32_t)((i - tile * tile_refs) * num_angles), __float_as_uint(am));
+  }
+  /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
+   * that point lives in the next tile, the entry is mirrored there with local ref -1. */
+  if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1) {
+    if (phase == 0) {
+      atomicAdd(&counts_or_cursor[(size_t)(tile + 1) * n_buckets + b], 1u);
+    } else {
+      uint32_t pos = atomicAdd(&counts_or_cursor[(size_t)(tile + 1) * n_buckets + b], 1u);
+      entries[pos] = make_uint2((uint32_t)(-num_angles), __float_as_uint(am));
+    }
+  }
+}
+
+/* ---- exclusive scan (u32), 1024 elements per block ------------------------------------------- */
+__global__ __launch_bounds__(256) void k_scan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                    uint32_t* __restrict__ block_sums, size_t n) {
+  __shared__ uint32_t wave_tot[4];
+  const size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+  uint32_t s = v[0] + v[1] + v[2] + v[3];
+  uint32_t incl = s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int k = 0; k < wv; k++) woff += wave_tot[k];
+  uint32_t excl = woff + incl - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k < n) out[base + k] = excl;
+    excl += v[k];
+  }
+  if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = woff + incl;
+}
+__global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_off, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += block_off[i / 1024];
+}
+
+/* ---- voting (row A5-match) ------------------------------------------------------------------- */
+struct VoteArgs {
+  CloudSoA surf;   /* reference points come from here */
+  CloudSoA paired; /* second points of the pairs (== surf for match, edge cloud for match_S2B) */
+  int same_cloud;
+  int scene_step, ref_offset, ref_stride, n_ref;
+  const SlotWord* slotmap;
+  uint32_t slot_mask;
+  const uint32_t* bucket_off;
+  int n_buckets;
+  const uint2* entries;
+  int n_tiles, tile_refs, num_angles, n_model;
+  double angle_step, dist_step;
+  uint2* partial;               /* [n_ref * n_tiles] {max votes, local flat index} */
+  unsigned long long* cellsum;  /* [n_ref * n_tiles] sum of the tile's accumulator == votes cast */
+  unsigned long long* pairs;    /* [n_ref] pairs hashed */
+};
+
+/*
+ * One workgroup = one scene reference point x one tile of model reference points.
+ * Each wave walks its share of the paired cloud 64 points at a time: lane j builds the pair
+ * feature (fp64, deterministic math), hashes it, maps the slot to a bucket and computes alpha_s.
+ * Then the wave visits the hit buckets one after another (ballot + readlane), all 64 lanes
+ * streaming the bucket's entries (coalesced 8-byte loads) and casting one LDS atomic per entry.
+ *
+ * Alpha bin, exactly: bin = (int)(A*(alpha_m - alpha_s + 2pi)/(4pi)) in fp64.  The fast path
+ * evaluates q = (alpha_m - alpha_s)*A/(4pi) + A/2 in fp32 (|error| <= 9e-8*A) and
+ * takes trunc(q) whenever q is farther than G = 5e-7*A from an integer; otherwise (about 3e-5 of
+ * the votes) the lane re-evaluates the fp64 chain.  Both paths give the oracle's integer.
+ */
+__global__ __launch_bounds__(VOTE_BLOCK) void k_vote(VoteArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* frame = reinterpret_cast<double*>(smem);
+  uint32_t* acc = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x / a.n_tiles, tile = blockIdx.x - r * a.n_tiles;
+  const int i_ref = (a.ref_offset + r * a.ref_stride) * a.scene_step;
+  const int tile_base = tile * a.tile_refs;
+  const int refs_here = min(a.tile_refs, a.n_model - tile_base);
+  const int cells = refs_here * a.num_angles;
+
+  for (int c = tid; c < cells; c += VOTE_BLOCK) acc[c] = 0u;
+  const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
+  if (tid == 0) ppf_transform_rt(p1, n1, frame, frame + 9);
+  __syncthreads();
+  double R[9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = frame[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) t[k] = frame[9 + k];
+
+  const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
+  const uint2* __restrict__ entries = a.entries;
+  const int A = a.num_angles;
+  const float S = (float)((double)A / (4 * PPF_PI));
+  const float O = 0.5f * (float)A;
+  const float G = 5e-7f * (float)A;
+  unsigned long long my_pairs = 0;
+
+  for (int base = wave * WAVE; base < a.paired.n; base += VOTE_BLOCK) {
+    const int j = base + lane;
+    uint32_t off = 0, cnt = 0;
+    double as = 0.0;
+    if (j < a.paired.n && !(a.same_cloud && j == i_ref)) {
+      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
+      const ppf_vec3 n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
+      double f[4] = {0, 0, 0, 0};
+      ppf_pair_feature(p1, n1, p2, n2, f);
+      const uint32_t slot = ppf_hash_feature(f, a.angle_step, a.dist_step) & a.slot_mask;
+      const ppf_vec3 rp = ppf_mul33(R, p2);
+      if (ppf_alpha_in_frame(t[1] + rp.y, t[2] + rp.z, &as)) {
+        my_pairs++;
+        const int b = slot_to_bucket(a.slotmap, slot);
+        if (b >= 0) {
+          off = boff[b];
+          cnt = boff[b + 1] - off;
+        }
+      }
+    }
+    unsigned long long hit = __ballot(cnt > 0);
+    const float as32 = (float)as;
+    const uint32_t as_lo = (uint32_t)ppf_d2bits(as), as_hi = (uint32_t)(ppf_d2bits(as) >> 32);
+    while (hit) {
+      const int l = __ffsll((long long)hit) - 1;
+      hit &= hit - 1;
+      const uint32_t o = __builtin_amdgcn_readlane(off, l);
+      const uint32_t c = __builtin_amdgcn_readlane(cnt, l);
+      const float asf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(as32), l));
+      const double asd = ppf_bits2d((uint64_t)__builtin_amdgcn_readlane(as_lo, l) |
+                                    ((uint64_t)__builtin_amdgcn_readlane(as_hi, l) << 32));
+      for (uint32_t e = lane; e < c; e += WAVE) {
+        const uint2 ent = entries[o + e];
+        const float am = __uint_as_float(ent.y);
+        const float q = __builtin_fmaf(am - asf, S, O);
+        int k = (int)q;
+        const float fr = q - (float)k;
+        if (fr < G || fr > 1.0f - G) k = ppf_alpha_bin_exact(am, asd, A);
+        const int idx = (int)ent.x + k;
+        if ((unsigned)idx < (unsigned)cells) atomicAdd(&acc[idx], 1u);
+      }
+    }
+  }
+  __syncthreads();
+
+  /* argmax in the reference's scan order (model ref ascending, alpha bin ascending, strict >)
+   * == smallest flat index among the maxima; plus the exact vote total of the tile. */
+  uint32_t bv = 0, bi = 0xFFFFFFFFu;
+  unsigned long long sum = 0;
+  for (int c = tid; c < cells; c += VOTE_BLOCK) {
+    const uint32_t v = acc[c];
+    sum += v;
+    if (v > bv) { bv = v; bi = (uint32_t)c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t v2 = __shfl_down(bv, o), i2 = __shfl_down(bi, o);
+    sum += __shfl_down(sum, o);
+    my_pairs += __shfl_down(my_pairs, o);
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+  __syncthreads(); /* everyone is done reading acc/frame; reuse the header as scratch */
+  uint32_t* red_v = reinterpret_cast<uint32_t*>(smem); /* 16 + 16 words of the header */
+  uint32_t* red_i = red_v + 16;
+  if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t v = (lane < VOTE_BLOCK / WAVE) ? red_v[lane] : 0u;
+    uint32_t ix = (lane < VOTE_BLOCK / WAVE) ? red_i[lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const uint32_t v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
+      if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+    }
+    if (lane == 0) a.partial[(size_t)r * a.n_tiles + tile] = make_uint2(v, ix);
+  }
+  if (lane == 0) {
+    atomicAdd(&a.cellsum[(size_t)r * a.n_tiles + tile], sum);
+    if (tile == 0) atomicAdd(&a.pairs[r], my_pairs);
+  }
+}
+
+/* ---- finalize: merge tiles, assemble the raw pose (rows A5 tail + A8) ---------------------- */
+struct FinalArgs {
+  CloudSoA surf, model;
+  int scene_step, ref_offset, ref_stride, n_ref;
+  int n_tiles, tile_refs, num_angles;
+  const uint2* partial;
+  const unsigned long long* cellsum;
+  const unsigned long long* pairs;
+  ppf_vote* votes;
+  ppf_pose* poses;
+  unsigned long long* totals; /* [0] votes, [1] pairs */
+};
+
+__global__ void k_finalize(FinalArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n_ref) return;
+  uint32_t maxVotes = 0, flat = 0;
+  unsigned long long nv = 0;
+  for (int t = 0; t < a.n_tiles; t++) {
+    const uint2 p = a.partial[(size_t)r * a.n_tiles + t];
+    nv += a.cellsum[(size_t)r * a.n_tiles + t];
+    if (p.x > maxVotes) { maxVotes = p.x; flat = (uint32_t)(t * a.tile_refs * a.num_angles) + p.y; }
+  }
+  const uint32_t refIndMax = maxVotes ? flat / (uint32_t)a.num_angles : 0u;
+  const uint32_t alphaIndMax = maxVotes ? flat % (uint32_t)a.num_angles : 0u;
+  ppf_vote v;
+  v.ref_ind_max = refIndMax; v.alpha_ind_max = alphaIndMax; v.max_votes = maxVotes;
+  a.votes[r] = v;
+  atomicAdd(&a.totals[0], nv);
+  atomicAdd(&a.totals[1], a.pairs[r]);
+
+  const int i_ref = (a.ref_offset + r * a.ref_stride) * a.scene_step;
+  double Rsg[9], tsg[3], RInv[9], tInv[3], Rmg[9], tmg[3];
+  ppf_transform_rt(ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref), Rsg, tsg);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RInv[i * 3 + j] = Rsg[j * 3 + i];
+  ppf_vec3 rt = ppf_mul33(RInv, ppf_mk3(tsg[0], tsg[1], tsg[2]));
+  tInv[0] = -rt.x; tInv[1] = -rt.y; tInv[2] = -rt.z;
+  ppf_transform_rt(ld3(a.model.x, a.model.y, a.model.z, (int)refIndMax),
+                   ld3(a.model.nx, a.model.ny, a.model.nz, (int)refIndMax), Rmg, tmg);
+  double TsgInv[16], Tmg[16], Talpha[16], tmp[16], raw[16];
+  ppf_rt_to_pose(RInv, tInv, TsgInv);
+  ppf_rt_to_pose(Rmg, tmg, Tmg);
+  const double alpha = ((int)alphaIndMax * (4 * PPF_PI)) / a.num_angles - 2 * PPF_PI;
+  const double sx = ppf_sin(alpha), cx = ppf_cos(alpha);
+  const double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+  const double t0[3] = {0, 0, 0};
+  ppf_rt_to_pose(Rx, t0, Talpha);
+  ppf_mat44_mul(Talpha, Tmg, tmp);
+  ppf_mat44_mul(TsgInv, tmp, raw);
+  ppf_pose P;
+  for (int k = 0; k < 16; k++) P.pose[k] = raw[k];
+  double Rr[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Rr[i * 3 + j] = raw[i * 4 + j];
+  P.t[0] = raw[3]; P.t[1] = raw[7]; P.t[2] = raw[11];
+  P.angle = ppf_angle_from_trace(Rr[0] + Rr[4] + Rr[8]);
+  ppf_dcm_to_quat(Rr, P.q);
+  P.alpha = alpha; P.residual = 0; P.model_index = refIndMax; P.num_votes = maxVotes;
+  a.poses[r] = P;
+}
+
+/* ============================================================================================ */
+/* host side                                                                                      */
+/* ============================================================================================ */
+namespace {
+
+uint32_t next_pow2(uint32_t v) {
+  v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+  return v;
+}
+
+void bbox_host(const float* pc, int n, int stride, float lo[3], float hi[3]) {
+  for (int k = 0; k < 3; k++) { lo[k] = pc[k]; hi[k] = pc[k]; }
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) {
+      const float v = pc[(size_t)i * stride + k];
+      lo[k] = v < lo[k] ? v : lo[k];
+      hi[k] = v > hi[k] ? v : hi[k];
+    }
+}
+
+/* Row A2 (samplePCByQuantization + computeBboxStd) on the host: cell index in float arithmetic,
+ * cells emitted in ascending index order, per-cell fp64 sums taken in ascending point order.
+ * Implemented as a stable sort of point indices by cell.  (Device version: next row N1.) */
+std::vector<float> sample_cloud_host(const float* pc, int n, int stride, float step) {
+  float lo[3], hi[3];
+  bbox_host(pc, n, stride, lo, hi);
+  const int ns = (int)(1.0 / step);
+  const float rg[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  std::vector<std::pair<int, int>> key((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const float* p = pc + (size_t)i * stride;
+    int c[3];
+    for (int k = 0; k < 3; k++) c[k] = rg[k] > 0.0f ? ppf_f2i((float)ns * (p[k] - lo[k]) / rg[k]) : 0;
+    key[i] = {c[0] * ns * ns + c[1] * ns + c[2], i};
+  }
+  std::sort(key.begin(), key.end());
+  std::vector<float> out;
+  size_t s = 0;
+  while (s < key.size()) {
+    size_t e = s;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    while (e < key.size() && key[e].first == key[s].first) {
+      const float* p = pc + (size_t)key[e].second * stride;
+      for (int k = 0; k < 6; k++) acc[k] += (double)p[k];
+      e++;
+    }
+    const double cn = (double)(e - s);
+    for (int k = 0; k < 6; k++) acc[k] /= cn;
+    float row[6] = {(float)acc[0], (float)acc[1], (float)acc[2], 0.f, 0.f, 0.f};
+    const double norm = std::sqrt(acc[3] * acc[3] + acc[4] * acc[4] + acc[5] * acc[5]);
+    if (norm > PPF_EPS) {
+      row[3] = (float)(acc[3] / norm); row[4] = (float)(acc[4] / norm); row[5] = (float)(acc[5] / norm);
+    }
+    out.insert(out.end(), row, row + 6);
+    s = e;
+  }
+  return out;
+}
+
+bool have_device() {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+ppf_status device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return PPF_OK;
+  const size_t nb = (n + 1023) / 1024;
+  DevBuf<uint32_t> sums, sums_scan;
+  if (nb > 1) {
+    HIPCHK(sums.reserve(nb));
+    HIPCHK(sums_scan.reserve(nb));
+  }
+  k_scan_block<<<dim3((unsigned)nb), dim3(256), 0, st>>>(in, out, nb > 1 ? sums.p : nullptr, n);
+  HIPCHK(hipGetLastError());
+  if (nb > 1) {
+    ppf_status s = device_exclusive_scan(sums.p, sums_scan.p, nb, st);
+    if (s != PPF_OK) return s;
+    k_scan_add<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(out, sums_scan.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); /* sums buffers die at scope exit */
+  }
+  return PPF_OK;
+}
+
+struct CloudDev {
+  DevBuf<float> buf; /* 6 planes of `pitch` floats */
+  int n = 0, pitch = 0;
+  CloudSoA view() const {
+    CloudSoA c;
+    c.x = buf.p; c.y = buf.p + pitch; c.z = buf.p + 2 * (size_t)pitch;
+    c.nx = buf.p + 3 * (size_t)pitch; c.ny = buf.p + 4 * (size_t)pitch; c.nz = buf.p + 5 * (size_t)pitch;
+    c.n = n;
+    return c;
+  }
+  /* from a device AoS cloud */
+  ppf_status load_device(const float* d_src, int rows, int stride, hipStream_t st) {
+    n = rows;
+    pitch = (rows + 63) & ~63;
+    HIPCHK(buf.reserve((size_t)6 * std::max(pitch, 64)));
+    if (rows > 0) {
+      k_aos_to_soa<<<dim3((rows + 255) / 256), dim3(256), 0, st>>>(d_src, rows, stride, buf.p, pitch);
+      HIPCHK(hipGetLastError());
+    }
+    return PPF_OK;
+  }
+  /* from a host AoS cloud (packed rows of 6) */
+  ppf_status load_host(const float* h_src, int rows, hipStream_t st) {
+    n = rows;
+    pitch = (rows + 63) & ~63;
+    HIPCHK(buf.reserve((size_t)6 * std::max(pitch, 64)));
+    std::vector<float> soa((size_t)6 * pitch, 0.f);
+    for (int i = 0; i < rows; i++)
+      for (int k = 0; k < 6; k++) soa[(size_t)k * pitch + i] = h_src[(size_t)i * 6 + k];
+    HIPCHK(hipMemcpyAsync(buf.p, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PPF_OK;
+  }
+};
+
+}  // namespace
+
+struct ppf_model {
+  std::atomic<int> refcount{1};
+  ppf_train_params params{};
+  ppf_model_info info{};
+  std::vector<float> sampled; /* host copy, n_ref x 6 */
+  CloudDev cloud;
+  DevBuf<SlotWord> slotmap;
+  DevBuf<uint32_t> bucket_off;  /* n_tiles * (n_buckets + 1) */
+  DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
+  DevBuf<uint2> entries;
+  int device = 0;
+};
+
+struct ppf_workspace {
+  CloudDev surf, edge;
+  DevBuf<float> staging;
+  DevBuf<uint2> partial;
+  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] */
+  DevBuf<ppf_vote> votes;
+  DevBuf<ppf_pose> raw_poses;
+  std::vector<ppf_pose> final_poses;
+  bool clustered = false;
+  ppf_match_stats stats{};
+  const ppf_model* model = nullptr;
+  ppf_match_params params{};
+  int n_ref = 0, n_ref_total = 0, rows = 0;
+  hipStream_t stream = nullptr;
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool pending = false;
+};
+
+namespace {
+
+/* Row A7 (clusterPoses) — greedy first-match clustering on the host for now (device: next).
+ * Total orders frozen as (votes desc, input order asc) / (cluster votes desc, creation asc). */
+void cluster_poses_host(const std::vector<ppf_pose>& in, int num_poses, double pos_thr, double rot_thr, bool weighted,
+                        std::vector<ppf_pose>& out) {
+  std::vector<int> order(in.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return in[a].num_votes > in[b].num_votes; });
+  num_poses = std::min<int>(num_poses, (int)order.size());
+  std::vector<std::vector<int>> members;
+  std::vector<unsigned long long> cvotes;
+  for (int s = 0; s < num_poses; s++) {
+    const ppf_pose& p = in[order[s]];
+    bool assigned = false;
+    for (size_t c = 0; c < members.size() && !assigned; c++) {
+      const ppf_pose& h = in[members[c][0]];
+      const double dx = h.t[0] - p.t[0], dy = h.t[1] - p.t[1], dz = h.t[2] - p.t[2];
+      const double dn = std::sqrt(dx * dx + dy * dy + dz * dz);
+      const double phi = std::fabs(p.angle - h.angle);
+      if (phi < rot_thr && dn < pos_thr) {
+        members[c].push_back(order[s]);
+        cvotes[c] += p.num_votes;
+        assigned = true;
+      }
+    }
+    if (!assigned) {
+      members.push_back({order[s]});
+      cvotes.push_back(p.num_votes);
+    }
+  }
+  std::vector<int> corder(members.size());
+  std::iota(corder.begin(), corder.end(), 0);
+  std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cvotes[a] > cvotes[b]; });
+  out.clear();
+  out.reserve(members.size());
+  for (int ci : corder) {
+    const std::vector<int>& mem = members[ci];
+    double q[4] = {0, 0, 0, 0}, t[3] = {0, 0, 0};
+    if (weighted) {
+      double ws = 0;
+      for (int id : mem) {
+        const double w = (double)in[id].num_votes;
+        for (int k = 0; k < 4; k++) q[k] += w * in[id].q[k];
+        for (int k = 0; k < 3; k++) t[k] += w * in[id].t[k];
+        ws += w;
+      }
+      for (int k = 0; k < 3; k++) t[k] *= 1.0 / ws;
+      for (int k = 0; k < 4; k++) q[k] *= 1.0 / ws;
+    } else {
+      const int cs = (int)mem.size();
+      for (int id : mem) {
+        for (int k = 0; k < 4; k++) q[k] += in[id].q[k];
+        for (int k = 0; k < 3; k++) t[k] += in[id].t[k];
+      }
+      for (int k = 0; k < 3; k++) t[k] *= 1.0 / cs;
+      for (int k = 0; k < 4; k++) q[k] *= 1.0 / cs;
+    }
+    ppf_pose P = in[mem[0]];
+    double R[9];
+    ppf_quat_to_dcm(q, R);
+    for (int k = 0; k < 4; k++) P.q[k] = q[k];
+    for (int k = 0; k < 3; k++) P.t[k] = t[k];
+    ppf_rt_to_pose(R, t, P.pose);
+    P.angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
+    P.num_votes = (uint32_t)cvotes[ci];
+    out.push_back(P);
+  }
+}
+
+void resolve_thresholds(const ppf_model* m, const ppf_match_params* p, double* pos, double* rot) {
+  *pos = p->position_threshold < 0 ? m->info.position_threshold_default : p->position_threshold;
+  *rot = p->rotation_threshold < 0 ? m->info.rotation_threshold_default : p->rotation_threshold;
+}
+
+}  // namespace
+
+/* ============================================================================================ */
+/* C-ABI                                                                                          */
+/* ============================================================================================ */
+extern "C" {
+
+void ppf_default_train_params(ppf_train_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->relative_sampling_step = 0.05;
+  p->relative_distance_step = 0.05;
+  p->num_angles = 30;
+}
+void ppf_default_match_params(ppf_match_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->relative_scene_sample_step = 1.0 / 5.0;
+  p->relative_scene_distance = 0.03;
+  p->position_threshold = -1;
+  p->rotation_threshold = -1;
+  p->ref_stride = 1;
+}
+int ppf_abi_version(void) { return PPF_ABI_VERSION; }
+int ppf_last_error(char* buf, int cap) {
+  if (buf && cap > 0) {
+    strncpy(buf, g_last_error.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+  }
+  return (int)g_last_error.size();
+}
+int ppf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
+                            int* n_out) {
+  if (!xyzn || n <= 0 || stride < 6 || !(relative_step > 0)) return fail(PPF_ERR_INVALID, "ppf_sample_cloud: bad argument");
+  std::vector<float> s = sample_cloud_host(xyzn, n, stride, (float)relative_step);
+  const int rows = (int)(s.size() / 6);
+  if (n_out) *n_out = rows;
+  if (out) {
+    if (cap_rows < rows) return fail(PPF_ERR_CAPACITY, "ppf_sample_cloud: need %d rows, have %d", rows, cap_rows);
+    memcpy(out, s.data(), s.size() * sizeof(float));
+  }
+  return PPF_OK;
+}
+
+ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* T, float* out) {
+  if (!xyzn || !T || !out || n < 0 || stride < 6) return fail(PPF_ERR_INVALID, "ppf_transform_pc_pose: bad argument");
+  for (int i = 0; i < n; i++) {
+    const float* p = xyzn + (size_t)i * stride;
+    float* o = out + (size_t)i * 6;
+    double v[4];
+    for (int r = 0; r < 4; r++) v[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
+    if (std::fabs(v[3]) > PPF_EPS) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2];
+    double nn[3];
+    for (int r = 0; r < 3; r++) nn[r] = T[r * 4] * p[3] + T[r * 4 + 1] * p[4] + T[r * 4 + 2] * p[5];
+    const double nrm = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+    if (nrm > PPF_EPS) { nn[0] /= nrm; nn[1] /= nrm; nn[2] /= nrm; }
+    o[3] = (float)nn[0]; o[4] = (float)nn[1]; o[5] = (float)nn[2];
+  }
+  return PPF_OK;
+}
+
+/* ---- model ------------------------------------------------------------------------------------ */
+static ppf_status build_table(ppf_model* m, hipStream_t st) {
+  const int N = m->info.n_ref;
+  const size_t NN = (size_t)N * N;
+  const uint32_t slots = m->info.slots;
+  const size_t words = (slots + 63) / 64;
+  DevBuf<uint32_t> pair_slot, word_cnt, word_rank, counts, offsets;
+  DevBuf<float> pair_alpha;
+  DevBuf<unsigned long long> bits;
+  HIPCHK(pair_slot.reserve(NN));
+  HIPCHK(pair_alpha.reserve(NN));
+  HIPCHK(bits.reserve(words));
+  HIPCHK(hipMemsetAsync(bits.p, 0, words * sizeof(unsigned long long), st));
+  k_train_pairs<<<dim3(N), dim3(256), 0, st>>>(m->cloud.view(), m->info.angle_step, m->info.distance_step, slots - 1,
+                                               pair_slot.p, pair_alpha.p, bits.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(word_cnt.reserve(words + 1));
+  HIPCHK(word_rank.reserve(words + 1));
+  HIPCHK(hipMemsetAsync(word_cnt.p, 0, (words + 1) * sizeof(uint32_t), st));
+  k_popcount_words<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(bits.p, word_cnt.p, words);
+  HIPCHK(hipGetLastError());
+  ppf_status s = device_exclusive_scan(word_cnt.p, word_rank.p, words + 1, st);
+  if (s != PPF_OK) return s;
+  uint32_t n_buckets = 0;
+  HIPCHK(hipMemcpyAsync(&n_buckets, word_rank.p + words, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  m->info.n_buckets = n_buckets;
+  HIPCHK(m->slotmap.reserve(words));
+  k_pack_slotmap<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(bits.p, word_rank.p, m->slotmap.p, words);
+  HIPCHK(hipGetLastError());
+
+  const int T = m->info.n_tiles;
+  const size_t ncnt = (size_t)T * n_buckets + 1;
+  HIPCHK(counts.reserve(ncnt));
+  HIPCHK(offsets.reserve(ncnt));
+  HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
+  HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
+  const unsigned nblk = (unsigned)((NN + 255) / 256);
+  k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
+                                                m->info.tile_refs, T, m->info.num_angles, counts.p, nullptr,
+                                                m->bucket_slot.p, 0);
+  HIPCHK(hipGetLastError());
+  s = device_exclusive_scan(counts.p, offsets.p, ncnt, st);
+  if (s != PPF_OK) return s;
+  uint32_t n_entries = 0;
+  HIPCHK(hipMemcpyAsync(&n_entries, offsets.p + (ncnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  m->info.n_entries = n_entries;
+  /* per-tile CSR rows of n_buckets+1 offsets: row t = offsets[t*NB .. t*NB+NB] (the next row's first
+   * element closes the last bucket), materialised with an explicit copy per tile */
+  HIPCHK(m->bucket_off.reserve((size_t)T * (n_buckets + 1)));
+  for (int t = 0; t < T; t++)
+    HIPCHK(hipMemcpyAsync(m->bucket_off.p + (size_t)t * (n_buckets + 1), offsets.p + (size_t)t * n_buckets,
+                          (size_t)(n_buckets + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  HIPCHK(m->entries.reserve(std::max<uint32_t>(n_entries, 1)));
+  /* cursors start at the offsets */
+  HIPCHK(hipMemcpyAsync(counts.p, offsets.p, ncnt * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
+                                                m->info.tile_refs, T, m->info.num_angles, counts.p, m->entries.p,
+                                                nullptr, 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
+                         m->entries.bytes();
+  return PPF_OK;
+}
+
+ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train_params* params, ppf_model** out) {
+  if (!out) return fail(PPF_ERR_INVALID, "ppf_model_train: out is NULL");
+  *out = nullptr;
+  if (!xyzn || n <= 1 || stride < 6 || !params) return fail(PPF_ERR_INVALID, "ppf_model_train: bad argument");
+  if (!(params->relative_sampling_step > 0) || !(params->num_angles >= 1))
+    return fail(PPF_ERR_INVALID, "ppf_model_train: bad parameters");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_train: no HIP device (this engine has no CPU fallback)");
+  ppf_model* m = new ppf_model();
+  m->params = *params;
+  HIPCHK(hipGetDevice(&m->device));
+  /* ctor + setSearchParams defaults of the reference's detector */
+  const double angle_step = (360.0 / params->num_angles) * PPF_PI / 180.0;
+  float lo[3], hi[3];
+  bbox_host(xyzn, n, stride, lo, hi);
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  const float diameter = std::sqrt(dx * dx + dy * dy + dz * dz);
+  const float dist_step = (float)(diameter * (params->distance_from_distance_step ? params->relative_distance_step
+                                                                                  : params->relative_sampling_step));
+  if (params->presampled) {
+    m->sampled.resize((size_t)n * 6);
+    for (int i = 0; i < n; i++) memcpy(&m->sampled[(size_t)i * 6], xyzn + (size_t)i * stride, 24);
+  } else {
+    m->sampled = sample_cloud_host(xyzn, n, stride, (float)params->relative_sampling_step);
+  }
+  const int N = (int)(m->sampled.size() / 6);
+  if (N < 2 || (uint64_t)N * N > 0x7FFFFFFFull) {
+    delete m;
+    return fail(PPF_ERR_INVALID, "ppf_model_train: %d sampled model points unsupported", N);
+  }
+  m->info.n_ref = N;
+  m->info.num_angles = (int)std::floor(2 * PPF_PI / angle_step);
+  m->info.angle_step = angle_step;
+  m->info.distance_step = dist_step;
+  m->info.diameter = diameter;
+  m->info.slots = next_pow2(std::max<uint32_t>((uint32_t)((size_t)N * N), 16u));
+  m->info.position_threshold_default = params->relative_sampling_step;
+  m->info.rotation_threshold_default = ((360 / angle_step) / 180.0 * PPF_PI);
+  const int A = m->info.num_angles;
+  int max_refs = LDS_ACC_BUDGET / (4 * A);
+  if (params->max_tile_refs > 0) max_refs = std::min(max_refs, params->max_tile_refs);
+  if (max_refs < 1) {
+    delete m;
+    return fail(PPF_ERR_INVALID, "ppf_model_train: num_angles %d too large for the LDS accumulator", A);
+  }
+  m->info.n_tiles = (N + max_refs - 1) / max_refs;
+  m->info.tile_refs = (N + m->info.n_tiles - 1) / m->info.n_tiles;
+  hipStream_t st = nullptr;
+  ppf_status s = m->cloud.load_host(m->sampled.data(), N, st);
+  if (s == PPF_OK) s = build_table(m, st);
+  if (s != PPF_OK) {
+    delete m;
+    return s;
+  }
+  *out = m;
+  return PPF_OK;
+}
+
+ppf_status ppf_model_retain(ppf_model* m) {
+  if (!m) return fail(PPF_ERR_INVALID, "ppf_model_retain: NULL");
+  m->refcount.fetch_add(1);
+  return PPF_OK;
+}
+ppf_status ppf_model_release(ppf_model* m) {
+  if (!m) return PPF_OK;
+  if (m->refcount.fetch_sub(1) == 1) delete m;
+  return PPF_OK;
+}
+ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info) {
+  if (!m || !info) return fail(PPF_ERR_INVALID, "ppf_model_get_info: NULL");
+  *info = m->info;
+  return PPF_OK;
+}
+ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows) {
+  if (!m || !out) return fail(PPF_ERR_INVALID, "ppf_model_get_sampled: NULL");
+  if (cap_rows < m->info.n_ref) return fail(PPF_ERR_CAPACITY, "ppf_model_get_sampled: need %d rows", m->info.n_ref);
+  memcpy(out, m->sampled.data(), m->sampled.size() * sizeof(float));
+  return PPF_OK;
+}
+ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32_t* bucket_off, int32_t* entry_cell,
+                               float* entry_alpha) {
+  if (!m) return fail(PPF_ERR_INVALID, "ppf_model_get_table: NULL");
+  const size_t nb = m->info.n_buckets, ne = m->info.n_entries;
+  if (bucket_slot) HIPCHK(hipMemcpy(bucket_slot, m->bucket_slot.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (bucket_off)
+    HIPCHK(hipMemcpy(bucket_off, m->bucket_off.p, (size_t)m->info.n_tiles * (nb + 1) * sizeof(uint32_t),
+                     hipMemcpyDeviceToHost));
+  if (entry_cell || entry_alpha) {
+    std::vector<uint2> e(ne);
+    HIPCHK(hipMemcpy(e.data(), m->entries.p, ne * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < ne; k++) {
+      if (entry_cell) entry_cell[k] = (int32_t)e[k].x;
+      if (entry_alpha) memcpy(&entry_alpha[k], &e[k].y, 4);
+    }
+  }
+  return PPF_OK;
+}
+
+/* ---- workspace / matching --------------------------------------------------------------------- */
+ppf_status ppf_workspace_create(ppf_workspace** out) {
+  if (!out) return fail(PPF_ERR_INVALID, "ppf_workspace_create: NULL");
+  *out = new ppf_workspace();
+  return PPF_OK;
+}
+ppf_status ppf_workspace_destroy(ppf_workspace* ws) {
+  if (!ws) return PPF_OK;
+  for (auto& e : ws->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete ws;
+  return PPF_OK;
+}
+ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on) {
+  if (!ws) return fail(PPF_ERR_INVALID, "ppf_workspace_enable_timing: NULL");
+  if (on && !ws->ev[0])
+    for (auto& e : ws->ev) HIPCHK(hipEventCreate(&e));
+  ws->timing = on != 0;
+  return PPF_OK;
+}
+
+static ppf_status check_match_args(const ppf_model* m, const void* scene, int ns, int sstride, const void* edge, int ne,
+                                   int estride, const ppf_match_params* p) {
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  if (!scene || ns <= 0 || sstride < 6 || !p) return fail(PPF_ERR_INVALID, "match: bad scene argument");
+  if (edge && (ne <= 0 || estride < 6)) return fail(PPF_ERR_INVALID, "match: bad edge argument");
+  if (!(p->relative_scene_sample_step <= 1 && p->relative_scene_sample_step > 0))
+    return fail(PPF_ERR_INVALID, "match: relativeSceneSampleStep must be in (0, 1]");
+  if (!p->presampled && !(p->relative_scene_distance > 0)) return fail(PPF_ERR_INVALID, "match: relativeSceneDistance must be > 0");
+  if (p->ref_stride < 1 || p->ref_offset < 0) return fail(PPF_ERR_INVALID, "match: bad ref_offset/ref_stride");
+  return PPF_OK;
+}
+
+ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride,
+                            const float* d_edge, int ne, int estride, const ppf_match_params* params, void* stream) {
+  if (!ws) return fail(PPF_ERR_INVALID, "ppf_match_device: workspace is NULL");
+  ppf_status s = check_match_args(m, d_scene, ns, sstride, d_edge, ne, estride, params);
+  if (s != PPF_OK) return s;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_device: no HIP device (this engine has no CPU fallback)");
+  hipStream_t st = (hipStream_t)stream;
+  ws->model = m;
+  ws->params = *params;
+  ws->stream = st;
+  ws->clustered = false;
+  ws->final_poses.clear();
+  memset(&ws->stats, 0, sizeof(ws->stats));
+
+  /* A2: sample the scene (and edge) cloud, or take the rows as they are */
+  auto load = [&](CloudDev& dst, const float* d_src, int rows, int stride) -> ppf_status {
+    if (params->presampled) return dst.load_device(d_src, rows, stride, st);
+    std::vector<float> host((size_t)rows * stride);
+    HIPCHK(hipMemcpyAsync(host.data(), d_src, host.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<float> smp = sample_cloud_host(host.data(), rows, stride, (float)params->relative_scene_distance);
+    return dst.load_host(smp.data(), (int)(smp.size() / 6), st);
+  };
+  s = load(ws->surf, d_scene, ns, sstride);
+  if (s != PPF_OK) return s;
+  if (d_edge) {
+    s = load(ws->edge, d_edge, ne, estride);
+    if (s != PPF_OK) return s;
+  }
+  const int rows = ws->surf.n;
+  const int scene_step = (int)(1.0 / params->relative_scene_sample_step);
+  const int n_ref_total = (rows + scene_step - 1) / scene_step;
+  const int n_ref = n_ref_total > params->ref_offset ? (n_ref_total - params->ref_offset + params->ref_stride - 1) / params->ref_stride : 0;
+  ws->rows = rows;
+  ws->n_ref_total = n_ref_total;
+  ws->n_ref = n_ref;
+  ws->stats.n_scene_sampled = rows;
+  ws->stats.n_paired = d_edge ? ws->edge.n : rows;
+  ws->stats.n_ref = n_ref;
+  ws->pending = true;
+  if (n_ref == 0) return PPF_OK;
+
+  const int T = m->info.n_tiles;
+  HIPCHK(ws->partial.reserve((size_t)n_ref * T));
+  const size_t n_cnt = (size_t)n_ref * T + n_ref + 2;
+  HIPCHK(ws->counters.reserve(n_cnt));
+  HIPCHK(ws->votes.reserve(n_ref));
+  HIPCHK(ws->raw_poses.reserve(n_ref));
+  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[0], st));
+  HIPCHK(hipMemsetAsync(ws->counters.p, 0, n_cnt * sizeof(unsigned long long), st));
+
+  VoteArgs va;
+  va.surf = ws->surf.view();
+  va.paired = d_edge ? ws->edge.view() : ws->surf.view();
+  va.same_cloud = d_edge ? 0 : 1;
+  va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride; va.n_ref = n_ref;
+  va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
+  va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
+  va.entries = m->entries.p;
+  va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
+  va.angle_step = m->info.angle_step; va.dist_step = m->info.distance_step;
+  va.partial = ws->partial.p;
+  va.cellsum = ws->counters.p;
+  va.pairs = ws->counters.p + (size_t)n_ref * T;
+  const size_t lds = (size_t)LDS_HEADER + (size_t)m->info.tile_refs * m->info.num_angles * 4;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024);
+  });
+  HIPCHK(attr_err);
+  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[1], st));
+  k_vote<<<dim3((unsigned)((size_t)n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
+  HIPCHK(hipGetLastError());
+  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[2], st));
+
+  FinalArgs fa;
+  fa.surf = ws->surf.view(); fa.model = m->cloud.view();
+  fa.scene_step = scene_step; fa.ref_offset = params->ref_offset; fa.ref_stride = params->ref_stride; fa.n_ref = n_ref;
+  fa.n_tiles = T; fa.tile_refs = m->info.tile_refs; fa.num_angles = m->info.num_angles;
+  fa.partial = ws->partial.p; fa.cellsum = va.cellsum; fa.pairs = va.pairs;
+  fa.votes = ws->votes.p; fa.poses = ws->raw_poses.p;
+  fa.totals = ws->counters.p + (size_t)n_ref * T + n_ref;
+  k_finalize<<<dim3((n_ref + 63) / 64), dim3(64), 0, st>>>(fa);
+  HIPCHK(hipGetLastError());
+  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[3], st));
+  return PPF_OK;
+}
+
+ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* raw_poses, int cap_ref, int* n_ref,
+                                 ppf_pose* poses, int cap_poses, int* n_poses, ppf_match_stats* stats) {
+  if (!ws || !ws->pending) return fail(PPF_ERR_INVALID, "ppf_workspace_results: no call in this workspace");
+  HIPCHK(hipStreamSynchronize(ws->stream));
+  const int nr = ws->n_ref;
+  if (n_ref) *n_ref = nr;
+  if ((votes || raw_poses) && cap_ref < nr) return fail(PPF_ERR_CAPACITY, "ppf_workspace_results: need room for %d reference points", nr);
+  if (nr > 0) {
+    const int T = ws->model->info.n_tiles;
+    unsigned long long tot[2];
+    HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)nr * T + nr, sizeof(tot), hipMemcpyDeviceToHost));
+    ws->stats.n_votes = tot[0];
+    ws->stats.n_pairs = tot[1];
+    if (ws->timing) {
+      HIPCHK(hipEventElapsedTime(&ws->stats.ms_vote_kernel, ws->ev[1], ws->ev[2]));
+      HIPCHK(hipEventElapsedTime(&ws->stats.ms_total_device, ws->ev[0], ws->ev[3]));
+    }
+    if (votes) HIPCHK(hipMemcpy(votes, ws->votes.p, (size_t)nr * sizeof(ppf_vote), hipMemcpyDeviceToHost));
+    if (raw_poses) HIPCHK(hipMemcpy(raw_poses, ws->raw_poses.p, (size_t)nr * sizeof(ppf_pose), hipMemcpyDeviceToHost));
+  }
+  if ((poses || n_poses) && !ws->params.skip_clustering) {
+    if (!ws->clustered) {
+      std::vector<ppf_pose> raw((size_t)nr);
+      if (nr > 0) HIPCHK(hipMemcpy(raw.data(), ws->raw_poses.p, (size_t)nr * sizeof(ppf_pose), hipMemcpyDeviceToHost));
+      double pos, rot;
+      resolve_thresholds(ws->model, &ws->params, &pos, &rot);
+      /* the reference clusters sampled.rows / sceneSamplingStep poses (integer division); a shard
+       * clusters its own share */
+      const int scene_step = (int)(1.0 / ws->params.relative_scene_sample_step);
+      int num = (ws->params.ref_stride == 1 && ws->params.ref_offset == 0) ? ws->rows / scene_step : nr;
+      cluster_poses_host(raw, num, pos, rot, ws->params.use_weighted_avg != 0, ws->final_poses);
+      ws->clustered = true;
+    }
+    ws->stats.n_poses = (int)ws->final_poses.size();
+    if (n_poses) *n_poses = (int)ws->final_poses.size();
+    if (poses) {
+      if (cap_poses < (int)ws->final_poses.size())
+        return fail(PPF_ERR_CAPACITY, "ppf_workspace_results: need room for %d poses", (int)ws->final_poses.size());
+      memcpy(poses, ws->final_poses.data(), ws->final_poses.size() * sizeof(ppf_pose));
+    }
+  } else if (n_poses) {
+    *n_poses = 0;
+  }
+  if (stats) *stats = ws->stats;
+  return PPF_OK;
+}
+
+ppf_status ppf_workspace_device_poses(ppf_workspace* ws, void** d_raw_poses, int* n_ref) {
+  if (!ws || !ws->pending || !d_raw_poses) return fail(PPF_ERR_INVALID, "ppf_workspace_device_poses: bad argument");
+  *d_raw_poses = ws->raw_poses.p;
+  if (n_ref) *n_ref = ws->n_ref;
+  return PPF_OK;
+}
+
+ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int num_poses,
+                             const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "ppf_cluster_poses: model is NULL");
+  if ((!in && n > 0) || n < 0 || !params || !n_out) return fail(PPF_ERR_INVALID, "ppf_cluster_poses: bad argument");
+  std::vector<ppf_pose> raw(in, in + n), fin;
+  double pos, rot;
+  resolve_thresholds(m, params, &pos, &rot);
+  cluster_poses_host(raw, num_poses, pos, rot, params->use_weighted_avg != 0, fin);
+  *n_out = (int)fin.size();
+  if (out) {
+    if (cap < (int)fin.size()) return fail(PPF_ERR_CAPACITY, "ppf_cluster_poses: need room for %d poses", (int)fin.size());
+    memcpy(out, fin.data(), fin.size() * sizeof(ppf_pose));
+  }
+  return PPF_OK;
+}
+
+/* host-buffer conveniences: upload, run on the default stream, download */
+static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                           int estride, const ppf_match_params* params, ppf_workspace* ws) {
+  ppf_status s = check_match_args(m, scene, ns, sstride, edge, ne, estride, params);
+  if (s != PPF_OK) return s;
+  if (!have_device()) return fail(PPF_ERR_HIP, "match: no HIP device (this engine has no CPU fallback)");
+  DevBuf<float> d_scene, d_edge;
+  HIPCHK(d_scene.reserve((size_t)ns * sstride));
+  HIPCHK(hipMemcpy(d_scene.p, scene, (size_t)ns * sstride * sizeof(float), hipMemcpyHostToDevice));
+  if (edge) {
+    HIPCHK(d_edge.reserve((size_t)ne * estride));
+    HIPCHK(hipMemcpy(d_edge.p, edge, (size_t)ne * estride * sizeof(float), hipMemcpyHostToDevice));
+  }
+  s = ppf_match_device(m, ws, d_scene.p, ns, sstride, edge ? d_edge.p : nullptr, ne, estride, params, nullptr);
+  if (s != PPF_OK) return s;
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return PPF_OK;
+}
+
+ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                     int estride, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
+  if (!n_out) return fail(PPF_ERR_INVALID, "ppf_match: n_out is NULL");
+  *n_out = 0;
+  ppf_workspace ws;
+  ppf_status s = run_host(m, scene, ns, sstride, edge, ne, estride, params, &ws);
+  if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
+  for (auto& e : ws.ev)
+    if (e) (void)hipEventDestroy(e);
+  return s;
+}
+
+ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                         int estride, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
+                         int* n_ref, ppf_match_stats* stats) {
+  ppf_workspace ws;
+  ppf_status s = ppf_workspace_enable_timing(&ws, 1);
+  if (s == PPF_OK) s = run_host(m, scene, ns, sstride, edge, ne, estride, params, &ws);
+  if (s == PPF_OK) s = ppf_workspace_results(&ws, votes, raw_poses, cap, n_ref, nullptr, 0, nullptr, stats);
+  for (auto& e : ws.ev)
+    if (e) (void)hipEventDestroy(e);
+  return s;
+}
+
+/* ---- model (de)serialisation: versioned binary CSR (the reference's XML format is defined by a
+ * private OpenCV patch and unknown) ------------------------------------------------- */
+static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '1'};
+
+ppf_status ppf_model_save(const ppf_model* m, const char* path) {
+  if (!m || !path) return fail(PPF_ERR_INVALID, "ppf_model_save: NULL");
+  const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->info.n_entries;
+  std::vector<SlotWord> slotmap(words);
+  std::vector<uint32_t> boff((size_t)m->info.n_tiles * (nb + 1)), bslot(nb);
+  std::vector<uint2> ent(ne);
+  HIPCHK(hipMemcpy(slotmap.data(), m->slotmap.p, words * sizeof(SlotWord), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(boff.data(), m->bucket_off.p, boff.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (nb) HIPCHK(hipMemcpy(bslot.data(), m->bucket_slot.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (ne) HIPCHK(hipMemcpy(ent.data(), m->entries.p, ne * sizeof(uint2), hipMemcpyDeviceToHost));
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(PPF_ERR_IO, "ppf_model_save: cannot open %s", path);
+  bool ok = fwrite(PPF_MAGIC, 1, 8, f) == 8;
+  ok = ok && fwrite(&m->params, sizeof(m->params), 1, f) == 1;
+  ok = ok && fwrite(&m->info, sizeof(m->info), 1, f) == 1;
+  ok = ok && fwrite(m->sampled.data(), sizeof(float), m->sampled.size(), f) == m->sampled.size();
+  ok = ok && fwrite(slotmap.data(), sizeof(SlotWord), words, f) == words;
+  ok = ok && fwrite(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
+  ok = ok && fwrite(bslot.data(), sizeof(uint32_t), nb, f) == nb;
+  ok = ok && fwrite(ent.data(), sizeof(uint2), ne, f) == ne;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return fail(PPF_ERR_IO, "ppf_model_save: short write to %s", path);
+  return PPF_OK;
+}
+
+ppf_status ppf_model_load(const char* path, ppf_model** out) {
+  if (!path || !out) return fail(PPF_ERR_INVALID, "ppf_model_load: NULL");
+  *out = nullptr;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_load: no HIP device");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(PPF_ERR_IO, "ppf_model_load: cannot open %s", path);
+  char magic[8];
+  ppf_model* m = new ppf_model();
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, PPF_MAGIC, 8) == 0;
+  ok = ok && fread(&m->params, sizeof(m->params), 1, f) == 1;
+  ok = ok && fread(&m->info, sizeof(m->info), 1, f) == 1;
+  ok = ok && m->info.n_ref >= 2 && m->info.n_ref < 65536 && m->info.slots >= 16 && (m->info.slots & (m->info.slots - 1)) == 0 &&
+       m->info.n_tiles >= 1 && m->info.n_entries < 0xFFFFFFFFull;
+  std::vector<SlotWord> slotmap;
+  std::vector<uint32_t> boff, bslot;
+  std::vector<uint2> ent;
+  if (ok) {
+    const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->info.n_entries;
+    m->sampled.resize((size_t)m->info.n_ref * 6);
+    slotmap.resize(words);
+    boff.resize((size_t)m->info.n_tiles * (nb + 1));
+    bslot.resize(nb);
+    ent.resize(ne);
+    ok = fread(m->sampled.data(), sizeof(float), m->sampled.size(), f) == m->sampled.size();
+    ok = ok && fread(slotmap.data(), sizeof(SlotWord), words, f) == words;
+    ok = ok && fread(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
+    ok = ok && fread(bslot.data(), sizeof(uint32_t), nb, f) == nb;
+    ok = ok && fread(ent.data(), sizeof(uint2), ne, f) == ne;
+  }
+  fclose(f);
+  if (!ok) {
+    delete m;
+    return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file", path);
+  }
+  m->refcount = 1;
+  ppf_status s = m->cloud.load_host(m->sampled.data(), m->info.n_ref, nullptr);
+  auto up = [&](auto& dst, const auto& src) -> ppf_status {
+    HIPCHK(dst.reserve(std::max<size_t>(src.size(), 1)));
+    if (!src.empty()) HIPCHK(hipMemcpy(dst.p, src.data(), src.size() * sizeof(src[0]), hipMemcpyHostToDevice));
+    return PPF_OK;
+  };
+  if (s == PPF_OK) s = up(m->slotmap, slotmap);
+  if (s == PPF_OK) s = up(m->bucket_off, boff);
+  if (s == PPF_OK) s = up(m->bucket_slot, bslot);
+  if (s == PPF_OK) s = up(m->entries, ent);
+  if (s != PPF_OK) {
+    delete m;
+    return s;
+  }
+  HIPCHK(hipGetDevice(&m->device));
+  *out = m;
+  return PPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+"""Host-side mirror of the operator interface the reference uses for the PPF path.
+
+Names, argument meaning and error behaviour follow ``cv::ppf_match_3d::PPF3DDetector`` exactly as
+/root/reference/include/CloudProcessing.h calls it:
+
+    PPF3DDetector(relativeSamplingStep, relativeDistanceStep)            :205,217,234
+    detector.trainModel(model N x 6 f32)                                 :236
+    detector.match(scene, results, relativeSceneSampleStep, relSceneDist):442
+    detector.match_S2B(scene, edge, results, step, dist)                 :495
+    detector.read(FileNode) / detector.write(FileStorage)                :112 / :250
+    Pose3D.pose, Pose3D.printPose()                 src/YOLO_cropping_ppf_test.cpp:124-125
+
+All compute goes through the C-ABI of libppf_hip.so (HIP kernels on gfx950).  Nothing here falls
+back to numpy/CPU: without the built extension the import of the library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import MatchParams, MatchStats, ModelInfo, Pose, PPFError, TrainParams, Vote, check, lib
+
+
+class Pose3D:
+    """cv::ppf_match_3d::Pose3D: 4x4 ``pose`` (model -> scene), quaternion ``q`` [w x y z], ``t``,
+    rotation ``angle``, ``alpha``, ``modelIndex``, ``numVotes``, ``residual``."""
+
+    __slots__ = ("pose", "q", "t", "angle", "alpha", "residual", "modelIndex", "numVotes")
+
+    def __init__(self, rec: Optional[Pose] = None):
+        if rec is None:
+            self.pose = np.eye(4)
+            self.q = np.array([1.0, 0, 0, 0])
+            self.t = np.zeros(3)
+            self.angle = self.alpha = self.residual = 0.0
+            self.modelIndex = self.numVotes = 0
+        else:
+            self.pose = np.array(rec.pose, dtype=np.float64).reshape(4, 4)
+            self.q = np.array(rec.q, dtype=np.float64)
+            self.t = np.array(rec.t, dtype=np.float64)
+            self.angle, self.alpha, self.residual = float(rec.angle), float(rec.alpha), float(rec.residual)
+            self.modelIndex, self.numVotes = int(rec.model_index), int(rec.num_votes)
+
+    def to_record(self) -> Pose:
+        rec = Pose()
+        rec.pose[:] = self.pose.reshape(16).tolist()
+        rec.q[:] = self.q.tolist()
+        rec.t[:] = self.t.tolist()
+        rec.angle, rec.alpha, rec.residual = self.angle, self.alpha, self.residual
+        rec.model_index, rec.num_votes = self.modelIndex, self.numVotes
+        return rec
+
+    def printPose(self):
+        print(f"\n-- Pose to Model Index {self.modelIndex}: NumVotes = {self.numVotes}, Residual = {self.residual}")
+        print(self.pose)
+
+    def clone(self) -> "Pose3D":
+        return Pose3D(self.to_record())
+
+
+def _cloud(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 6 or a.shape[0] < 1:
+        raise PPFError(_capi.PPF_ERR_INVALID, f"{name} must be an N x 6 float32 cloud (x y z nx ny nz)")
+    return a
+
+
+class _ModelHandle:
+    """Ref-counted owner of a ppf_model*: detector copies share it (the reference copies its
+    detector by value before every match, CloudProcessing.h:432,485)."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().ppf_model_release(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class PPF3DDetector:
+    def __init__(self, relativeSamplingStep: float = 0.05, relativeDistanceStep: float = 0.05, numAngles: float = 30,
+                 *, distance_from_distance_step: bool = False, max_tile_refs: int = 0):
+        self.sampling_step_relative = float(relativeSamplingStep)
+        self.distance_step_relative = float(relativeDistanceStep)
+        self.angle_step_relative = float(numAngles)
+        self._dist_flag = bool(distance_from_distance_step)
+        self._max_tile_refs = int(max_tile_refs)
+        self._position_threshold = -1.0
+        self._rotation_threshold = -1.0
+        self._use_weighted_avg = False
+        self._model: Optional[_ModelHandle] = None
+        self.last_stats: Optional[dict] = None
+
+    # -- copy semantics: share the trained table ------------------------------------------------
+    def __copy__(self):
+        d = PPF3DDetector(self.sampling_step_relative, self.distance_step_relative, self.angle_step_relative,
+                          distance_from_distance_step=self._dist_flag, max_tile_refs=self._max_tile_refs)
+        d._position_threshold, d._rotation_threshold = self._position_threshold, self._rotation_threshold
+        d._use_weighted_avg = self._use_weighted_avg
+        d._model = self._model
+        return d
+
+    @property
+    def trained(self) -> bool:
+        return self._model is not None
+
+    def setSearchParams(self, positionThreshold: float = -1, rotationThreshold: float = -1,
+                        useWeightedClustering: bool = False):
+        self._position_threshold = float(positionThreshold)
+        self._rotation_threshold = float(rotationThreshold)
+        self._use_weighted_avg = bool(useWeightedClustering)
+
+    # -- training ---------------------------------------------------------------------------------
+    def trainModel(self, model: np.ndarray, presampled: bool = False):
+        pc = _cloud(model, "model")
+        tp = TrainParams()
+        lib().ppf_default_train_params(C.byref(tp))
+        tp.relative_sampling_step = self.sampling_step_relative
+        tp.relative_distance_step = self.distance_step_relative
+        tp.num_angles = self.angle_step_relative
+        tp.presampled = int(presampled)
+        tp.distance_from_distance_step = int(self._dist_flag)
+        tp.max_tile_refs = self._max_tile_refs
+        out = C.c_void_p()
+        check(lib().ppf_model_train(pc.ctypes.data, pc.shape[0], pc.shape[1], C.byref(tp), C.byref(out)))
+        self._model = _ModelHandle(out.value)
+        return self
+
+    def info(self) -> dict:
+        self._require_trained()
+        mi = ModelInfo()
+        check(lib().ppf_model_get_info(self._model.ptr, C.byref(mi)))
+        return {k: getattr(mi, k) for k, _ in ModelInfo._fields_}
+
+    def sampled_model(self) -> np.ndarray:
+        n = self.info()["n_ref"]
+        out = np.empty((n, 6), dtype=np.float32)
+        check(lib().ppf_model_get_sampled(self._model.ptr, out.ctypes.data, n))
+        return out
+
+    def table(self) -> dict:
+        """CSR dump of the device table (inspection / tests)."""
+        mi = self.info()
+        nb, ne, T = mi["n_buckets"], mi["n_entries"], mi["n_tiles"]
+        slot = np.empty(nb, dtype=np.uint32)
+        off = np.empty(T * (nb + 1), dtype=np.uint32)
+        cell = np.empty(ne, dtype=np.int32)
+        alpha = np.empty(ne, dtype=np.float32)
+        check(lib().ppf_model_get_table(self._model.ptr, slot.ctypes.data, off.ctypes.data, cell.ctypes.data,
+                                        alpha.ctypes.data))
+        return {"bucket_slot": slot, "bucket_off": off.reshape(T, nb + 1), "entry_cell": cell, "entry_alpha": alpha}
+
+    # -- (de)serialisation: detector.write / detector.read -----------------------------------------
+    def write(self, path: str):
+        self._require_trained()
+        check(lib().ppf_model_save(self._model.ptr, str(path).encode()))
+
+    def read(self, path: str):
+        out = C.c_void_p()
+        check(lib().ppf_model_load(str(path).encode(), C.byref(out)))
+        self._model = _ModelHandle(out.value)
+        mi = self.info()
+        return self
+
+    # -- matching -----------------------------------------------------------------------------------
+    def _require_trained(self):
+        if self._model is None:
+            raise PPFError(_capi.PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training")
+
+    def _params(self, step, dist, presampled, ref_offset=0, ref_stride=1, skip_clustering=False) -> MatchParams:
+        mp = MatchParams()
+        lib().ppf_default_match_params(C.byref(mp))
+        mp.relative_scene_sample_step = float(step)
+        mp.relative_scene_distance = float(dist)
+        mp.position_threshold = self._position_threshold
+        mp.rotation_threshold = self._rotation_threshold
+        mp.use_weighted_avg = int(self._use_weighted_avg)
+        mp.presampled = int(presampled)
+        mp.ref_offset, mp.ref_stride = int(ref_offset), int(ref_stride)
+        mp.skip_clustering = int(skip_clustering)
+        return mp
+
+    def match(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
+              relativeSceneDistance: float = 0.03, *, presampled: bool = False, edge: Optional[np.ndarray] = None,
+              max_results: Optional[int] = None) -> List[Pose3D]:
+        """detector.match(): clustered poses sorted by votes (descending)."""
+        self._require_trained()
+        sc = _cloud(scene, "scene")
+        ed = _cloud(edge, "edge") if edge is not None else None
+        mp = self._params(relativeSceneSampleStep, relativeSceneDistance, presampled)
+        cap = max(sc.shape[0] // max(int(1.0 / relativeSceneSampleStep), 1) + 8, 8)
+        out = (Pose * cap)()
+        n = C.c_int(0)
+        check(lib().ppf_match(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1],
+                              ed.ctypes.data if ed is not None else None, ed.shape[0] if ed is not None else 0,
+                              ed.shape[1] if ed is not None else 6, C.byref(mp), out, cap, C.byref(n)))
+        res = [Pose3D(out[i]) for i in range(n.value)]
+        return res if max_results is None else res[:max_results]
+
+    def match_S2B(self, scene: np.ndarray, edge: np.ndarray, relativeSceneSampleStep: float = 0.05,
+                  relativeSceneDistance: float = 0.05, *, presampled: bool = False) -> List[Pose3D]:
+        """detector.match_S2B(): reference points from the surface cloud, paired points from the
+        edge cloud (the reference's own definition is not recoverable)."""
+        return self.match(scene, relativeSceneSampleStep, relativeSceneDistance, presampled=presampled, edge=edge)
+
+    def raw_votes(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
+                  relativeSceneDistance: float = 0.03, *, presampled: bool = False,
+                  edge: Optional[np.ndarray] = None, ref_offset: int = 0, ref_stride: int = 1) -> dict:
+        """Per-reference-point argmax triples {refIndMax, alphaIndMax, maxVotes} + raw poses +
+        exact counters: the bit-exact parity surface."""
+        self._require_trained()
+        sc = _cloud(scene, "scene")
+        ed = _cloud(edge, "edge") if edge is not None else None
+        mp = self._params(relativeSceneSampleStep, relativeSceneDistance, presampled, ref_offset, ref_stride, True)
+        cap = sc.shape[0] + 8
+        votes = (Vote * cap)()
+        poses = (Pose * cap)()
+        n = C.c_int(0)
+        st = MatchStats()
+        check(lib().ppf_raw_votes(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1],
+                                  ed.ctypes.data if ed is not None else None, ed.shape[0] if ed is not None else 0,
+                                  ed.shape[1] if ed is not None else 6, C.byref(mp), votes, poses, cap, C.byref(n),
+                                  C.byref(st)))
+        nr = n.value
+        triples = np.array([[votes[i].ref_ind_max, votes[i].alpha_ind_max, votes[i].max_votes] for i in range(nr)],
+                           dtype=np.uint32).reshape(nr, 3)
+        self.last_stats = {k: getattr(st, k) for k, _ in MatchStats._fields_}
+        return {"n_ref": nr, "triples": triples, "raw_poses": [Pose3D(poses[i]) for i in range(nr)],
+                "stats": self.last_stats}
+
+    def cluster(self, poses: List[Pose3D], num_poses: Optional[int] = None) -> List[Pose3D]:
+        """clusterPoses() on a caller-supplied list (e.g. gathered from several ranks)."""
+        self._require_trained()
+        n = len(poses)
+        arr = (Pose * max(n, 1))()
+        for i, p in enumerate(poses):
+            arr[i] = p.to_record()
+        out = (Pose * max(n, 1))()
+        nout = C.c_int(0)
+        mp = self._params(1.0, 0.05, True)
+        check(lib().ppf_cluster_poses(self._model.ptr, arr, n, n if num_poses is None else int(num_poses),
+                                      C.byref(mp), out, max(n, 1), C.byref(nout)))
+        return [Pose3D(out[i]) for i in range(nout.value)]
+
+
+def samplePCByQuantization(pc: np.ndarray, relative_step: float) -> np.ndarray:
+    a = _cloud(pc, "cloud")
+    n = C.c_int(0)
+    out = np.empty((a.shape[0], 6), dtype=np.float32)
+    check(lib().ppf_sample_cloud(a.ctypes.data, a.shape[0], a.shape[1], float(relative_step), out.ctypes.data,
+                                 a.shape[0], C.byref(n)))
+    return out[: n.value].copy()
+
+
+def transformPCPose(pc: np.ndarray, pose: np.ndarray) -> np.ndarray:
+    a = _cloud(pc, "cloud")
+    T = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
+    out = np.empty((a.shape[0], 6), dtype=np.float32)
+    check(lib().ppf_transform_pc_pose(a.ctypes.data, a.shape[0], a.shape[1],
+                                      T.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data))
+    return out
