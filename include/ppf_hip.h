@@ -43,6 +43,7 @@
 #ifndef PPF_HIP_H
 #define PPF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -179,6 +180,13 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
 /* Wait for the workspace's last call and copy results out (any pointer may be NULL). */
 ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* raw_poses, int cap_ref, int* n_ref,
                                  ppf_pose* poses, int cap_poses, int* n_poses, ppf_match_stats* stats);
+/* exact per-reference-point counters of the last call: accumulator increments and pairs hashed */
+ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref, uint64_t* pairs_per_ref, int cap);
+/* Full accumulators (n_ref x n_model*num_angles u32, the reference's `accumulator` array before its
+ * argmax scan) of the voted reference points; presampled clouds only.  Debug / parity surface. */
+ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                                  int estride, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
+                                  int* n_ref);
 /* device pointer to the per-reference pose records of the last call (n_ref x ppf_pose), for a
  * collective gather without a host copy */
 ppf_status ppf_workspace_device_poses(ppf_workspace* ws, void** d_raw_poses, int* n_ref);

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _pose_close(a, b, diameter):
-    dR = a[:3, :3] @ b[:3, :3].T
-    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
-    return ang <= 1e-6 and np.linalg.norm(a[:3, 3] - b[:3, 3]) <= 1e-9 * diameter
+    """Clustered poses: rotation entries within 1e-6 (<= 1e-6 rad), translation within 1e-9 x diameter.
+    (Cluster-averaged quaternions are not re-normalised by the reference's library, so R is compared
+    entry-wise rather than through a rotation angle.)"""
+    return np.abs(a[:3, :3] - b[:3, :3]).max() <= 1e-6 and np.linalg.norm(a[:3, 3] - b[:3, 3]) <= 1e-9 * diameter
 
 
 def _check_against_oracle(det, ora, scene, step, dist, presampled, edge=None):

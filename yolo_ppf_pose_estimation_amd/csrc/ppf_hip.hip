@@ -244,6 +244,7 @@ struct VoteArgs {
   uint2* partial;               /* [n_ref * n_tiles] {max votes, local flat index} */
   unsigned long long* cellsum;  /* [n_ref * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref] pairs hashed */
+  uint32_t* acc_dump;           /* optional [n_ref][n_model*num_angles] full accumulators (debug/tests) */
 };
 
 /*
@@ -285,7 +286,11 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(VoteArgs a) {
   const int A = a.num_angles;
   const float S = (float)((double)A / (4 * PPF_PI));
   const float O = 0.5f * (float)A;
+#ifdef PPF_FORCE_EXACT
+  const float G = 2.0f;
+#else
   const float G = 5e-7f * (float)A;
+#endif
   unsigned long long my_pairs = 0;
 
   for (int base = wave * WAVE; base < a.paired.n; base += VOTE_BLOCK) {
@@ -317,8 +322,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(VoteArgs a) {
       const uint32_t o = __builtin_amdgcn_readlane(off, l);
       const uint32_t c = __builtin_amdgcn_readlane(cnt, l);
       const float asf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(as32), l));
-      const double asd = ppf_bits2d((uint64_t)__builtin_amdgcn_readlane(as_lo, l) |
-                                    ((uint64_t)__builtin_amdgcn_readlane(as_hi, l) << 32));
+      /* readlane returns a signed int: go through uint32_t so the low word is not sign-extended */
+      const double asd = ppf_bits2d((uint64_t)(uint32_t)__builtin_amdgcn_readlane(as_lo, l) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(as_hi, l) << 32));
       for (uint32_t e = lane; e < c; e += WAVE) {
         const uint2 ent = entries[o + e];
         const float am = __uint_as_float(ent.y);
@@ -332,6 +338,11 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(VoteArgs a) {
     }
   }
   __syncthreads();
+
+  if (a.acc_dump) {
+    uint32_t* dst = a.acc_dump + (size_t)r * a.n_model * a.num_angles + (size_t)tile_base * a.num_angles;
+    for (int c = tid; c < cells; c += VOTE_BLOCK) dst[c] = acc[c];
+  }
 
   /* argmax in the reference's scan order (model ref ascending, alpha bin ascending, strict >)
    * == smallest flat index among the maxima; plus the exact vote total of the tile. */
@@ -583,6 +594,7 @@ struct ppf_workspace {
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool pending = false;
+  uint32_t* acc_dump = nullptr; /* set by ppf_debug_accumulators for one call */
 };
 
 namespace {
@@ -989,6 +1001,7 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   va.partial = ws->partial.p;
   va.cellsum = ws->counters.p;
   va.pairs = ws->counters.p + (size_t)n_ref * T;
+  va.acc_dump = ws->acc_dump;
   const size_t lds = (size_t)LDS_HEADER + (size_t)m->info.tile_refs * m->info.num_angles * 4;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
@@ -1059,6 +1072,51 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
     *n_poses = 0;
   }
   if (stats) *stats = ws->stats;
+  return PPF_OK;
+}
+
+static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                           int estride, const ppf_match_params* params, ppf_workspace* ws);
+
+ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref, uint64_t* pairs_per_ref, int cap) {
+  if (!ws || !ws->pending) return fail(PPF_ERR_INVALID, "ppf_workspace_ref_counters: no call in this workspace");
+  HIPCHK(hipStreamSynchronize(ws->stream));
+  const int nr = ws->n_ref;
+  if (cap < nr) return fail(PPF_ERR_CAPACITY, "ppf_workspace_ref_counters: need room for %d reference points", nr);
+  if (nr == 0) return PPF_OK;
+  const int T = ws->model->info.n_tiles;
+  std::vector<unsigned long long> h((size_t)nr * T + nr);
+  HIPCHK(hipMemcpy(h.data(), ws->counters.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int r = 0; r < nr; r++) {
+    unsigned long long v = 0;
+    for (int t = 0; t < T; t++) v += h[(size_t)r * T + t];
+    if (votes_per_ref) votes_per_ref[r] = v;
+    if (pairs_per_ref) pairs_per_ref[r] = h[(size_t)nr * T + r];
+  }
+  return PPF_OK;
+}
+
+ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
+                                  int estride, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
+                                  int* n_ref) {
+  if (!m || !acc || !params) return fail(PPF_ERR_INVALID, "ppf_debug_accumulators: bad argument");
+  ppf_match_params p = *params;
+  const size_t per_ref = (size_t)m->info.n_ref * m->info.num_angles;
+  const int scene_step = (int)(1.0 / p.relative_scene_sample_step);
+  if (!p.presampled) return fail(PPF_ERR_INVALID, "ppf_debug_accumulators: presampled clouds only");
+  const int n_ref_total = (ns + scene_step - 1) / scene_step;
+  const int nr = n_ref_total > p.ref_offset ? (n_ref_total - p.ref_offset + p.ref_stride - 1) / p.ref_stride : 0;
+  if (cap_words < per_ref * nr) return fail(PPF_ERR_CAPACITY, "ppf_debug_accumulators: need %zu words", per_ref * nr);
+  DevBuf<uint32_t> dump;
+  HIPCHK(dump.reserve(std::max<size_t>(per_ref * nr, 1)));
+  HIPCHK(hipMemset(dump.p, 0, per_ref * nr * sizeof(uint32_t)));
+  ppf_workspace ws;
+  ws.acc_dump = dump.p;
+  p.skip_clustering = 1;
+  ppf_status s = run_host(m, scene, ns, sstride, edge, ne, estride, &p, &ws);
+  if (s != PPF_OK) return s;
+  HIPCHK(hipMemcpy(acc, dump.p, per_ref * nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (n_ref) *n_ref = nr;
   return PPF_OK;
 }
 

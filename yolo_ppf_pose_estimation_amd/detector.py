@@ -235,6 +235,25 @@ class PPF3DDetector:
         return {"n_ref": nr, "triples": triples, "raw_poses": [Pose3D(poses[i]) for i in range(nr)],
                 "stats": self.last_stats}
 
+    def accumulators(self, scene: np.ndarray, relativeSceneSampleStep: float, *, edge: Optional[np.ndarray] = None,
+                     ref_offset: int = 0, ref_stride: int = 1) -> np.ndarray:
+        """Full Hough accumulators (n_ref, N_m, numAngles) of presampled clouds (debug / parity)."""
+        self._require_trained()
+        sc = _cloud(scene, "scene")
+        ed = _cloud(edge, "edge") if edge is not None else None
+        mp = self._params(relativeSceneSampleStep, 0.05, True, ref_offset, ref_stride, True)
+        mi = self.info()
+        step = int(1.0 / relativeSceneSampleStep)
+        n_tot = (sc.shape[0] + step - 1) // step
+        nr = max((n_tot - ref_offset + ref_stride - 1) // ref_stride, 0)
+        acc = np.zeros((max(nr, 1), mi["n_ref"], mi["num_angles"]), dtype=np.uint32)
+        n = C.c_int(0)
+        check(lib().ppf_debug_accumulators(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1],
+                                           ed.ctypes.data if ed is not None else None,
+                                           ed.shape[0] if ed is not None else 0, ed.shape[1] if ed is not None else 6,
+                                           C.byref(mp), acc.ctypes.data, acc.size, C.byref(n)))
+        return acc[: n.value]
+
     def cluster(self, poses: List[Pose3D], num_poses: Optional[int] = None) -> List[Pose3D]:
         """clusterPoses() on a caller-supplied list (e.g. gathered from several ranks)."""
         self._require_trained()
