@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — PPF pair-matches/s of the MI355X voting engine on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one synthetic YOLO crop per rank: pair features + hash +
+table lookup + Hough voting (k_vote) + argmax + pose assembly (k_finalize) + pose clustering, with
+the crop and the model table already resident in HBM.  At N=1 the workload is BASELINE.json
+configs[1] (C2): the bottle model sampled to 2,000 points vs one 50,000-point synthetic crop
+(seed 12345), presampled so all 50k points vote, reference stride 20 -> 2,500 reference points.
+At N>1 every rank matches its own crop (config C3, seeds 1000+rank; weak scaling) and the only
+collective is one all_gather (RCCL) of each rank's top poses per step.
+
+The line printed by rank 0 carries
+  value        whole-job pair-matches (accumulator increments, exact integer) per second
+  roofline     the voting kernel against the HBM roofline: algorithmic bytes per launch
+               (SURVEY.md §8d / DESIGN.md §5) / its average device time measured with HIP events
+               on the launch stream
+  cpu_baseline the CPU oracle (kind "port": our restatement of the reference's library path,
+               OpenMP over reference points where upstream parallelises) timed on a bounded
+               sample of the same workload, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+MODEL_STEP = 0.036      # bottle -> 2,000 sampled model points
+SCENE_POINTS = 50000
+SCENE_STEP = 1.0 / 20.0  # reference stride 20 -> 2,500 reference points
+TOP_K = 5                # poses kept per crop (CloudProcessing.h:455,508)
+
+
+def algorithmic_bytes(n_ref, n_model, num_angles, n_pairs, n_votes):
+    """per reference point 24 B (its xyzn) + accumulator clear and scan
+    2 x 4 x N_m x A + 12 B result; per scene pair 24 B (xyzn) + 8 B (bucket header); per vote 8 B
+    model entry + 8 B accumulator read-modify-write."""
+    return n_ref * (24 + 2 * 4 * n_model * num_angles + 12) + n_pairs * 32 + n_votes * 16
+
+
+def cpu_baseline(bottle, scene, n_ref_total, target_seconds=15.0):
+    """Oracle (CPU restatement) on a bounded sample of the step's reference points."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    threads = oracle_lib.max_threads()
+    ora = oracle_lib.OracleDetector(MODEL_STEP, 0.05).train_model(bottle)
+    step = int(1.0 / SCENE_STEP)
+    # calibrate on 2 reference points per thread, then size the sample for ~target_seconds
+    probe = [(k * (n_ref_total // (2 * threads))) * step for k in range(2 * threads)]
+    t0 = time.perf_counter()
+    r = ora.match(scene, relative_scene_sample_step=SCENE_STEP, presampled=True, ref_list=probe, threads=threads,
+                  cluster=False)
+    dt = time.perf_counter() - t0
+    n_sample = int(min(n_ref_total, max(2 * threads, (target_seconds / max(dt, 1e-3)) * len(probe))))
+    n_sample = max(threads, (n_sample // threads) * threads)
+    refs = [int(k * n_ref_total / n_sample) * step for k in range(n_sample)]
+    t0 = time.perf_counter()
+    r = ora.match(scene, relative_scene_sample_step=SCENE_STEP, presampled=True, ref_list=refs, threads=threads,
+                  cluster=False)
+    dt = time.perf_counter() - t0
+    votes = int(r["votes_per_ref"].sum())
+    return {
+        "value": votes / dt,
+        "unit": "pair-matches/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_sample} of {n_ref_total} reference points (evenly spaced) of the same crop, all "
+                  f"{scene.shape[0]} paired points each, {votes} pair-matches in {dt:.2f} s, "
+                  f"{n_sample / dt:.2f} poses/s",
+        "poses_per_s": n_sample / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from yolo_ppf_pose_estimation_amd import synth
+    from yolo_ppf_pose_estimation_amd._capi import Pose
+    from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+    from yolo_ppf_pose_estimation_amd.device import Workspace
+    import ctypes as C
+
+    bottle = np.load(os.path.join(ROOT, "tests", "golden", "bottle_model_xyzn.npy"))
+    det = PPF3DDetector(MODEL_STEP, 0.05).trainModel(bottle)
+    info = det.info()
+    seed = 12345 if world == 1 else 1000 + rank
+    scene, _ = synth.make_scene(bottle, n_points=SCENE_POINTS, seed=seed)
+    d_scene = torch.from_numpy(scene).cuda()
+    stream = torch.cuda.Stream()
+    ws = Workspace(timing=True)
+    n_ref_total = (SCENE_POINTS + int(1.0 / SCENE_STEP) - 1) // int(1.0 / SCENE_STEP)
+    pose_words = C.sizeof(Pose) // 8
+    top = torch.zeros((TOP_K, pose_words), dtype=torch.float64, device="cuda")
+    gathered = torch.zeros((world * TOP_K, pose_words), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        with torch.cuda.stream(stream):
+            ws.match_device(det, d_scene.data_ptr(), SCENE_POINTS, 6, SCENE_STEP, 0.05, presampled=True,
+                            stream=stream.cuda_stream)
+            res = ws.results(n_ref_total, want_poses=True)  # waits for the stream, clusters the poses
+            if world > 1:
+                recs = (Pose * TOP_K)()
+                for k, p in enumerate(res["poses"][:TOP_K]):
+                    recs[k] = p.to_record()
+                host = np.frombuffer(recs, dtype=np.float64).reshape(TOP_K, pose_words)
+                top.copy_(torch.from_numpy(host.copy()), non_blocking=False)
+                dist.all_gather_into_tensor(gathered, top)  # the path's only collective: final pose gather
+        return res
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    vote_ms, votes, pairs = [], 0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        st = res["stats"]
+        vote_ms.append(st["ms_vote_kernel"])
+        votes += st["n_votes"]
+        pairs += st["n_pairs"]
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    n_poses_clustered = len(res["poses"])
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(votes), float(pairs)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    all_votes, all_pairs = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        st = res["stats"]
+        avg_vote_s = float(np.mean(vote_ms)) * 1e-3
+        abytes = algorithmic_bytes(st["n_ref"], info["n_ref"], info["num_angles"], st["n_pairs"], st["n_votes"])
+        hbm_only = abytes - 8 * st["n_votes"] - st["n_ref"] * 2 * 4 * info["n_ref"] * info["num_angles"]
+        achieved = abytes / avg_vote_s / 1e9
+        line = {
+            "metric": "PPF pair-matches/sec (accumulator votes) per cropped scene",
+            "value": all_votes / elapsed,
+            "unit": "pair-matches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 votes / f64 pair features",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
+                            "(presampled, every point paired), reference stride 20 -> 2,500 reference points, "
+                            "30 alpha bins" + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"),
+                "n_model": info["n_ref"], "n_scene": SCENE_POINTS, "n_ref": st["n_ref"],
+                "n_tiles": info["n_tiles"], "tile_refs": info["tile_refs"],
+                "table_buckets": info["n_buckets"], "table_entries": info["n_entries"],
+                "parallelism": f"crops sharded 1/GPU x{world}, RCCL all_gather of top-{TOP_K} poses only",
+            },
+            "poses_per_s": world * st["n_ref"] * args.steps / elapsed,
+            "scene_pairs_per_s": all_pairs / elapsed,
+            "votes_per_step_per_gpu": st["n_votes"],
+            "clustered_poses": n_poses_clustered,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_vote",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": abytes,
+                "hbm_only_algorithmic_bytes_per_launch": hbm_only,
+                "avg_kernel_ms": avg_vote_s * 1e3,
+                "note": "16 B/vote counts the 8 B accumulator RMW although the accumulator is LDS-resident; "
+                        "hbm_only_* removes the LDS part (8 B/vote + clear/scan)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(bottle, scene, n_ref_total, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,8 @@
  *                 in one 16-byte load (the reference indexes 2^k slots by hash % slots and never
  *                 compares keys, so only "which slots are non-empty" has to be kept)
  *   bucket_off    n_tiles x (n_buckets+1) u32 CSR offsets, one CSR per accumulator tile
- *   entries       {i32 cell_base = local_model_ref*numAngles, f32 alpha_m}: 8 B per model pair
+ *   (each bucket's entries are stored interleaved over their 32 LDS bank classes, see place_entry)
+ *   entries       {u32 LDS byte offset of the model ref's accumulator row = (guard + local_ref*pitch)*4, f32 alpha_m}: 8 B per model pair
  *   accumulator   LDS, tile_refs x numAngles u32 per workgroup (one workgroup = one scene
  *                 reference point x one tile of model reference points)
  *
@@ -75,10 +76,8 @@ struct DevBuf {
   size_t bytes() const { return cap * sizeof(T); }
 };
 
-constexpr int WAVE = 64;
-constexpr int VOTE_BLOCK = 1024;
-constexpr int LDS_HEADER = 256;                    /* bytes in front of the accumulator: frame + reduce scratch */
 constexpr int LDS_ACC_BUDGET = 128 * 1024;         /* accumulator bytes per workgroup (160 KiB LDS per CU) */
+constexpr size_t HIT_BYTES_BUDGET = 4ull << 30;    /* hit-list scratch per batch of reference points */
 constexpr float SPILL_ALPHA_MIN = 3.1415f;         /* entries with alpha_m >= this can reach alpha bin == numAngles */
 
 }  // namespace
@@ -86,6 +85,10 @@ constexpr float SPILL_ALPHA_MIN = 3.1415f;         /* entries with alpha_m >= th
 /* ============================================================================================ */
 /* device code                                                                                    */
 /* ============================================================================================ */
+
+/* LDS accumulator geometry (see ppf_match_kernels.h): row pitch in words and guard words below cell 0 */
+__host__ __device__ constexpr int vote_pitch(int A) { return (A + 1) | 1; }
+__host__ __device__ constexpr int vote_guard(int A) { return 64 + 2 * vote_pitch(A); }
 
 struct CloudSoA {
   const float *x, *y, *z, *nx, *ny, *nz;
@@ -163,10 +166,44 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
 }
 
 /* phase 0: count entries per (tile, bucket); phase 1: scatter through cursors */
+/* LDS bank class of a table entry: the bank its vote lands on when alpha_s == 0.  For any other
+ * alpha_s the bins of a bucket's entries shift together (up to one bin of jitter), so entries of
+ * distinct classes keep landing on distinct banks. */
+__device__ __forceinline__ uint32_t entry_bank_class(uint32_t row_bytes, float alpha_m, int num_angles) {
+  const int bin0 = (int)(alpha_m * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles);
+  return (row_bytes / 4u + (uint32_t)bin0) & 31u;
+}
+
+/* Place one entry.  Buckets are stored bank-interleaved: the entries of a (tile, bucket) are dealt
+ * round-robin over their 32 bank classes, so 32 consecutive entries (one LDS lane group of a wave's
+ * ds_add) address 32 different banks and never the same cell twice.  With per-class counts cc[] and
+ * the entry's rank k inside its class c, its slot is  sum_c' min(cc[c'], k) + #{c' < c : cc[c'] > k}. */
+__device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_bytes, float am, int num_angles,
+                                            uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                            uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
+                                            uint2* __restrict__ entries) {
+  const uint32_t c = entry_bank_class(row_bytes, am, num_angles);
+  if (phase == 0) {
+    atomicAdd(&counts[tb], 1u);
+    atomicAdd(&class_cnt[tb * 32 + c], 1u);
+    return;
+  }
+  const uint32_t k = atomicAdd(&class_cur[tb * 32 + c], 1u);
+  uint32_t pos = 0;
+#pragma unroll 8
+  for (uint32_t cc = 0; cc < 32; cc++) {
+    const uint32_t n = class_cnt[tb * 32 + cc];
+    pos += min(n, k) + ((cc < c && n > k) ? 1u : 0u);
+  }
+  entries[offsets[tb] + pos] = make_uint2(row_bytes, __float_as_uint(am));
+}
+
+/* phase 0: count entries per (tile, bucket) and per bank class; phase 1: place them */
 __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
                             const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int n_tiles,
-                            int num_angles, uint32_t* __restrict__ counts_or_cursor, uint2* __restrict__ entries,
-                            uint32_t* __restrict__ bucket_slot, int phase) {
+                            int num_angles, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                            uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
+                            uint2* __restrict__ entries, uint32_t* __restrict__ bucket_slot, int phase) {
   const size_t total = (size_t)n_model * n_model;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -176,23 +213,15 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
   const int b = slot_to_bucket(slotmap, slot);
   const int tile = i / tile_refs;
   const float am = pair_alpha[idx];
-  if (phase == 0) {
-    atomicAdd(&counts_or_cursor[(size_t)tile * n_buckets + b], 1u);
-    if (bucket_slot) bucket_slot[b] = slot;
-  } else {
-    uint32_t pos = atomicAdd(&counts_or_cursor[(size_t)tile * n_buckets + b], 1u);
-    entries[pos] = make_uint2((uint32_t)((i - tile * tile_refs) * num_angles), __float_as_uint(am));
-  }
+  if (phase == 0 && bucket_slot) bucket_slot[b] = slot;
+  place_entry(phase, (size_t)tile * n_buckets + b,
+              (uint32_t)((vote_guard(num_angles) + (i - tile * tile_refs) * vote_pitch(num_angles)) * 4), am, num_angles,
+              counts, offsets, class_cnt, class_cur, entries);
   /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
-   * that point lives in the next tile, the entry is mirrored there with local ref -1. */
-  if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1) {
-    if (phase == 0) {
-      atomicAdd(&counts_or_cursor[(size_t)(tile + 1) * n_buckets + b], 1u);
-    } else {
-      uint32_t pos = atomicAdd(&counts_or_cursor[(size_t)(tile + 1) * n_buckets + b], 1u);
-      entries[pos] = make_uint2((uint32_t)(-num_angles), __float_as_uint(am));
-    }
-  }
+   * that point lives in the next tile, the entry is mirrored there: bin A -> cell 0, others -> guard. */
+  if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1)
+    place_entry(phase, (size_t)(tile + 1) * n_buckets + b, (uint32_t)((vote_guard(num_angles) - num_angles) * 4), am,
+                num_angles, counts, offsets, class_cnt, class_cur, entries);
 }
 
 /* ---- exclusive scan (u32), 1024 elements per block ------------------------------------------- */
@@ -228,158 +257,7 @@ __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restric
   if (i < n) out[i] += block_off[i / 1024];
 }
 
-/* ---- voting (row A5-match) ------------------------------------------------------------------- */
-struct VoteArgs {
-  CloudSoA surf;   /* reference points come from here */
-  CloudSoA paired; /* second points of the pairs (== surf for match, edge cloud for match_S2B) */
-  int same_cloud;
-  int scene_step, ref_offset, ref_stride, n_ref;
-  const SlotWord* slotmap;
-  uint32_t slot_mask;
-  const uint32_t* bucket_off;
-  int n_buckets;
-  const uint2* entries;
-  int n_tiles, tile_refs, num_angles, n_model;
-  double angle_step, dist_step;
-  uint2* partial;               /* [n_ref * n_tiles] {max votes, local flat index} */
-  unsigned long long* cellsum;  /* [n_ref * n_tiles] sum of the tile's accumulator == votes cast */
-  unsigned long long* pairs;    /* [n_ref] pairs hashed */
-  uint32_t* acc_dump;           /* optional [n_ref][n_model*num_angles] full accumulators (debug/tests) */
-};
-
-/*
- * One workgroup = one scene reference point x one tile of model reference points.
- * Each wave walks its share of the paired cloud 64 points at a time: lane j builds the pair
- * feature (fp64, deterministic math), hashes it, maps the slot to a bucket and computes alpha_s.
- * Then the wave visits the hit buckets one after another (ballot + readlane), all 64 lanes
- * streaming the bucket's entries (coalesced 8-byte loads) and casting one LDS atomic per entry.
- *
- * Alpha bin, exactly: bin = (int)(A*(alpha_m - alpha_s + 2pi)/(4pi)) in fp64.  The fast path
- * evaluates q = (alpha_m - alpha_s)*A/(4pi) + A/2 in fp32 (|error| <= 9e-8*A) and
- * takes trunc(q) whenever q is farther than G = 5e-7*A from an integer; otherwise (about 3e-5 of
- * the votes) the lane re-evaluates the fp64 chain.  Both paths give the oracle's integer.
- */
-__global__ __launch_bounds__(VOTE_BLOCK) void k_vote(VoteArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  double* frame = reinterpret_cast<double*>(smem);
-  uint32_t* acc = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = blockIdx.x / a.n_tiles, tile = blockIdx.x - r * a.n_tiles;
-  const int i_ref = (a.ref_offset + r * a.ref_stride) * a.scene_step;
-  const int tile_base = tile * a.tile_refs;
-  const int refs_here = min(a.tile_refs, a.n_model - tile_base);
-  const int cells = refs_here * a.num_angles;
-
-  for (int c = tid; c < cells; c += VOTE_BLOCK) acc[c] = 0u;
-  const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
-  if (tid == 0) ppf_transform_rt(p1, n1, frame, frame + 9);
-  __syncthreads();
-  double R[9], t[3];
-#pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = frame[k];
-#pragma unroll
-  for (int k = 0; k < 3; k++) t[k] = frame[9 + k];
-
-  const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
-  const uint2* __restrict__ entries = a.entries;
-  const int A = a.num_angles;
-  const float S = (float)((double)A / (4 * PPF_PI));
-  const float O = 0.5f * (float)A;
-#ifdef PPF_FORCE_EXACT
-  const float G = 2.0f;
-#else
-  const float G = 5e-7f * (float)A;
-#endif
-  unsigned long long my_pairs = 0;
-
-  for (int base = wave * WAVE; base < a.paired.n; base += VOTE_BLOCK) {
-    const int j = base + lane;
-    uint32_t off = 0, cnt = 0;
-    double as = 0.0;
-    if (j < a.paired.n && !(a.same_cloud && j == i_ref)) {
-      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
-      const ppf_vec3 n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
-      double f[4] = {0, 0, 0, 0};
-      ppf_pair_feature(p1, n1, p2, n2, f);
-      const uint32_t slot = ppf_hash_feature(f, a.angle_step, a.dist_step) & a.slot_mask;
-      const ppf_vec3 rp = ppf_mul33(R, p2);
-      if (ppf_alpha_in_frame(t[1] + rp.y, t[2] + rp.z, &as)) {
-        my_pairs++;
-        const int b = slot_to_bucket(a.slotmap, slot);
-        if (b >= 0) {
-          off = boff[b];
-          cnt = boff[b + 1] - off;
-        }
-      }
-    }
-    unsigned long long hit = __ballot(cnt > 0);
-    const float as32 = (float)as;
-    const uint32_t as_lo = (uint32_t)ppf_d2bits(as), as_hi = (uint32_t)(ppf_d2bits(as) >> 32);
-    while (hit) {
-      const int l = __ffsll((long long)hit) - 1;
-      hit &= hit - 1;
-      const uint32_t o = __builtin_amdgcn_readlane(off, l);
-      const uint32_t c = __builtin_amdgcn_readlane(cnt, l);
-      const float asf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(as32), l));
-      /* readlane returns a signed int: go through uint32_t so the low word is not sign-extended */
-      const double asd = ppf_bits2d((uint64_t)(uint32_t)__builtin_amdgcn_readlane(as_lo, l) |
-                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(as_hi, l) << 32));
-      for (uint32_t e = lane; e < c; e += WAVE) {
-        const uint2 ent = entries[o + e];
-        const float am = __uint_as_float(ent.y);
-        const float q = __builtin_fmaf(am - asf, S, O);
-        int k = (int)q;
-        const float fr = q - (float)k;
-        if (fr < G || fr > 1.0f - G) k = ppf_alpha_bin_exact(am, asd, A);
-        const int idx = (int)ent.x + k;
-        if ((unsigned)idx < (unsigned)cells) atomicAdd(&acc[idx], 1u);
-      }
-    }
-  }
-  __syncthreads();
-
-  if (a.acc_dump) {
-    uint32_t* dst = a.acc_dump + (size_t)r * a.n_model * a.num_angles + (size_t)tile_base * a.num_angles;
-    for (int c = tid; c < cells; c += VOTE_BLOCK) dst[c] = acc[c];
-  }
-
-  /* argmax in the reference's scan order (model ref ascending, alpha bin ascending, strict >)
-   * == smallest flat index among the maxima; plus the exact vote total of the tile. */
-  uint32_t bv = 0, bi = 0xFFFFFFFFu;
-  unsigned long long sum = 0;
-  for (int c = tid; c < cells; c += VOTE_BLOCK) {
-    const uint32_t v = acc[c];
-    sum += v;
-    if (v > bv) { bv = v; bi = (uint32_t)c; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t v2 = __shfl_down(bv, o), i2 = __shfl_down(bi, o);
-    sum += __shfl_down(sum, o);
-    my_pairs += __shfl_down(my_pairs, o);
-    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
-  }
-  __syncthreads(); /* everyone is done reading acc/frame; reuse the header as scratch */
-  uint32_t* red_v = reinterpret_cast<uint32_t*>(smem); /* 16 + 16 words of the header */
-  uint32_t* red_i = red_v + 16;
-  if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
-  __syncthreads();
-  if (wave == 0) {
-    uint32_t v = (lane < VOTE_BLOCK / WAVE) ? red_v[lane] : 0u;
-    uint32_t ix = (lane < VOTE_BLOCK / WAVE) ? red_i[lane] : 0xFFFFFFFFu;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const uint32_t v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
-      if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
-    }
-    if (lane == 0) a.partial[(size_t)r * a.n_tiles + tile] = make_uint2(v, ix);
-  }
-  if (lane == 0) {
-    atomicAdd(&a.cellsum[(size_t)r * a.n_tiles + tile], sum);
-    if (tile == 0) atomicAdd(&a.pairs[r], my_pairs);
-  }
-}
+#include "ppf_match_kernels.h"
 
 /* ---- finalize: merge tiles, assemble the raw pose (rows A5 tail + A8) ---------------------- */
 struct FinalArgs {
@@ -581,6 +459,10 @@ struct ppf_workspace {
   CloudDev surf, edge;
   DevBuf<float> staging;
   DevBuf<uint2> partial;
+  DevBuf<double> frames;
+  DevBuf<HitRec> hits;
+  DevBuf<uint2> keys_a, keys_b;
+  DevBuf<uint32_t> hit_count;
   DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
@@ -592,7 +474,7 @@ struct ppf_workspace {
   int n_ref = 0, n_ref_total = 0, rows = 0;
   hipStream_t stream = nullptr;
   bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool pending = false;
   uint32_t* acc_dump = nullptr; /* set by ppf_debug_accumulators for one call */
 };
@@ -777,10 +659,15 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(offsets.reserve(ncnt));
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
+  DevBuf<uint32_t> class_cnt, class_cur; /* per (tile, bucket, bank class) */
+  HIPCHK(class_cnt.reserve(ncnt * 32));
+  HIPCHK(class_cur.reserve(ncnt * 32));
+  HIPCHK(hipMemsetAsync(class_cnt.p, 0, ncnt * 32 * sizeof(uint32_t), st));
+  HIPCHK(hipMemsetAsync(class_cur.p, 0, ncnt * 32 * sizeof(uint32_t), st));
   const unsigned nblk = (unsigned)((NN + 255) / 256);
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
-                                                m->info.tile_refs, T, m->info.num_angles, counts.p, nullptr,
-                                                m->bucket_slot.p, 0);
+                                                m->info.tile_refs, T, m->info.num_angles, counts.p, nullptr, class_cnt.p,
+                                                class_cur.p, nullptr, m->bucket_slot.p, 0);
   HIPCHK(hipGetLastError());
   s = device_exclusive_scan(counts.p, offsets.p, ncnt, st);
   if (s != PPF_OK) return s;
@@ -795,11 +682,9 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(m->bucket_off.p + (size_t)t * (n_buckets + 1), offsets.p + (size_t)t * n_buckets,
                           (size_t)(n_buckets + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   HIPCHK(m->entries.reserve(std::max<uint32_t>(n_entries, 1)));
-  /* cursors start at the offsets */
-  HIPCHK(hipMemcpyAsync(counts.p, offsets.p, ncnt * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
-                                                m->info.tile_refs, T, m->info.num_angles, counts.p, m->entries.p,
-                                                nullptr, 1);
+                                                m->info.tile_refs, T, m->info.num_angles, counts.p, offsets.p, class_cnt.p,
+                                                class_cur.p, m->entries.p, nullptr, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
@@ -845,7 +730,7 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   m->info.position_threshold_default = params->relative_sampling_step;
   m->info.rotation_threshold_default = ((360 / angle_step) / 180.0 * PPF_PI);
   const int A = m->info.num_angles;
-  int max_refs = LDS_ACC_BUDGET / (4 * A);
+  int max_refs = (LDS_ACC_BUDGET - 4 * vote_guard(A)) / (4 * vote_pitch(A));
   if (params->max_tile_refs > 0) max_refs = std::min(max_refs, params->max_tile_refs);
   if (max_refs < 1) {
     delete m;
@@ -897,7 +782,10 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
     std::vector<uint2> e(ne);
     HIPCHK(hipMemcpy(e.data(), m->entries.p, ne * sizeof(uint2), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < ne; k++) {
-      if (entry_cell) entry_cell[k] = (int32_t)e[k].x;
+      if (entry_cell) { /* byte offset of the row -> reference layout local_ref*numAngles (mirrored spill entries: -numAngles) */
+        const int32_t w = (int32_t)(e[k].x / 4) - vote_guard(m->info.num_angles);
+        entry_cell[k] = w < 0 ? -m->info.num_angles : (w / vote_pitch(m->info.num_angles)) * m->info.num_angles;
+      }
       if (entry_alpha) memcpy(&entry_alpha[k], &e[k].y, 4);
     }
   }
@@ -988,11 +876,11 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   if (ws->timing) HIPCHK(hipEventRecord(ws->ev[0], st));
   HIPCHK(hipMemsetAsync(ws->counters.p, 0, n_cnt * sizeof(unsigned long long), st));
 
-  VoteArgs va;
+  MatchArgs va;
   va.surf = ws->surf.view();
   va.paired = d_edge ? ws->edge.view() : ws->surf.view();
   va.same_cloud = d_edge ? 0 : 1;
-  va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride; va.n_ref = n_ref;
+  va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride;
   va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
   va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
   va.entries = m->entries.p;
@@ -1002,7 +890,20 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   va.cellsum = ws->counters.p;
   va.pairs = ws->counters.p + (size_t)n_ref * T;
   va.acc_dump = ws->acc_dump;
-  const size_t lds = (size_t)LDS_HEADER + (size_t)m->info.tile_refs * m->info.num_angles * 4;
+  va.ablate = 0;
+  const int n_paired = va.paired.n;
+  /* reference points are processed in batches whose worst-case hit lists (every pair hits) fit the scratch budget */
+  const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_ref, HIT_BYTES_BUDGET / ((size_t)n_paired * (sizeof(HitRec) + 2 * sizeof(uint2)))));
+  HIPCHK(ws->frames.reserve((size_t)batch * 12));
+  HIPCHK(ws->hits.reserve((size_t)batch * n_paired));
+  HIPCHK(ws->keys_a.reserve((size_t)batch * n_paired));
+  HIPCHK(ws->keys_b.reserve((size_t)batch * n_paired));
+  HIPCHK(ws->hit_count.reserve(batch));
+  va.frames = ws->frames.p; va.hits = ws->hits.p; va.hit_count = ws->hit_count.p; va.hit_cap = n_paired;
+  va.keys_a = ws->keys_a.p; va.keys_b = ws->keys_b.p;
+  va.key_bits = 1;
+  while (va.key_bits < 32 && (1ull << va.key_bits) < (unsigned long long)m->info.n_buckets) va.key_bits++;
+  const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)m->info.tile_refs * vote_pitch(m->info.num_angles)) * 4;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
@@ -1010,10 +911,25 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
                                    160 * 1024);
   });
   HIPCHK(attr_err);
-  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[1], st));
-  k_vote<<<dim3((unsigned)((size_t)n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
-  HIPCHK(hipGetLastError());
-  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[2], st));
+  /* timing: ev[1]..ev[2] bracket the voting kernel of the first batch only when there are several;
+   * with one batch (every measured configuration) they bracket exactly one k_vote launch */
+  const int pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
+  for (int base = 0; base < n_ref; base += batch) {
+    va.ref_base = base;
+    va.n_ref = std::min(batch, n_ref - base);
+    HIPCHK(hipMemsetAsync(ws->hit_count.p, 0, (size_t)va.n_ref * sizeof(uint32_t), st));
+    k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
+    HIPCHK(hipGetLastError());
+    if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[4], st));
+    k_pairs<<<dim3(pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+    HIPCHK(hipGetLastError());
+    k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), 0, st>>>(va);
+    HIPCHK(hipGetLastError());
+    if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[1], st));
+    k_vote<<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
+    HIPCHK(hipGetLastError());
+    if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[2], st));
+  }
 
   FinalArgs fa;
   fa.surf = ws->surf.view(); fa.model = m->cloud.view();
@@ -1043,6 +959,7 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
     ws->stats.n_pairs = tot[1];
     if (ws->timing) {
       HIPCHK(hipEventElapsedTime(&ws->stats.ms_vote_kernel, ws->ev[1], ws->ev[2]));
+      HIPCHK(hipEventElapsedTime(&ws->stats.ms_pair_kernel, ws->ev[4], ws->ev[1]));
       HIPCHK(hipEventElapsedTime(&ws->stats.ms_total_device, ws->ev[0], ws->ev[3]));
     }
     if (votes) HIPCHK(hipMemcpy(votes, ws->votes.p, (size_t)nr * sizeof(ppf_vote), hipMemcpyDeviceToHost));

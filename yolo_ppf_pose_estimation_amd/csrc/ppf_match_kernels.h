@@ -1,0 +1,525 @@
+/*
+ * ppf_match_kernels.h — the matching hot path on gfx950, included by
+ * ppf_hip.hip.  Reference call sites: /root/reference/include/CloudProcessing.h:442 (match), :495
+ * (match_S2B).
+ *
+ * Four kernels per batch of scene reference points:
+ *
+ *   k_frames   one thread per reference point: the rotation/translation (Rsg, tsg) that takes the
+ *              reference point to the origin with its normal on +x (fp64, 12 doubles per point).
+ *
+ *   k_pairs    one thread per scene pair (s_r, s_i): pair feature (fp64, deterministic math) ->
+ *              4 x int32 key -> MurmurHash3 -> slot -> dense bucket id through the slot map (one
+ *              16-byte load).  Only ~1-2 % of the pairs of a real crop land in a non-empty slot;
+ *              for those the lane also computes alpha_s and the wave appends a 16-byte hit record
+ *              {bucket, alpha_s} to the reference point's hit list (ballot + one atomic per wave).
+ *              VALU(fp64)-bound; reads 24 B per pair from the L2-resident scene SoA.
+ *
+ *   k_group    one workgroup per reference point: stable LSD radix sort (8-bit digits, in L2-resident
+ *              global memory) of the point's hit list by bucket id.  On a real crop many pairs of one
+ *              reference point fall into the same few heavy buckets (measured: votes / distinct
+ *              bucket entries = 31), so grouping them lets k_vote read a bucket once for all of them.
+ *
+ *   k_vote     one workgroup per (reference point, accumulator tile).  The tile's Hough accumulator
+ *              lives in LDS.  Sorted hits form runs (one bucket, m hits with different alpha_s); a run
+ *              is cut into work items of <= VOTE_CHUNK table entries x <= VOTE_MAX_HITS hits.  A wave
+ *              loads a batch of 64 x VOTE_UNROLL entries (coalesced 8-byte loads, next batch
+ *              prefetched into a second register set) and votes it once per hit of the item straight
+ *              from registers: HBM/L2 traffic per vote drops from 8 B to 8/m B and the kernel is bound
+ *              by VALU issue (5 VALU per vote) and the LDS atomic rate.
+ *
+ * Alpha bin, exactly: bin = (int)(A*(alpha_m - alpha_s + 2pi)/(4pi)) in fp64 is what the reference
+ * computes.  The fast path evaluates q = (alpha_m - alpha_s)*A/(4pi) + A/2 in fp32 (|error| <= 9e-8*A,
+ * folded as alpha_m*S + (A/2 - alpha_s*S): |error| <= 1.1e-7*A) and takes trunc(q)
+ * whenever q is farther than G = 5e-7*A from an integer; otherwise
+ * (about 3e-5 of the votes) the lane re-evaluates the fp64 chain.  Both paths give the same integer.
+ */
+#ifndef PPF_MATCH_KERNELS_H
+#define PPF_MATCH_KERNELS_H
+
+#ifndef PPF_ABL
+#define PPF_ABL 0 /* diagnostic ablations of k_vote; 0 in every shipped build */
+#endif
+
+constexpr int PAIR_BLOCK = 256;
+constexpr int PAIRS_PER_THREAD = 8;   /* one k_pairs workgroup covers 2048 paired points of one reference point */
+constexpr int VOTE_BLOCK = 1024;
+constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
+constexpr int VOTE_UNROLL = 8;        /* entry loads in flight per lane */
+constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * 4; /* table entries per work item (2048) */
+constexpr int VOTE_MAX_HITS = 16;     /* hits of one bucket run voted per work item */
+constexpr int GROUP_BLOCK = 1024;
+constexpr int VOTE_SEG = VOTE_BLOCK;  /* hits staged in LDS per segment: one per thread */
+constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + run-start masks (16 x u64) */
+
+struct HitRec {
+  uint32_t bucket;   /* dense bucket id */
+  uint32_t alpha32;  /* (float)alpha_s bits, for the fp32 fast path */
+  double alpha_s;    /* exact alpha_s */
+};
+
+struct MatchArgs {
+  CloudSoA surf;   /* reference points come from here */
+  CloudSoA paired; /* second points of the pairs (== surf for match, the edge cloud for match_S2B) */
+  int same_cloud;
+  int scene_step, ref_offset, ref_stride; /* reference point r (global) -> row (ref_offset + r*ref_stride)*scene_step */
+  int ref_base, n_ref;                    /* this batch: global r = ref_base + local r */
+  /* model table */
+  const SlotWord* slotmap;
+  uint32_t slot_mask;
+  const uint32_t* bucket_off;
+  int n_buckets;
+  const uint2* entries;
+  int n_tiles, tile_refs, num_angles, n_model;
+  double angle_step, dist_step;
+  /* per-batch scratch */
+  double* frames;          /* [n_ref][12] */
+  HitRec* hits;            /* [n_ref][hit_cap] */
+  uint32_t* hit_count;     /* [n_ref] */
+  uint2* keys_a;           /* [n_ref][hit_cap] {bucket, hit index}: sorted by bucket after k_group */
+  uint2* keys_b;           /* [n_ref][hit_cap] ping-pong */
+  int hit_cap;
+  int key_bits;            /* bits of a bucket id */
+  /* results, indexed by global r */
+  uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
+  unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
+  unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
+  uint32_t* acc_dump;           /* optional [n_ref_all][n_model*num_angles] full accumulators (debug/tests) */
+  int ablate;                   /* PPF_ABLATE env (diagnostic builds only): 1 conflict-free atomics, 2 no atomics, 3 no entry loads */
+};
+
+__device__ __forceinline__ int ref_row(const MatchArgs& a, int r_local) {
+  return (a.ref_offset + (a.ref_base + r_local) * a.ref_stride) * a.scene_step;
+}
+
+__global__ __launch_bounds__(64) void k_frames(MatchArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n_ref) return;
+  const int i = ref_row(a, r);
+  double R[9], t[3];
+  ppf_transform_rt(ld3(a.surf.x, a.surf.y, a.surf.z, i), ld3(a.surf.nx, a.surf.ny, a.surf.nz, i), R, t);
+  double* f = a.frames + (size_t)r * 12;
+#pragma unroll
+  for (int k = 0; k < 9; k++) f[k] = R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) f[9 + k] = t[k];
+}
+
+/* grid: x = chunks of PAIR_BLOCK*PAIRS_PER_THREAD paired points, y = reference point of the batch */
+__global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
+  const int r = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int i_ref = ref_row(a, r);
+  const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
+  const double* __restrict__ fr = a.frames + (size_t)r * 12;
+  /* rows 1 and 2 of Rsg and tsg.y/z are all alpha_s needs */
+  const double R10 = fr[3], R11 = fr[4], R12 = fr[5], R20 = fr[6], R21 = fr[7], R22 = fr[8], ty = fr[10], tz = fr[11];
+  HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
+  unsigned long long my_pairs = 0;
+  const int j0 = blockIdx.x * (PAIR_BLOCK * PAIRS_PER_THREAD) + threadIdx.x;
+#pragma unroll 1
+  for (int it = 0; it < PAIRS_PER_THREAD; it++) {
+    const int j = j0 + it * PAIR_BLOCK;
+    if ((j - lane) >= a.paired.n) break; /* whole wave past the end */
+    bool hit = false;
+    HitRec rec;
+    rec.bucket = 0; rec.alpha32 = 0; rec.alpha_s = 0.0;
+    if (j < a.paired.n && !(a.same_cloud && j == i_ref)) {
+      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
+      const ppf_vec3 n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
+      double f[4] = {0, 0, 0, 0};
+      ppf_pair_feature(p1, n1, p2, n2, f);
+      const uint32_t slot = ppf_hash_feature(f, a.angle_step, a.dist_step) & a.slot_mask;
+      const int b = slot_to_bucket(a.slotmap, slot);
+      /* alpha_s = angle of (tsg + Rsg p2) about x; the reference skips the pair when it is NaN.
+       * For finite clouds it never is, so it is only evaluated for pairs that found a bucket;
+       * `pairs` counts pairs hashed. */
+      const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
+      const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
+      const bool finite_q = (qy == qy) && (qz == qz);
+      my_pairs += finite_q ? 1u : 0u;
+      if (b >= 0 && finite_q) {
+        double as;
+        if (ppf_alpha_in_frame(qy, qz, &as)) {
+          hit = true;
+          rec.bucket = (uint32_t)b;
+          rec.alpha32 = __float_as_uint((float)as);
+          rec.alpha_s = as;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&a.hit_count[r], (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (hit) {
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        hits[base + rank] = rec;
+        a.keys_a[(size_t)r * a.hit_cap + base + rank] = make_uint2(rec.bucket, base + rank);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_down(my_pairs, o);
+  if (lane == 0 && my_pairs) atomicAdd(&a.pairs[a.ref_base + r], my_pairs);
+}
+
+/*
+ * k_group: stable LSD radix sort of one reference point's {bucket, hit index} keys by bucket id.
+ * Elements are taken 1024 at a time in list order; inside a tile, wave w owns elements 64w..64w+63,
+ * so (wave, lane) order is list order.  Rank of an element among equal digits = digits before it in
+ * earlier tiles (running base) + in earlier waves of the tile (wave counts) + in lower lanes of its
+ * wave (ballot match).  The result always ends in keys_a.
+ */
+__global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
+  __shared__ uint32_t base[256];
+  __shared__ uint32_t wcnt[GROUP_BLOCK / 64][256];
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n = a.hit_count[r];
+  if (n < 2) return;
+  uint2* src = a.keys_a + (size_t)r * a.hit_cap;
+  uint2* dst = a.keys_b + (size_t)r * a.hit_cap;
+  const int passes = (a.key_bits + 7) / 8;
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = pass * 8;
+    if (tid < 256) base[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) atomicAdd(&base[(src[i].x >> shift) & 255u], 1u);
+    __syncthreads();
+    if (wave == 0) { /* exclusive scan of the 256 digit counts: 4 per lane */
+      uint32_t c[4], tsum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { c[k] = base[lane * 4 + k]; tsum += c[k]; }
+      uint32_t incl = tsum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      uint32_t ex = incl - tsum;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { base[lane * 4 + k] = ex; ex += c[k]; }
+    }
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n; t0 += GROUP_BLOCK) {
+      for (int k = tid; k < (GROUP_BLOCK / 64) * 256; k += GROUP_BLOCK) (&wcnt[0][0])[k] = 0;
+      __syncthreads();
+      const uint32_t i = t0 + tid;
+      const bool valid = i < n;
+      uint2 key = make_uint2(0, 0);
+      uint32_t d = 0;
+      if (valid) { key = src[i]; d = (key.x >> shift) & 255u; }
+      /* lanes of this wave with the same digit */
+      unsigned long long same = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const unsigned long long bb = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? bb : ~bb;
+      }
+      const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+      if (valid && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(same);
+      __syncthreads();
+      if (valid) {
+        uint32_t pos = base[d] + rank;
+        for (int w = 0; w < wave; w++) pos += wcnt[w][d];
+        dst[pos] = key;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t add = 0;
+#pragma unroll
+        for (int w = 0; w < GROUP_BLOCK / 64; w++) add += wcnt[w][tid];
+        base[tid] += add;
+      }
+      __syncthreads();
+    }
+    uint2* tmp = src; src = dst; dst = tmp;
+  }
+  if (passes & 1) { /* result sits in keys_b: copy back */
+    uint2* ka = a.keys_a + (size_t)r * a.hit_cap;
+    const uint2* kb = a.keys_b + (size_t)r * a.hit_cap;
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) ka[i] = kb[i];
+  }
+}
+
+/*
+ * Accumulator layout in LDS (words):  [guard: VOTE_GUARD(P)] [tile_refs x P cells]
+ *   P = (A+1)|1 is the row pitch: A alpha bins + the "bin == A" spill cell of the row (the reference
+ *   indexes corrI*A + alpha_index without a range check, so alpha_index == A lands on the next model
+ *   reference point's bin 0; the spill cell is folded into that bin when the accumulator is scanned).
+ *   An odd pitch also spreads rows over all 32 LDS banks.
+ *   The guard words below cell 0 take every vote that must not count: mirrored spill entries
+ *   (word offset GW-A) with any bin other than A, and the lanes past the end of a bucket (word = lane).
+ *   With it the vote needs no range check at all.  Entry offsets are bytes from the guard's start.
+ *
+ * One vote = v_fma_f32 (q'), v_cvt_i32_f32 (k), v_fract_f32 + v_cmp (guard band), v_lshl_add_u32
+ * (byte address), ds_add_u32.
+ *   q' = alpha_m*S + Ohg,  Ohg = A/2 - alpha_s*S + G  (folded once per hit), k = trunc(q')
+ *   k is the reference's integer whenever fract(q') >= 2G; otherwise the lane
+ *   re-evaluates the fp64 chain.  That happens for ~3e-5 of the votes, so the re-evaluation is
+ *   taken once per batch of U entries and only when some lane of the wave needs it.
+ */
+
+template <int U>
+__device__ __forceinline__ void load_entries(uint2* ent, const uint2* __restrict__ src, const uint32_t e0,
+                                             const int lane) {
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+#if PPF_ABL == 3 || PPF_ABL == 5 /* diagnostic: no entry loads */
+    ent[u] = make_uint2(((e0 + u * 64 + lane) & 1023u) * 124u, 0x3a000000u + ((e0 + lane) & 0xffffu) * 64u);
+#else
+    ent[u] = src[e0 + u * 64 + lane];
+#endif
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes, const uint2* ent, const int n_valid,
+                                           const float S, const float Ohg, const double* __restrict__ asd_lds,
+                                           const float G2, const int A) {
+  int k[U];
+  bool need = false;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const float q = __builtin_fmaf(__uint_as_float(ent[u].y), S, Ohg);
+    k[u] = (int)q;
+    need |= (__builtin_amdgcn_fractf(q) < G2);
+  }
+  if (__builtin_expect(__any(need), 0)) {
+    const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float q = __builtin_fmaf(__uint_as_float(ent[u].y), S, Ohg);
+      if (__builtin_amdgcn_fractf(q) < G2) k[u] = ppf_alpha_bin_exact(__uint_as_float(ent[u].y), asd, A);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    if (u < n_valid) {
+      const int adr = (int)ent[u].x + k[u] * 4;
+#if PPF_ABL == 2 || PPF_ABL == 5 /* diagnostic: no atomics */
+      asm volatile("" ::"v"(adr));
+#else
+      atomicAdd(reinterpret_cast<uint32_t*>(acc_bytes + adr), 1u);
+#endif
+    }
+  }
+}
+
+__global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
+  uint32_t* seg_prefix = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);          /* VOTE_SEG + 64 */
+  uint32_t* seg_off = seg_prefix + (VOTE_SEG + 64);                                /* VOTE_SEG */
+  uint32_t* seg_cnt = seg_off + VOTE_SEG;                                          /* VOTE_SEG */
+  uint32_t* seg_m = seg_cnt + VOTE_SEG;                                            /* VOTE_SEG: run length at run starts */
+  uint32_t* seg_a32 = seg_m + VOTE_SEG;                                            /* VOTE_SEG */
+  double* seg_a64 = reinterpret_cast<double*>(seg_a32 + VOTE_SEG);                 /* VOTE_SEG */
+  const int A = a.num_angles;
+  const int P = vote_pitch(A);
+  const int GW = vote_guard(A);
+  uint32_t* lds_acc = reinterpret_cast<uint32_t*>(seg_a64 + VOTE_SEG);             /* guard + cells */
+  uint32_t* acc = lds_acc + GW;
+  /* table entries carry byte offsets relative to the start of the guard ((GW + local_ref*P)*4), so the
+   * vote address is entry.x + k*4 on top of a compile-time LDS offset */
+  unsigned char* acc_bytes = reinterpret_cast<unsigned char*>(lds_acc);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* scalar: the work-item loop is wave-uniform */
+  const int r = blockIdx.x / a.n_tiles, tile = blockIdx.x - r * a.n_tiles;
+  const int rg = a.ref_base + r;
+  const int tile_base = tile * a.tile_refs;
+  const int refs_here = min(a.tile_refs, a.n_model - tile_base);
+  const int words = GW + refs_here * P;
+  for (int c = tid; c < words; c += VOTE_BLOCK) lds_acc[c] = 0u;
+
+  const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
+  const uint2* __restrict__ entries = a.entries;
+  const HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
+  const int n_hits = (int)a.hit_count[r];
+  const float S = (float)((double)A / (4 * PPF_PI));
+#ifdef PPF_FORCE_EXACT
+  const float G = 1.0f;
+#else
+  const float G = 5e-7f * (float)A;
+#endif
+  const float G2 = 2.0f * G;
+  const float Og = 0.5f * (float)A + G;
+  const uint32_t tail_bytes = (uint32_t)(lane * 4); /* per-lane guard word for lanes past the end of a bucket */
+
+  const uint2* __restrict__ keys = a.keys_a + (size_t)r * a.hit_cap;
+  unsigned long long* start_mask = reinterpret_cast<unsigned long long*>(red + 16); /* VOTE_WAVES x u64 */
+
+  for (int seg0 = 0; seg0 < n_hits; seg0 += VOTE_SEG) {
+    /* Stage a segment of the bucket-sorted hit list: this tile's bucket range, alpha_s, run
+     * structure (a run = consecutive hits of one bucket), work items per run, exclusive scan. */
+    __syncthreads(); /* previous segment fully consumed (and the accumulator clear, first time) */
+    const int n_seg = min(VOTE_SEG, n_hits - seg0);
+    uint32_t off = 0, cnt = 0;
+    bool is_start = true; /* positions past the end terminate the last run */
+    if (tid < n_seg) {
+      const uint2 key = keys[seg0 + tid];
+      const HitRec h = hits[key.y];
+      off = boff[key.x];
+      cnt = boff[key.x + 1] - off;
+      seg_a32[tid] = h.alpha32;
+      seg_a64[tid] = h.alpha_s;
+      is_start = (tid == 0) || (keys[seg0 + tid - 1].x != key.x);
+    }
+    const unsigned long long smask = __ballot(is_start);
+    if (lane == 0) start_mask[wave] = smask;
+    __syncthreads();
+    uint32_t items = 0, m = 0;
+    if (tid < n_seg && is_start && cnt > 0) {
+      /* run length: distance to the next run start (or to the end of the segment) */
+      int next = VOTE_SEG;
+      unsigned long long rest = (lane == 63) ? 0ull : (smask >> (lane + 1));
+      if (rest) {
+        next = tid + 1 + (__ffsll((long long)rest) - 1);
+      } else {
+        for (int w = wave + 1; w < VOTE_WAVES; w++) {
+          const unsigned long long mw = start_mask[w];
+          if (mw) { next = w * 64 + (__ffsll((long long)mw) - 1); break; }
+        }
+      }
+      m = (uint32_t)(min(next, n_seg) - tid);
+      items = ((m + VOTE_MAX_HITS - 1) / VOTE_MAX_HITS) * ((cnt + VOTE_CHUNK - 1) / VOTE_CHUNK);
+    }
+    seg_off[tid] = off;
+    seg_cnt[tid] = cnt;
+    seg_m[tid] = m;
+    uint32_t incl = items;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < VOTE_WAVES; k++) {
+      const uint32_t w = red[k];
+      if (k < wave) woff += w;
+      total += w;
+    }
+    seg_prefix[tid] = woff + incl - items; /* exclusive */
+    if (tid < 64) seg_prefix[VOTE_SEG + tid] = total; /* sentinel + padding for the 64-wide look-ahead */
+    __syncthreads();
+
+    /* waves take work items round-robin; the owning run start is found with a 64-wide look-ahead
+     * from the previous one (positions that start no run in this tile have 0 items and are skipped) */
+    int h = 0;
+    for (uint32_t item = wave; item < total; item += VOTE_WAVES) {
+      while (true) { /* advance h to the last position with prefix <= item */
+        const uint32_t pv = seg_prefix[min(h + 1 + lane, VOTE_SEG + 63)];
+        const unsigned long long le = __ballot(pv <= item);
+        const int adv = __popcll(le);
+        h += adv;
+        if (adv < 64) break;
+      }
+      /* the staged values are the same in every lane: move them to scalar registers so the item
+       * runs on scalar control flow and scalar base addresses */
+      const uint32_t local = item - (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_prefix[h]);
+      const uint32_t c_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_cnt[h]);
+      const uint32_t m_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_m[h]);
+      const uint32_t nchunk = (c_all + VOTE_CHUNK - 1) / VOTE_CHUNK;
+      const uint32_t sub = local / nchunk, chunk = local - sub * nchunk;
+      const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_off[h]) + chunk * VOTE_CHUNK;
+#if PPF_ABL == 6 /* diagnostic: empty work items */
+      const uint32_t c = 0;
+#else
+      const uint32_t c = min((uint32_t)VOTE_CHUNK, c_all - chunk * VOTE_CHUNK);
+#endif
+      const int h0 = h + (int)(sub * VOTE_MAX_HITS);
+      const int nh = min((int)VOTE_MAX_HITS, h + (int)m_all - h0);
+      /* lane l holds the folded offset of hit h0+l: Ohg = A/2 + G - alpha_s*S */
+      float ohg_v = 0.f;
+      if (lane < nh) ohg_v = Og - __uint_as_float(seg_a32[h0 + lane]) * S;
+      const uint2* __restrict__ src = entries + o;
+      constexpr uint32_t B = 64 * VOTE_UNROLL;
+      const uint32_t nfull = c / B;
+      /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
+       * flight while batch b is voted for every hit of the item.  The prefetch is unconditional
+       * (the last one re-reads the final batch): a conditional one would merge two control-flow
+       * paths and force the compiler into a vmcnt that also waits for the prefetch. */
+      uint2 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
+      if (nfull) load_entries<VOTE_UNROLL>(ea, src, 0, lane);
+      uint32_t b = 0;
+      while (b < nfull) {
+        load_entries<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
+        for (int hh = 0; hh < nh; hh++) {
+          const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
+          cast_votes<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
+        }
+        if (++b >= nfull) break;
+        load_entries<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
+        for (int hh = 0; hh < nh; hh++) {
+          const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
+          cast_votes<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
+        }
+        ++b;
+      }
+      const uint32_t e0 = nfull * B;
+      if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
+#pragma unroll
+        for (int u = 0; u < VOTE_UNROLL; u++) {
+          const uint32_t e = e0 + u * 64 + lane;
+          ea[u] = src[min(e, c - 1)];
+          if (e >= c) ea[u].x = tail_bytes;
+        }
+        const int n_valid = (int)((c - e0 + 63) / 64);
+        for (int hh = 0; hh < nh; hh++) {
+          const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
+          cast_votes<VOTE_UNROLL>(acc_bytes, ea, n_valid, S, Ohg, &seg_a64[h0 + hh], G2, A);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  /* Scan in the reference's order (model ref ascending, alpha bin ascending, strict >) == smallest
+   * upstream flat index ref*A + bin among the maxima; the spill cell of row ref-1 is folded into
+   * (ref, bin 0) on the way.  Also the exact vote total of the tile. */
+  const int cells = refs_here * A;
+  uint32_t* dump = a.acc_dump ? a.acc_dump + (size_t)rg * a.n_model * A + (size_t)tile_base * A : nullptr;
+  uint32_t bv = 0, bi = 0xFFFFFFFFu;
+  unsigned long long sum = 0;
+  for (int c = tid; c < cells; c += VOTE_BLOCK) {
+    const int ref = c / A, bin = c - ref * A;
+    uint32_t v = acc[ref * P + bin];
+    if (bin == 0 && ref > 0) v += acc[(ref - 1) * P + A];
+    if (dump) dump[c] = v;
+    sum += v;
+    if (v > bv) { bv = v; bi = (uint32_t)c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t v2 = __shfl_down(bv, o), i2 = __shfl_down(bi, o);
+    sum += __shfl_down(sum, o);
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+  uint32_t* red_v = seg_prefix; /* staging arrays are free now */
+  uint32_t* red_i = seg_prefix + VOTE_WAVES;
+  __syncthreads();
+  if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t v = (lane < VOTE_WAVES) ? red_v[lane] : 0u;
+    uint32_t ix = (lane < VOTE_WAVES) ? red_i[lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = VOTE_WAVES / 2; o > 0; o >>= 1) {
+      const uint32_t v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
+      if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+    }
+    if (lane == 0) a.partial[(size_t)rg * a.n_tiles + tile] = make_uint2(v, ix);
+  }
+  if (lane == 0 && sum) atomicAdd(&a.cellsum[(size_t)rg * a.n_tiles + tile], sum);
+}
+
+/* fixed LDS of k_vote: header + hit staging (the guard and the cells are sized per model) */
+constexpr size_t VOTE_LDS_FIXED = LDS_HEADER + (size_t)(VOTE_SEG + 64) * 4 + (size_t)VOTE_SEG * 4 * 4 + (size_t)VOTE_SEG * 8;
+
+#endif /* PPF_MATCH_KERNELS_H */
