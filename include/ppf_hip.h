@@ -20,10 +20,8 @@
  *                                   parity surface {refIndMax, alphaIndMax, maxVotes}
  *   ppf_match_device (+workspace)   same as ppf_match with clouds already resident in HBM and an
  *                                   explicit HIP stream: the entry bench.py times
- *   ppf_match_batch                 many crops x many models (BASELINE config C5)
  *   ppf_sample_cloud                samplePCByQuantization inside trainModel/match (A2)
  *   ppf_transform_pc_pose           transformPCPose, src/YOLO_cropping_ppf_test.cpp:125
- *   ppf_icp_refine                  ICP(100,0.005f,2.5f,8).registerModelToScene :465-470,:518-523
  *
  * Conventions
  *   - Clouds are float32 rows `x y z nx ny nz` (the N x 6 CV_32FC1 Mat that
@@ -187,6 +185,9 @@ ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref
 ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
                                   int estride, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
                                   int* n_ref);
+/* Evaluate include/ppf_detmath.h on the device: fn 0 acos(x), 1 sin(x), 2 cos(x), 3 atan2(x, y), 4 sqrt(x),
+ * 5 x / y.  The bit patterns must equal the host's (tests/test_gpu_detmath.py). */
+ppf_status ppf_debug_device_math(int fn, const double* x, const double* y, double* out, int n);
 /* device pointer to the per-reference pose records of the last call (n_ref x ppf_pose), for a
  * collective gather without a host copy */
 ppf_status ppf_workspace_device_poses(ppf_workspace* ws, void** d_raw_poses, int* n_ref);

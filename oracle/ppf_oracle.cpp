@@ -443,6 +443,9 @@ VoteResult voteOneRef(const Model& m, const float* surf, int /*nSurf*/, const fl
   uint64_t votes = 0, pairs = 0;
   for (int j = 0; j < nPaired; j++) {
     if (sameCloud && i == j) continue;
+    /* match_S2B (build-defined): the reference point itself is not paired even when it
+     * also appears in the edge cloud (bit-identical row), so edge == scene reduces exactly to match() */
+    if (!sameCloud && memcmp(surf + (size_t)i * 6, paired + (size_t)j * 6, 24) == 0) continue;
     const V3 p2 = v3(paired + (size_t)j * 6), n2 = v3(paired + (size_t)j * 6 + 3);
     double f[4] = {0, 0, 0, 0};
     computePPFFeatures<M>(p1, n1, p2, n2, f);

@@ -1,0 +1,93 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/ppf_hip.h declares, and its
+host-only entry points behave (no compute calls here; compute parity lives in the -m gpu tests)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from yolo_ppf_pose_estimation_amd import _capi
+from yolo_ppf_pose_estimation_amd._capi import MatchParams, TrainParams, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "ppf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _header_functions()
+    assert len(names) >= 25
+    L = C.CDLL(_capi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"libppf_hip.so lacks {n}"
+    assert sorted(_capi._SIGNATURES) == names, "python binding table and header disagree"
+    assert lib().ppf_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof() of every struct as a C compiler sees include/ppf_hip.h == the ctypes mirror."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "ppf_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(ppf_pose),sizeof(ppf_vote),sizeof(ppf_train_params),sizeof(ppf_match_params),'
+                   'sizeof(ppf_model_info),sizeof(ppf_match_stats));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    want = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    got = [C.sizeof(t) for t in (_capi.Pose, _capi.Vote, TrainParams, MatchParams, _capi.ModelInfo, _capi.MatchStats)]
+    assert got == want
+
+
+def test_defaults_mirror_the_reference_library():
+    tp, mp = TrainParams(), MatchParams()
+    lib().ppf_default_train_params(C.byref(tp))
+    lib().ppf_default_match_params(C.byref(mp))
+    assert (tp.relative_sampling_step, tp.relative_distance_step, tp.num_angles) == (0.05, 0.05, 30)
+    assert mp.relative_scene_sample_step == pytest.approx(0.2) and mp.relative_scene_distance == 0.03
+    assert mp.position_threshold < 0 and mp.rotation_threshold < 0 and mp.ref_stride == 1
+
+
+def test_host_helpers_match_the_oracle(bottle):
+    from yolo_ppf_pose_estimation_amd.detector import samplePCByQuantization, transformPCPose
+    from yolo_ppf_pose_estimation_amd.ply import transform_pc_pose
+    for step in (0.05, 0.0714, 0.036):
+        np.testing.assert_array_equal(samplePCByQuantization(bottle, step), O.sample(bottle, step))
+    # pcl::PointNormal-like pitch (12 floats per row) gives the same result as the packed Mat layout
+    wide = np.zeros((bottle.shape[0], 12), np.float32)
+    wide[:, :6] = bottle
+    np.testing.assert_array_equal(samplePCByQuantization(wide, 0.05), O.sample(bottle, 0.05))
+    T = np.eye(4); T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]; T[:3, 3] = [0.1, -0.2, 0.3]
+    np.testing.assert_allclose(transformPCPose(bottle[:100], T), transform_pc_pose(bottle[:100], T), atol=1e-6)
+
+
+def test_errors_without_a_device_are_loud(bottle):
+    """No CPU fallback: on a box without a GPU every compute entry point reports PPF_ERR_HIP."""
+    if lib().ppf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+    with pytest.raises(_capi.PPFError) as e:
+        PPF3DDetector(0.05, 0.05).trainModel(bottle)
+    assert e.value.status == _capi.PPF_ERR_HIP
+    assert "no HIP device" in str(e.value)
+
+
+def test_argument_validation_precedes_any_device_work(bottle):
+    from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+    det = PPF3DDetector(0.05, 0.05)
+    with pytest.raises(_capi.PPFError) as e:
+        det.match(bottle[:100])
+    assert e.value.status == _capi.PPF_ERR_NOT_TRAINED  # the wrapper's pre-check, CloudProcessing.h:435-439
+    with pytest.raises(_capi.PPFError) as e:
+        det.trainModel(bottle[:, :3])
+    assert e.value.status == _capi.PPF_ERR_INVALID
+    out = C.c_void_p()
+    tp = TrainParams()
+    lib().ppf_default_train_params(C.byref(tp))
+    assert lib().ppf_model_train(None, 10, 6, C.byref(tp), C.byref(out)) == _capi.PPF_ERR_INVALID
+    assert "bad argument" in _capi.last_error()

@@ -115,10 +115,10 @@ def test_match_s2b(bottle):
     scene, _ = synth.make_scene(bottle, n_points=4000, seed=25)
     a = det.raw_votes(scene, 1.0 / 40.0, 0.05, presampled=True)
     b = det.raw_votes(scene, 1.0 / 40.0, 0.05, presampled=True, edge=scene)
-    # with edge == scene the pair (i, i) is no longer skipped by index; it has |d| = 0 -> key of zeros
+    np.testing.assert_array_equal(a["triples"], b["triples"])  # the identity of SURVEY.md §8a A6
+    assert a["stats"]["n_votes"] == b["stats"]["n_votes"] and a["stats"]["n_pairs"] == b["stats"]["n_pairs"]
     want = ora.match(scene, edge=scene, relative_scene_sample_step=1.0 / 40.0, presampled=True, cluster=False)
     np.testing.assert_array_equal(b["triples"], want["triples"])
-    assert a["n_ref"] == b["n_ref"]
     edge = scene[::3].copy()
     _check_against_oracle(det, ora, scene, 1.0 / 40.0, 0.05, True, edge=edge)
 

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "ppf_workspace_ref_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_debug_accumulators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(MatchParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ppf_debug_device_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_workspace_device_poses": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "ppf_cluster_poses": (C.c_int, [C.c_void_p, C.POINTER(Pose), C.c_int, C.c_int, C.POINTER(MatchParams),
                                     C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),

@@ -259,6 +259,21 @@ __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restric
 
 #include "ppf_match_kernels.h"
 
+/* ---- diagnostic: evaluate the deterministic math and the pair feature on the device ----------------- */
+__global__ void k_debug_math(int fn, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out,
+                             int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (fn) {
+    case 0: out[i] = ppf_acos(x[i]); break;
+    case 1: out[i] = ppf_sin(x[i]); break;
+    case 2: out[i] = ppf_cos(x[i]); break;
+    case 3: out[i] = ppf_atan2(x[i], y[i]); break;
+    case 4: out[i] = ppf_sqrt(x[i]); break;
+    default: out[i] = x[i] / y[i]; break;
+  }
+}
+
 /* ---- finalize: merge tiles, assemble the raw pose (rows A5 tail + A8) ---------------------- */
 struct FinalArgs {
   CloudSoA surf, model;
@@ -1034,6 +1049,21 @@ ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns
   if (s != PPF_OK) return s;
   HIPCHK(hipMemcpy(acc, dump.p, per_ref * nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (n_ref) *n_ref = nr;
+  return PPF_OK;
+}
+
+ppf_status ppf_debug_device_math(int fn, const double* x, const double* y, double* out, int n) {
+  if (!x || !out || n <= 0 || fn < 0 || fn > 5) return fail(PPF_ERR_INVALID, "ppf_debug_device_math: bad argument");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_debug_device_math: no HIP device");
+  DevBuf<double> dx, dy, dout;
+  HIPCHK(dx.reserve(n));
+  HIPCHK(dy.reserve(n));
+  HIPCHK(dout.reserve(n));
+  HIPCHK(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dy.p, y ? y : x, (size_t)n * 8, hipMemcpyHostToDevice));
+  k_debug_math<<<dim3((n + 255) / 256), dim3(256)>>>(fn, dx.p, dy.p, dout.p, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return PPF_OK;
 }
 

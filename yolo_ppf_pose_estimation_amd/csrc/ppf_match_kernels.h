@@ -127,6 +127,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
     if (j < a.paired.n && !(a.same_cloud && j == i_ref)) {
       const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
       const ppf_vec3 n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
+      /* match_S2B: the reference point itself is never paired, even when the edge cloud contains it
+       * (bit-identical row), so edge == scene reduces exactly to match().  Values came from floats, so
+       * comparing the doubles compares the float bits (no NaN/-0 cases in finite clouds). */
+      const bool self_pair = !a.same_cloud && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x &&
+                             n2.y == n1.y && n2.z == n1.z;
+      if (!self_pair) {
       double f[4] = {0, 0, 0, 0};
       ppf_pair_feature(p1, n1, p2, n2, f);
       const uint32_t slot = ppf_hash_feature(f, a.angle_step, a.dist_step) & a.slot_mask;
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
           rec.alpha32 = __float_as_uint((float)as);
           rec.alpha_s = as;
         }
+      }
       }
     }
     const unsigned long long m = __ballot(hit);
