@@ -129,15 +129,13 @@ def main():
         with torch.cuda.stream(stream):
             ws.match_device(det, d_scene.data_ptr(), SCENE_POINTS, 6, SCENE_STEP, 0.05, presampled=True,
                             stream=stream.cuda_stream)
-            res = ws.results(n_ref_total, want_poses=True)  # waits for the stream, clusters the poses
+            # waits for the stream; clustering already ran on the device, only the clustered poses come back
+            fin, k_top, n_clusters, st = ws.top_poses(TOP_K)
             if world > 1:
-                recs = (Pose * TOP_K)()
-                for k, p in enumerate(res["poses"][:TOP_K]):
-                    recs[k] = p.to_record()
-                host = np.frombuffer(recs, dtype=np.float64).reshape(TOP_K, pose_words)
+                host = np.frombuffer(fin, dtype=np.float64)[: TOP_K * pose_words].reshape(TOP_K, pose_words)
                 top.copy_(torch.from_numpy(host.copy()), non_blocking=False)
                 dist.all_gather_into_tensor(gathered, top)  # the path's only collective: final pose gather
-        return res
+        return {"stats": st, "n_clusters": n_clusters}
 
     def sync():
         if world > 1:
@@ -147,18 +145,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    vote_ms, votes, pairs = [], 0, 0
+    vote_ms, pair_ms, votes, pairs = [], [], 0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
         st = res["stats"]
         vote_ms.append(st["ms_vote_kernel"])
+        pair_ms.append(st["ms_pair_kernel"])
         votes += st["n_votes"]
         pairs += st["n_pairs"]
     sync()
     elapsed = time.perf_counter() - t0
 
-    n_poses_clustered = len(res["poses"])
+    n_poses_clustered = res["n_clusters"]
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(votes), float(pairs)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -199,6 +198,8 @@ def main():
             "scene_pairs_per_s": all_pairs / elapsed,
             "votes_per_step_per_gpu": st["n_votes"],
             "clustered_poses": n_poses_clustered,
+            "kernel_ms": {"k_pairs": float(np.mean(pair_ms)), "k_vote": float(np.mean(vote_ms)),
+                          "device_total": st["ms_total_device"]},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_vote",

@@ -1,0 +1,108 @@
+/*
+ * cloud_processor_demo.cpp — the reference's PPF call sequence on the HIP engine.
+ *
+ * A cut-down ppf::CloudProcessor (the PPF half of /root/reference/include/CloudProcessing.h) written
+ * against include/ppf_match_3d.hpp instead of <opencv2/surface_matching.hpp>.  Method bodies keep the
+ * reference's structure line for line so the diff a maintainer has to make is visible:
+ *   LoadSingleModel  CloudProcessing.h:209-221      TrainDetector  :222-261
+ *   Matching         :428-480                       Matching_S2B   :481-533   (ICP step: see INTEGRATION.md)
+ * and main() follows src/YOLO_cropping_ppf_test.cpp:113-127.
+ *
+ *   usage: cloud_processor_demo model.ply scene.ply [edge.ply] [out.ply]
+ *   build: g++ -std=c++17 -Iinclude examples/cloud_processor_demo.cpp -Lyolo_ppf_pose_estimation_amd/csrc -lppf_hip
+ */
+#include <chrono>
+#include <iostream>
+#include <map>
+
+#include "ppf_match_3d.hpp"
+
+using namespace std;
+using namespace ppfhip;
+using namespace ppfhip::ppf_match_3d;
+
+class CloudProcessor {
+  vector<Mat> models;
+  map<double, string> id_to_label;
+  map<string, double> label_to_id;
+  vector<bool> if_trained;
+  double relativeSamplingStep, relativeDistanceStep;
+
+ public:
+  vector<PPF3DDetector> detectors;
+  CloudProcessor(double relativeSamplingStep_input = 0.025, double relativeDistanceStep_input = 0.05)
+      : relativeSamplingStep(relativeSamplingStep_input), relativeDistanceStep(relativeDistanceStep_input) {}
+  ~CloudProcessor() {
+    for (uint32_t i = 0; i < detectors.size(); i++) detectors[i].~PPF3DDetector(); /* as the reference does (:79-83) */
+  }
+  void LoadSingleModel(Mat model_input, string label) {
+    models.push_back(model_input);
+    int id = (int)models.size() - 1;
+    if_trained.push_back(false);
+    label_to_id[label] = id;
+    id_to_label[id] = label;
+    ppf_match_3d::PPF3DDetector detector(relativeSamplingStep, relativeDistanceStep);
+    detectors.push_back(detector);
+    cout << "Loaded, having " << models.size() << " models now. " << endl;
+  }
+  void TrainDetector(double relativeSamplingStep_train, double relativeDistanceStep_train) {
+    for (uint32_t i = 0; i < models.size(); i++) {
+      cout << "Training the " << (i + 1) << " model in: ";
+      ppf_match_3d::PPF3DDetector detector(relativeSamplingStep_train, relativeDistanceStep_train);
+      auto t1 = chrono::steady_clock::now();
+      detector.trainModel(models[i]);
+      auto t2 = chrono::steady_clock::now();
+      cout << chrono::duration<double>(t2 - t1).count() << "sec" << endl;
+      detectors[i] = detector;
+      if_trained[i] = true;
+    }
+  }
+  Pose3D Matching_S2B(const string name, Mat scene, Mat edge, double relativeSceneSampleStep = 0.05, double relativeSceneDistance = 0.05) {
+    int id = (int)label_to_id[name];
+    PPF3DDetector detector = detectors[id]; /* by-value copy, as the reference does (:485) */
+    vector<Pose3DPtr> results;
+    if (!if_trained[id]) throw Error(PPF_ERR_NOT_TRAINED, "Model [" + name + "] not trained yet.");
+    cout << "Start Matching [" << name << "]" << endl;
+    auto t1 = chrono::steady_clock::now();
+    if (edge.empty()) detector.match(scene, results, relativeSceneSampleStep, relativeSceneDistance);
+    else detector.match_S2B(scene, edge, results, relativeSceneSampleStep, relativeSceneDistance);
+    auto t2 = chrono::steady_clock::now();
+    cout << endl << "PPF Elapsed Time " << chrono::duration<double>(t2 - t1).count() << " sec" << endl;
+    size_t results_size = results.size();
+    if (results_size == 0) {
+      cout << "No matching Poses found. Exiting." << endl;
+      exit(0);
+    }
+    size_t N = 5;
+    if (results_size < N) N = results_size;
+    vector<Pose3DPtr> resultsSub(results.begin(), results.begin() + N);
+    /* the reference refines resultsSub with ICP(100, 0.005f, 2.5f, 8) here (:518-523) */
+    return *resultsSub[0];
+  }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    cerr << "usage: " << argv[0] << " model.ply scene.ply [edge.ply|-] [out.ply] [train_step]" << endl;
+    return 1;
+  }
+  try {
+    Mat bottle = loadPLYSimple(argv[1], 1);
+    Mat objMat = loadPLYSimple(argv[2], 1);
+    Mat edgeMat;
+    if (argc > 3 && string(argv[3]) != "-") edgeMat = loadPLYSimple(argv[3], 1);
+    const double train_step = argc > 5 ? atof(argv[5]) : 0.05;
+    CloudProcessor Processor(train_step, 0.05);
+    Processor.LoadSingleModel(bottle, "bottle");
+    Processor.TrainDetector(train_step, 0.05);
+    Pose3D result_pose = Processor.Matching_S2B("bottle", objMat, edgeMat, 0.05, 0.05);
+    result_pose.printPose();
+    Mat pct = transformPCPose(bottle, result_pose.pose);
+    if (argc > 4) writePLY(pct, argv[4]);
+    cout << "RESULT votes=" << result_pose.numVotes << " modelIndex=" << result_pose.modelIndex << endl;
+  } catch (const Error& e) {
+    cerr << "ppf error " << (int)e.status << ": " << e.what() << endl;
+    return 10 + (int)e.status;
+  }
+  return 0;
+}

@@ -1,0 +1,279 @@
+/*
+ * ppf_match_3d.hpp — header-only C++ facade over the C-ABI (ppf_hip.h), shaped like the part of
+ * OpenCV's cv::ppf_match_3d that /root/reference/include/CloudProcessing.h and
+ * /root/reference/src/YOLO_cropping_ppf_test.cpp use:
+ *
+ *     PPF3DDetector(relSampling, relDistance)          CloudProcessing.h:205,217,234
+ *     detector.trainModel(Mat)                         :236
+ *     detector.match(scene, results, step, dist)       :442
+ *     detector.match_S2B(scene, edge, results, ...)    :495
+ *     detector.read(...) / detector.write(...)         :112 / :250
+ *     by-value copies, explicit ~PPF3DDetector()       :81,206,218,240,432,485
+ *     Pose3D (.pose, printPose), Pose3DPtr             src:122-125
+ *     loadPLYSimple / transformPCPose / writePLY       src:114,125,127
+ *
+ * It compiles WITHOUT OpenCV: clouds are ppf_match_3d::Mat (rows x cols float32, row-major, the
+ * layout of the N x 6 CV_32FC1 Mat the reference builds at CloudProcessing.h:163-190).  When
+ * <opencv2/core.hpp> is available the same calls also take cv::Mat (zero-copy).
+ *
+ * Failures of the C-ABI become exceptions (ppf_match_3d::Error carries the status and the
+ * library's message), which is how CV_Error / CV_Assert surface in the reference's library.
+ * The detector is a ref-counted handle: copies share the device table, destruction (even the
+ * reference's explicit double destruction) is safe.
+ */
+#ifndef PPF_MATCH_3D_HPP
+#define PPF_MATCH_3D_HPP
+
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ppf_hip.h"
+
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>) && !defined(PPF_MATCH_3D_NO_OPENCV)
+#include <opencv2/core.hpp>
+#define PPF_MATCH_3D_HAVE_OPENCV 1
+#endif
+#endif
+
+namespace ppfhip {
+namespace ppf_match_3d {
+
+class Error : public std::runtime_error {
+ public:
+  Error(ppf_status st, const std::string& msg) : std::runtime_error(msg), status(st) {}
+  ppf_status status;
+};
+
+inline void check(ppf_status st) {
+  if (st == PPF_OK) return;
+  char buf[512];
+  ppf_last_error(buf, (int)sizeof(buf));
+  throw Error(st, buf);
+}
+
+/* Minimal float32 matrix with the accessors the reference uses on cv::Mat for point clouds. */
+class Mat {
+ public:
+  Mat() : rows(0), cols(0) {}
+  Mat(int r, int c) : rows(r), cols(c), data_(new std::vector<float>((size_t)r * c, 0.f)) {}
+  Mat(int r, int c, const float* src) : rows(r), cols(c), data_(new std::vector<float>(src, src + (size_t)r * c)) {}
+  int rows, cols;
+  bool empty() const { return rows == 0 || !data_; }
+  template <class T = float> T* ptr(int i = 0) { return reinterpret_cast<T*>(data_->data() + (size_t)i * cols); }
+  template <class T = float> const T* ptr(int i = 0) const { return reinterpret_cast<const T*>(data_->data() + (size_t)i * cols); }
+  float& at(int i, int j) { return (*data_)[(size_t)i * cols + j]; }
+  float at(int i, int j) const { return (*data_)[(size_t)i * cols + j]; }
+  Mat clone() const { return empty() ? Mat() : Mat(rows, cols, data_->data()); }
+
+ private:
+  std::shared_ptr<std::vector<float>> data_;
+};
+
+typedef std::array<double, 16> Matx44d; /* row-major 4x4 */
+
+/* cv::ppf_match_3d::Pose3D */
+class Pose3D {
+ public:
+  Pose3D() : alpha(0), residual(0), modelIndex(0), numVotes(0), angle(0) {
+    pose.fill(0); pose[0] = pose[5] = pose[10] = pose[15] = 1;
+    t[0] = t[1] = t[2] = 0; q[0] = 1; q[1] = q[2] = q[3] = 0;
+  }
+  explicit Pose3D(const ppf_pose& p) : alpha(p.alpha), residual(p.residual), modelIndex(p.model_index),
+                                       numVotes(p.num_votes), angle(p.angle) {
+    std::memcpy(pose.data(), p.pose, sizeof(p.pose));
+    std::memcpy(t, p.t, sizeof(t));
+    std::memcpy(q, p.q, sizeof(q));
+  }
+  void printPose() const {
+    std::printf("\n-- Pose to Model Index %u: NumVotes = %u, Residual = %f\n", modelIndex, numVotes, residual);
+    for (int i = 0; i < 4; i++) std::printf("[%g, %g, %g, %g]\n", pose[i * 4], pose[i * 4 + 1], pose[i * 4 + 2], pose[i * 4 + 3]);
+  }
+  std::shared_ptr<Pose3D> clone() const { return std::make_shared<Pose3D>(*this); }
+
+  double alpha, residual;
+  unsigned modelIndex, numVotes;
+  Matx44d pose;
+  double angle;
+  double t[3];
+  double q[4];
+};
+typedef std::shared_ptr<Pose3D> Pose3DPtr; /* cv::Ptr<T> is std::shared_ptr<T> in OpenCV 4 */
+
+class PPF3DDetector {
+ public:
+  PPF3DDetector() : PPF3DDetector(0.05, 0.05, 30) {}
+  PPF3DDetector(double relativeSamplingStep, double relativeDistanceStep = 0.05, double numAngles = 30) : model_(nullptr) {
+    ppf_default_train_params(&tp_);
+    tp_.relative_sampling_step = relativeSamplingStep;
+    tp_.relative_distance_step = relativeDistanceStep;
+    tp_.num_angles = numAngles;
+    ppf_default_match_params(&mp_);
+  }
+  PPF3DDetector(const PPF3DDetector& o) : tp_(o.tp_), mp_(o.mp_), model_(o.model_) {
+    if (model_) ppf_model_retain(model_);
+  }
+  PPF3DDetector& operator=(const PPF3DDetector& o) {
+    if (this != &o) {
+      if (o.model_) ppf_model_retain(o.model_);
+      if (model_) ppf_model_release(model_);
+      tp_ = o.tp_; mp_ = o.mp_; model_ = o.model_;
+    }
+    return *this;
+  }
+  /* idempotent: the reference destroys its detectors explicitly and then again through the vector */
+  virtual ~PPF3DDetector() {
+    if (model_) { ppf_model_release(model_); model_ = nullptr; }
+  }
+
+  void setSearchParams(double positionThreshold = -1, double rotationThreshold = -1, bool useWeightedClustering = false) {
+    mp_.position_threshold = positionThreshold;
+    mp_.rotation_threshold = rotationThreshold;
+    mp_.use_weighted_avg = useWeightedClustering ? 1 : 0;
+  }
+  bool isTrained() const { return model_ != nullptr; }
+
+  void trainModel(const float* xyzn, int rows, int strideFloats) {
+    ppf_model* m = nullptr;
+    check(ppf_model_train(xyzn, rows, strideFloats, &tp_, &m));
+    if (model_) ppf_model_release(model_);
+    model_ = m;
+  }
+  void match(const float* scene, int rows, int stride, std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 1.0 / 5.0,
+             double relativeSceneDistance = 0.03) {
+    run(scene, rows, stride, nullptr, 0, 6, results, relativeSceneSampleStep, relativeSceneDistance);
+  }
+  void match_S2B(const float* scene, int rows, int stride, const float* edge, int erows, int estride,
+                 std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 0.05, double relativeSceneDistance = 0.05) {
+    run(scene, rows, stride, edge, erows, estride, results, relativeSceneSampleStep, relativeSceneDistance);
+  }
+
+  /* anything with rows / cols / ptr<float>(i): ppf_match_3d::Mat, cv::Mat */
+  template <class M> void trainModel(const M& pc) { require_cloud(pc, "trainModel"); trainModel(pc.template ptr<float>(0), pc.rows, stride_of(pc)); }
+  template <class M>
+  void match(const M& pc, std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 1.0 / 5.0, double relativeSceneDistance = 0.03) {
+    require_cloud(pc, "match");
+    match(pc.template ptr<float>(0), pc.rows, stride_of(pc), results, relativeSceneSampleStep, relativeSceneDistance);
+  }
+  template <class M>
+  void match_S2B(const M& scene, const M& edge, std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 0.05,
+                 double relativeSceneDistance = 0.05) {
+    require_cloud(scene, "match_S2B"); require_cloud(edge, "match_S2B");
+    match_S2B(scene.template ptr<float>(0), scene.rows, stride_of(scene), edge.template ptr<float>(0), edge.rows, stride_of(edge), results,
+              relativeSceneSampleStep, relativeSceneDistance);
+  }
+
+  /* (de)serialisation: the reference's FileStorage XML format comes from a private OpenCV patch and is
+   * unknown; the engine keeps a versioned binary table file instead */
+  void write(const std::string& path) const { require_trained(); check(ppf_model_save(model_, path.c_str())); }
+  void read(const std::string& path) {
+    ppf_model* m = nullptr;
+    check(ppf_model_load(path.c_str(), &m));
+    if (model_) ppf_model_release(model_);
+    model_ = m;
+    ppf_model_info info;
+    check(ppf_model_get_info(model_, &info));
+  }
+  ppf_model_info info() const { require_trained(); ppf_model_info i; check(ppf_model_get_info(model_, &i)); return i; }
+  const ppf_model* handle() const { return model_; }
+
+ private:
+  template <class M> static int stride_of(const M& m) { return m.cols; }
+  template <class M> static void require_cloud(const M& m, const char* who) {
+    if (m.rows <= 0 || m.cols < 6) throw Error(PPF_ERR_INVALID, std::string(who) + ": expected an N x 6 float32 cloud (x y z nx ny nz)");
+  }
+  void require_trained() const {
+    if (!model_) throw Error(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  }
+  void run(const float* scene, int rows, int stride, const float* edge, int erows, int estride, std::vector<Pose3DPtr>& results,
+           double step, double dist) {
+    require_trained();
+    ppf_match_params p = mp_;
+    p.relative_scene_sample_step = step;
+    p.relative_scene_distance = dist;
+    int cap = rows + 8, n = 0;
+    std::vector<ppf_pose> out((size_t)cap);
+    check(ppf_match(model_, scene, rows, stride, edge, erows, estride, &p, out.data(), cap, &n));
+    results.clear();
+    results.reserve((size_t)n);
+    for (int i = 0; i < n; i++) results.push_back(std::make_shared<Pose3D>(out[(size_t)i]));
+  }
+
+  ppf_train_params tp_;
+  ppf_match_params mp_;
+  ppf_model* model_;
+};
+
+/* ---- helpers the reference's driver takes from the same namespace ---------------------------------- */
+inline Mat loadPLYSimple(const char* fileName, int withNormals = 0) {
+  std::ifstream ifs(fileName);
+  if (!ifs.is_open()) throw Error(PPF_ERR_IO, std::string("Error opening input file: ") + fileName);
+  std::string line;
+  int numVertices = 0, numProps = 0;
+  bool inVertex = false;
+  while (std::getline(ifs, line)) {
+    std::istringstream ss(line);
+    std::string tok;
+    ss >> tok;
+    if (tok == "element") { std::string what; ss >> what; inVertex = (what == "vertex"); if (inVertex) ss >> numVertices; }
+    else if (tok == "property" && inVertex) numProps++;
+    else if (tok == "format") { std::string f; ss >> f; if (f != "ascii") throw Error(PPF_ERR_IO, "loadPLYSimple: only ascii PLY is supported"); }
+    else if (tok == "end_header") break;
+  }
+  const int cols = withNormals ? 6 : 3;
+  if (numProps < cols) throw Error(PPF_ERR_IO, "loadPLYSimple: not enough vertex properties");
+  Mat cloud(numVertices, cols);
+  for (int i = 0; i < numVertices; i++) {
+    float* row = cloud.ptr<float>(i);
+    std::getline(ifs, line);
+    std::istringstream ss(line);
+    for (int c = 0; c < numProps; c++) { float v; ss >> v; if (c < cols) row[c] = v; }
+    if (withNormals) {
+      const double nrm = std::sqrt((double)row[3] * row[3] + (double)row[4] * row[4] + (double)row[5] * row[5]);
+      if (nrm > 0.00001) { row[3] = (float)(row[3] / nrm); row[4] = (float)(row[4] / nrm); row[5] = (float)(row[5] / nrm); }
+    }
+  }
+  return cloud;
+}
+
+inline void writePLY(const Mat& pc, const char* fileName) {
+  std::ofstream out(fileName);
+  if (!out) throw Error(PPF_ERR_IO, std::string("Error opening output file: ") + fileName);
+  out << "ply\nformat ascii 1.0\nelement vertex " << pc.rows << "\nproperty float x\nproperty float y\nproperty float z\n";
+  if (pc.cols >= 6) out << "property float nx\nproperty float ny\nproperty float nz\n";
+  out << "end_header\n";
+  for (int i = 0; i < pc.rows; i++) {
+    const float* r = pc.ptr<float>(i);
+    out << r[0] << " " << r[1] << " " << r[2];
+    if (pc.cols >= 6) out << " " << r[3] << " " << r[4] << " " << r[5];
+    out << "\n";
+  }
+}
+
+inline Mat transformPCPose(const Mat& pc, const Matx44d& pose) {
+  if (pc.cols < 6) throw Error(PPF_ERR_INVALID, "transformPCPose: expected an N x 6 cloud");
+  Mat out(pc.rows, 6);
+  check(ppf_transform_pc_pose(pc.ptr<float>(0), pc.rows, pc.cols, pose.data(), out.ptr<float>(0)));
+  return out;
+}
+
+inline Mat samplePCByQuantization(const Mat& pc, float sampleStep) {
+  int n = 0;
+  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, sampleStep, nullptr, 0, &n));
+  Mat out(n, 6);
+  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, sampleStep, out.ptr<float>(0), n, &n));
+  return out;
+}
+
+}  // namespace ppf_match_3d
+}  // namespace ppfhip
+
+#endif /* PPF_MATCH_3D_HPP */

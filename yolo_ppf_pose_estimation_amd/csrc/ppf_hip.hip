@@ -336,6 +336,170 @@ __global__ void k_finalize(FinalArgs a) {
   a.poses[r] = P;
 }
 
+/* ---- pose clustering (row A7: clusterPoses / matchPose / PoseCluster3D), one workgroup ---------------
+ * 1. rank poses by (votes desc, input index asc)   [the reference's std::sort is not stable; this total
+ *    order is the frozen one]                       O(n^2) counting, n <= a few thousand
+ * 2. greedy: in rank order, a pose joins the FIRST cluster (creation order) whose first pose is within
+ *    position_threshold (|dt|) and rotation_threshold (|angle difference|), else it opens a cluster.
+ *    Sequential over poses, parallel over cluster heads (min-reduce of the matching cluster index).
+ * 3. per cluster: quaternion / translation sums taken in joining order (fp64, same order as the CPU
+ *    restatement, so results are bit-identical), plain or vote-weighted mean, pose rebuilt from the mean
+ *    quaternion; cluster votes = sum of member votes.
+ * 4. clusters ranked by (votes desc, creation order asc) and written out.
+ */
+struct ClusterArgs {
+  const ppf_pose* in;
+  int n, num_poses;
+  double pos_thr, rot_thr;
+  int weighted;
+  uint32_t* order;    /* [n] rank -> pose */
+  uint32_t* assign;   /* [n] rank position -> cluster */
+  uint32_t* head;     /* [n] cluster -> pose index of its first member */
+  unsigned long long* cvotes; /* [n] */
+  uint32_t* crank;    /* [n] cluster -> output slot */
+  double* soa;        /* [8n] ranked poses tx,ty,tz,angle | cluster heads hx,hy,hz,hangle */
+  ppf_pose* out;      /* [n] */
+  uint32_t* n_out;
+};
+
+/*
+ * Step 2 without 2,500 serial barrier rounds: poses are taken 1024 at a time (rank order).
+ *   A. every thread looks its pose up among the clusters that existed BEFORE the block; a hit there is
+ *      final, because clusters opened later have larger indices and the rule is "first cluster".
+ *   B. one wave then walks the block's unmatched poses in order; each is compared (64 lanes in
+ *      parallel) only with the clusters opened inside this block, joins the first match or opens one.
+ * The serial part is proportional to the number of clusters opened, not to the number of poses.
+ */
+__global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
+  extern __shared__ __align__(16) unsigned char csm[];
+  uint32_t* s_votes = reinterpret_cast<uint32_t*>(csm); /* [n] votes, later cluster votes (low words) */
+  __shared__ uint32_t s_nclusters;
+  __shared__ uint32_t s_match[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.n;
+  const int np = min(a.num_poses, n);
+  double* px = a.soa; double* py = px + n; double* pz = py + n; double* pa = pz + n;
+  double* hx = pa + n; double* hy = hx + n; double* hz = hy + n; double* ha = hz + n;
+  /* 1. ranks by (votes desc, index asc) */
+  for (int i = tid; i < n; i += 1024) s_votes[i] = a.in[i].num_votes;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t vi = s_votes[i];
+    uint32_t rank = 0;
+    for (int j = 0; j < n; j++) {
+      const uint32_t vj = s_votes[j];
+      rank += (vj > vi || (vj == vi && j < i)) ? 1u : 0u;
+    }
+    a.order[rank] = (uint32_t)i;
+    px[rank] = a.in[i].t[0]; py[rank] = a.in[i].t[1]; pz[rank] = a.in[i].t[2]; pa[rank] = a.in[i].angle;
+  }
+  if (tid == 0) s_nclusters = 0;
+  __syncthreads();
+  /* 2. greedy first-match assignment */
+  for (int s0 = 0; s0 < np; s0 += 1024) {
+    const uint32_t nc0 = s_nclusters;
+    const int s = s0 + tid;
+    uint32_t mine = 0xFFFFFFFFu;
+    if (s < np) {
+      const double tx = px[s], ty = py[s], tz = pz[s], ang = pa[s];
+      for (uint32_t c = 0; c < nc0; c++) {
+        const double dx = hx[c] - tx, dy = hy[c] - ty, dz = hz[c] - tz;
+        const double dn = ppf_sqrt(dx * dx + dy * dy + dz * dz);
+        const double phi = ppf_fabs(ang - ha[c]);
+        if (phi < a.rot_thr && dn < a.pos_thr) { mine = c; break; }
+      }
+    }
+    s_match[tid] = mine;
+    __syncthreads();
+    if (wave == 0) {
+      const int cnt = min(1024, np - s0);
+      uint32_t nc = nc0;
+      for (int k = 0; k < cnt; k++) {
+        uint32_t m = s_match[k];
+        const int sk = s0 + k;
+        if (m == 0xFFFFFFFFu) {
+          const double tx = px[sk], ty = py[sk], tz = pz[sk], ang = pa[sk];
+          for (uint32_t cb = nc0; cb < nc && m == 0xFFFFFFFFu; cb += 64) {
+            const uint32_t c = cb + lane;
+            bool hit = false;
+            if (c < nc) {
+              const double dx = hx[c] - tx, dy = hy[c] - ty, dz = hz[c] - tz;
+              const double dn = ppf_sqrt(dx * dx + dy * dy + dz * dz);
+              const double phi = ppf_fabs(ang - ha[c]);
+              hit = phi < a.rot_thr && dn < a.pos_thr;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (bal) m = cb + (uint32_t)(__ffsll((long long)bal) - 1);
+          }
+          if (m == 0xFFFFFFFFu) { /* open a cluster */
+            m = nc;
+            if (lane == 0) {
+              a.head[m] = a.order[sk];
+              a.cvotes[m] = 0;
+              hx[m] = tx; hy[m] = ty; hz[m] = tz; ha[m] = ang;
+            }
+            nc++;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+        }
+        if (lane == 0) {
+          a.assign[sk] = m;
+          a.cvotes[m] += a.in[a.order[sk]].num_votes;
+        }
+      }
+      if (lane == 0) s_nclusters = nc;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const int nc = (int)s_nclusters;
+  /* 4a. cluster ranks by (votes desc, creation order asc) */
+  for (int c = tid; c < nc; c += 1024) {
+    const unsigned long long vc = a.cvotes[c];
+    uint32_t rank = 0;
+    for (int d = 0; d < nc; d++) {
+      const unsigned long long vd = a.cvotes[d];
+      rank += (vd > vc || (vd == vc && d < c)) ? 1u : 0u;
+    }
+    a.crank[c] = rank;
+  }
+  __syncthreads();
+  /* 3 + 4b. averages in joining order, rebuild the pose, write to the ranked slot */
+  for (int c = tid; c < nc; c += 1024) {
+    double q[4] = {0, 0, 0, 0}, t[3] = {0, 0, 0}, wsum = 0;
+    int members = 0;
+    for (int s = 0; s < np; s++) {
+      if (a.assign[s] != (uint32_t)c) continue;
+      const ppf_pose& p = a.in[a.order[s]];
+      if (a.weighted) {
+        const double w = (double)p.num_votes;
+        for (int k = 0; k < 4; k++) q[k] += w * p.q[k];
+        for (int k = 0; k < 3; k++) t[k] += w * p.t[k];
+        wsum += w;
+      } else {
+        for (int k = 0; k < 4; k++) q[k] += p.q[k];
+        for (int k = 0; k < 3; k++) t[k] += p.t[k];
+      }
+      members++;
+    }
+    const double inv = a.weighted ? 1.0 / wsum : 1.0 / members;
+    for (int k = 0; k < 3; k++) t[k] *= inv;
+    for (int k = 0; k < 4; k++) q[k] *= inv;
+    ppf_pose P = a.in[a.head[c]];
+    double R[9];
+    ppf_quat_to_dcm(q, R);
+    for (int k = 0; k < 4; k++) P.q[k] = q[k];
+    for (int k = 0; k < 3; k++) P.t[k] = t[k];
+    ppf_rt_to_pose(R, t, P.pose);
+    P.angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
+    P.num_votes = (uint32_t)a.cvotes[c];
+    a.out[a.crank[c]] = P;
+  }
+  if (tid == 0) *a.n_out = (uint32_t)nc;
+}
+
 /* ============================================================================================ */
 /* host side                                                                                      */
 /* ============================================================================================ */
@@ -481,6 +645,10 @@ struct ppf_workspace {
   DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
+  DevBuf<ppf_pose> d_final;
+  DevBuf<uint32_t> cl_u32;              /* order | assign | head | crank | n_out */
+  DevBuf<unsigned long long> cl_votes;
+  DevBuf<double> cl_soa;
   std::vector<ppf_pose> final_poses;
   bool clustered = false;
   ppf_match_stats stats{};
@@ -496,77 +664,40 @@ struct ppf_workspace {
 
 namespace {
 
-/* Row A7 (clusterPoses) — greedy first-match clustering on the host for now (device: next).
- * Total orders frozen as (votes desc, input order asc) / (cluster votes desc, creation asc). */
-void cluster_poses_host(const std::vector<ppf_pose>& in, int num_poses, double pos_thr, double rot_thr, bool weighted,
-                        std::vector<ppf_pose>& out) {
-  std::vector<int> order(in.size());
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return in[a].num_votes > in[b].num_votes; });
-  num_poses = std::min<int>(num_poses, (int)order.size());
-  std::vector<std::vector<int>> members;
-  std::vector<unsigned long long> cvotes;
-  for (int s = 0; s < num_poses; s++) {
-    const ppf_pose& p = in[order[s]];
-    bool assigned = false;
-    for (size_t c = 0; c < members.size() && !assigned; c++) {
-      const ppf_pose& h = in[members[c][0]];
-      const double dx = h.t[0] - p.t[0], dy = h.t[1] - p.t[1], dz = h.t[2] - p.t[2];
-      const double dn = std::sqrt(dx * dx + dy * dy + dz * dz);
-      const double phi = std::fabs(p.angle - h.angle);
-      if (phi < rot_thr && dn < pos_thr) {
-        members[c].push_back(order[s]);
-        cvotes[c] += p.num_votes;
-        assigned = true;
-      }
-    }
-    if (!assigned) {
-      members.push_back({order[s]});
-      cvotes.push_back(p.num_votes);
-    }
-  }
-  std::vector<int> corder(members.size());
-  std::iota(corder.begin(), corder.end(), 0);
-  std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cvotes[a] > cvotes[b]; });
-  out.clear();
-  out.reserve(members.size());
-  for (int ci : corder) {
-    const std::vector<int>& mem = members[ci];
-    double q[4] = {0, 0, 0, 0}, t[3] = {0, 0, 0};
-    if (weighted) {
-      double ws = 0;
-      for (int id : mem) {
-        const double w = (double)in[id].num_votes;
-        for (int k = 0; k < 4; k++) q[k] += w * in[id].q[k];
-        for (int k = 0; k < 3; k++) t[k] += w * in[id].t[k];
-        ws += w;
-      }
-      for (int k = 0; k < 3; k++) t[k] *= 1.0 / ws;
-      for (int k = 0; k < 4; k++) q[k] *= 1.0 / ws;
-    } else {
-      const int cs = (int)mem.size();
-      for (int id : mem) {
-        for (int k = 0; k < 4; k++) q[k] += in[id].q[k];
-        for (int k = 0; k < 3; k++) t[k] += in[id].t[k];
-      }
-      for (int k = 0; k < 3; k++) t[k] *= 1.0 / cs;
-      for (int k = 0; k < 4; k++) q[k] *= 1.0 / cs;
-    }
-    ppf_pose P = in[mem[0]];
-    double R[9];
-    ppf_quat_to_dcm(q, R);
-    for (int k = 0; k < 4; k++) P.q[k] = q[k];
-    for (int k = 0; k < 3; k++) P.t[k] = t[k];
-    ppf_rt_to_pose(R, t, P.pose);
-    P.angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
-    P.num_votes = (uint32_t)cvotes[ci];
-    out.push_back(P);
-  }
-}
+ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int num_poses, double pos, double rot,
+                           bool weighted, hipStream_t st);
 
 void resolve_thresholds(const ppf_model* m, const ppf_match_params* p, double* pos, double* rot) {
   *pos = p->position_threshold < 0 ? m->info.position_threshold_default : p->position_threshold;
   *rot = p->rotation_threshold < 0 ? m->info.rotation_threshold_default : p->rotation_threshold;
+}
+
+ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int num_poses, double pos, double rot,
+                           bool weighted, hipStream_t st) {
+  HIPCHK(ws->d_final.reserve(std::max(n, 1)));
+  HIPCHK(ws->cl_u32.reserve((size_t)4 * std::max(n, 1) + 1));
+  HIPCHK(ws->cl_votes.reserve(std::max(n, 1)));
+  HIPCHK(ws->cl_soa.reserve((size_t)8 * std::max(n, 1)));
+  if ((size_t)n * 4 > 120 * 1024) return fail(PPF_ERR_INVALID, "clustering more than 30720 poses per call is not supported");
+  ClusterArgs ca;
+  ca.soa = ws->cl_soa.p;
+  ca.in = d_in; ca.n = n; ca.num_poses = num_poses; ca.pos_thr = pos; ca.rot_thr = rot; ca.weighted = weighted ? 1 : 0;
+  ca.order = ws->cl_u32.p; ca.assign = ca.order + n; ca.head = ca.assign + n; ca.crank = ca.head + n;
+  ca.n_out = ca.crank + n;
+  ca.cvotes = ws->cl_votes.p;
+  ca.out = ws->d_final.p;
+  HIPCHK(hipMemsetAsync(ca.n_out, 0, sizeof(uint32_t), st));
+  if (n > 0) {
+    static std::once_flag once_c;
+    static hipError_t attr_c = hipSuccess;
+    std::call_once(once_c, [] {
+      attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    HIPCHK(attr_c);
+    k_cluster<<<dim3(1), dim3(1024), (size_t)n * 4, st>>>(ca);
+    HIPCHK(hipGetLastError());
+  }
+  return PPF_OK;
 }
 
 }  // namespace
@@ -955,6 +1086,16 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   fa.totals = ws->counters.p + (size_t)n_ref * T + n_ref;
   k_finalize<<<dim3((n_ref + 63) / 64), dim3(64), 0, st>>>(fa);
   HIPCHK(hipGetLastError());
+  if (!params->skip_clustering) {
+    double pos, rot;
+    resolve_thresholds(m, params, &pos, &rot);
+    /* the reference clusters sampled.rows / sceneSamplingStep poses (integer division: the lowest-voted
+     * pose is dropped when the stride does not divide the row count); a shard clusters its own share */
+    const int num = (params->ref_stride == 1 && params->ref_offset == 0) ? rows / scene_step : n_ref;
+    s = enqueue_cluster(ws, ws->raw_poses.p, n_ref, num, pos, rot, params->use_weighted_avg != 0, st);
+    if (s != PPF_OK) return s;
+    ws->clustered = true;
+  }
   if (ws->timing) HIPCHK(hipEventRecord(ws->ev[3], st));
   return PPF_OK;
 }
@@ -980,18 +1121,12 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
     if (votes) HIPCHK(hipMemcpy(votes, ws->votes.p, (size_t)nr * sizeof(ppf_vote), hipMemcpyDeviceToHost));
     if (raw_poses) HIPCHK(hipMemcpy(raw_poses, ws->raw_poses.p, (size_t)nr * sizeof(ppf_pose), hipMemcpyDeviceToHost));
   }
-  if ((poses || n_poses) && !ws->params.skip_clustering) {
-    if (!ws->clustered) {
-      std::vector<ppf_pose> raw((size_t)nr);
-      if (nr > 0) HIPCHK(hipMemcpy(raw.data(), ws->raw_poses.p, (size_t)nr * sizeof(ppf_pose), hipMemcpyDeviceToHost));
-      double pos, rot;
-      resolve_thresholds(ws->model, &ws->params, &pos, &rot);
-      /* the reference clusters sampled.rows / sceneSamplingStep poses (integer division); a shard
-       * clusters its own share */
-      const int scene_step = (int)(1.0 / ws->params.relative_scene_sample_step);
-      int num = (ws->params.ref_stride == 1 && ws->params.ref_offset == 0) ? ws->rows / scene_step : nr;
-      cluster_poses_host(raw, num, pos, rot, ws->params.use_weighted_avg != 0, ws->final_poses);
-      ws->clustered = true;
+  if ((poses || n_poses) && !ws->params.skip_clustering && ws->clustered) {
+    if (ws->final_poses.empty() && nr > 0) {
+      uint32_t nf = 0;
+      HIPCHK(hipMemcpy(&nf, ws->cl_u32.p + (size_t)4 * nr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      ws->final_poses.resize(nf);
+      if (nf) HIPCHK(hipMemcpy(ws->final_poses.data(), ws->d_final.p, (size_t)nf * sizeof(ppf_pose), hipMemcpyDeviceToHost));
     }
     ws->stats.n_poses = (int)ws->final_poses.size();
     if (n_poses) *n_poses = (int)ws->final_poses.size();
@@ -1078,14 +1213,24 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
                              const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
   if (!m) return fail(PPF_ERR_NOT_TRAINED, "ppf_cluster_poses: model is NULL");
   if ((!in && n > 0) || n < 0 || !params || !n_out) return fail(PPF_ERR_INVALID, "ppf_cluster_poses: bad argument");
-  std::vector<ppf_pose> raw(in, in + n), fin;
+  *n_out = 0;
+  if (n == 0) return PPF_OK;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_cluster_poses: no HIP device (this engine has no CPU fallback)");
+  ppf_workspace ws;
+  DevBuf<ppf_pose> d_in;
+  HIPCHK(d_in.reserve(n));
+  HIPCHK(hipMemcpy(d_in.p, in, (size_t)n * sizeof(ppf_pose), hipMemcpyHostToDevice));
   double pos, rot;
   resolve_thresholds(m, params, &pos, &rot);
-  cluster_poses_host(raw, num_poses, pos, rot, params->use_weighted_avg != 0, fin);
-  *n_out = (int)fin.size();
+  ppf_status s = enqueue_cluster(&ws, d_in.p, n, num_poses, pos, rot, params->use_weighted_avg != 0, nullptr);
+  if (s != PPF_OK) return s;
+  HIPCHK(hipStreamSynchronize(nullptr));
+  uint32_t nf = 0;
+  HIPCHK(hipMemcpy(&nf, ws.cl_u32.p + (size_t)4 * n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *n_out = (int)nf;
   if (out) {
-    if (cap < (int)fin.size()) return fail(PPF_ERR_CAPACITY, "ppf_cluster_poses: need room for %d poses", (int)fin.size());
-    memcpy(out, fin.data(), fin.size() * sizeof(ppf_pose));
+    if (cap < (int)nf) return fail(PPF_ERR_CAPACITY, "ppf_cluster_poses: need room for %d poses", (int)nf);
+    if (nf) HIPCHK(hipMemcpy(out, ws.d_final.p, (size_t)nf * sizeof(ppf_pose), hipMemcpyDeviceToHost));
   }
   return PPF_OK;
 }

@@ -49,11 +49,23 @@ class Workspace:
         check(lib().ppf_workspace_results(self.ptr, votes, raw, cap_ref, C.byref(n_ref), fin if want_poses else None,
                                           cap_ref, C.byref(n_pose) if want_poses else None, C.byref(st)))
         nr = n_ref.value
-        tri = np.array([[votes[i].ref_ind_max, votes[i].alpha_ind_max, votes[i].max_votes] for i in range(nr)],
-                       dtype=np.uint32).reshape(nr, 3)
+        tri = np.frombuffer(votes, dtype=np.uint32)[: 3 * nr].reshape(nr, 3).copy()
         return {"n_ref": nr, "triples": tri, "raw_poses": [Pose3D(raw[i]) for i in range(nr)],
                 "poses": [Pose3D(fin[i]) for i in range(n_pose.value)] if want_poses else [],
                 "stats": {k: getattr(st, k) for k, _ in MatchStats._fields_}}
+
+    def top_poses(self, k: int):
+        """Wait for the call and fetch only the clustered poses (as a ctypes array of ppf_pose records, at most
+        `cap` of them are converted by the caller) and the counters -- the lean per-step read-back."""
+        if not hasattr(self, "_fin") or len(self._fin) < self._cap_hint:
+            self._fin = (Pose * self._cap_hint)()
+        n_pose = C.c_int(0)
+        st = MatchStats()
+        check(lib().ppf_workspace_results(self.ptr, None, None, 0, None, self._fin, self._cap_hint, C.byref(n_pose),
+                                          C.byref(st)))
+        return self._fin, min(n_pose.value, k), n_pose.value, {f: getattr(st, f) for f, _ in MatchStats._fields_}
+
+    _cap_hint = 65536
 
     def stats(self) -> dict:
         st = MatchStats()
