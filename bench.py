@@ -106,7 +106,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from yolo_ppf_pose_estimation_amd import synth
+    from yolo_ppf_pose_estimation_amd import parallel, synth
     from yolo_ppf_pose_estimation_amd._capi import Pose
     from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
     from yolo_ppf_pose_estimation_amd.device import Workspace
@@ -121,9 +121,6 @@ def main():
     stream = torch.cuda.Stream()
     ws = Workspace(timing=True)
     n_ref_total = (SCENE_POINTS + int(1.0 / SCENE_STEP) - 1) // int(1.0 / SCENE_STEP)
-    pose_words = C.sizeof(Pose) // 8
-    top = torch.zeros((TOP_K, pose_words), dtype=torch.float64, device="cuda")
-    gathered = torch.zeros((world * TOP_K, pose_words), dtype=torch.float64, device="cuda") if world > 1 else None
 
     def step():
         with torch.cuda.stream(stream):
@@ -132,9 +129,8 @@ def main():
             # waits for the stream; clustering already ran on the device, only the clustered poses come back
             fin, k_top, n_clusters, st = ws.top_poses(TOP_K)
             if world > 1:
-                host = np.frombuffer(fin, dtype=np.float64)[: TOP_K * pose_words].reshape(TOP_K, pose_words)
-                top.copy_(torch.from_numpy(host.copy()), non_blocking=False)
-                dist.all_gather_into_tensor(gathered, top)  # the path's only collective: final pose gather
+                # the path's only collective: all_gather (RCCL) of each rank's top poses, 5 x 216 B per rank
+                parallel.gather_poses(parallel.poses_to_array(fin, k_top, TOP_K), device="cuda")
         return {"stats": st, "n_clusters": n_clusters}
 
     def sync():
