@@ -113,7 +113,7 @@ def main():
     import ctypes as C
 
     bottle = np.load(os.path.join(ROOT, "tests", "golden", "bottle_model_xyzn.npy"))
-    det = PPF3DDetector(MODEL_STEP, 0.05).trainModel(bottle)
+    det = PPF3DDetector(MODEL_STEP, 0.05, max_tile_refs=int(os.environ.get("PPF_TILE_REFS", "0"))).trainModel(bottle)
     info = det.info()
     seed = 12345 if world == 1 else 1000 + rank
     scene, _ = synth.make_scene(bottle, n_points=SCENE_POINTS, seed=seed)

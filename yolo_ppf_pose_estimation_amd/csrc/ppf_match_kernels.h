@@ -46,8 +46,17 @@ constexpr int PAIRS_PER_THREAD = 8;   /* one k_pairs workgroup covers 2048 paire
 constexpr int VOTE_BLOCK = 1024;
 constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
 constexpr int VOTE_UNROLL = 8;        /* entry loads in flight per lane */
-constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * 4; /* table entries per work item (2048) */
-constexpr int VOTE_MAX_HITS = 16;     /* hits of one bucket run voted per work item */
+#ifndef PPF_VOTE_CHUNK_BATCHES
+#define PPF_VOTE_CHUNK_BATCHES 4
+#endif
+#ifndef PPF_VOTE_MAX_HITS
+#define PPF_VOTE_MAX_HITS 16
+#endif
+#ifndef PPF_VOTE_DYNAMIC
+#define PPF_VOTE_DYNAMIC 1
+#endif
+constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * PPF_VOTE_CHUNK_BATCHES; /* table entries per work item (2048) */
+constexpr int VOTE_MAX_HITS = PPF_VOTE_MAX_HITS; /* hits of one bucket run voted per work item */
 constexpr int GROUP_BLOCK = 1024;
 constexpr int VOTE_SEG = VOTE_BLOCK;  /* hits staged in LDS per segment: one per thread */
 constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + run-start masks (16 x u64) */
@@ -414,12 +423,22 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     }
     seg_prefix[tid] = woff + incl - items; /* exclusive */
     if (tid < 64) seg_prefix[VOTE_SEG + tid] = total; /* sentinel + padding for the 64-wide look-ahead */
+#if PPF_VOTE_DYNAMIC
+    if (tid == 0) red[48] = VOTE_WAVES; /* next unclaimed work item (each wave starts with item == its id) */
+#endif
     __syncthreads();
 
     /* waves take work items round-robin; the owning run start is found with a 64-wide look-ahead
      * from the previous one (positions that start no run in this tile have 0 items and are skipped) */
     int h = 0;
+#if PPF_VOTE_DYNAMIC
+    /* work items are claimed from an LDS counter as waves become free (items of one segment differ by
+     * orders of magnitude in size); a wave's items still come in increasing order */
+    for (uint32_t item = wave; item < total;
+         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u))) {
+#else
     for (uint32_t item = wave; item < total; item += VOTE_WAVES) {
+#endif
       while (true) { /* advance h to the last position with prefix <= item */
         const uint32_t pv = seg_prefix[min(h + 1 + lane, VOTE_SEG + 63)];
         const unsigned long long le = __ballot(pv <= item);
