@@ -142,6 +142,17 @@ __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_st
   }
 }
 
+__global__ void k_bucket_total(const uint32_t* __restrict__ bucket_off, int n_buckets, int n_tiles, uint32_t* __restrict__ total) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) return;
+  uint32_t t = 0;
+  for (int k = 0; k < n_tiles; k++) {
+    const uint32_t* row = bucket_off + (size_t)k * (n_buckets + 1);
+    t += row[b + 1] - row[b];
+  }
+  total[b] = t;
+}
+
 __global__ void k_popcount_words(const unsigned long long* __restrict__ bits, uint32_t* __restrict__ cnt, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) cnt[i] = (uint32_t)__popcll(bits[i]);
@@ -630,6 +641,7 @@ struct ppf_model {
   DevBuf<SlotWord> slotmap;
   DevBuf<uint32_t> bucket_off;  /* n_tiles * (n_buckets + 1) */
   DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
+  DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
   DevBuf<uint2> entries;
   int device = 0;
 };
@@ -642,6 +654,8 @@ struct ppf_workspace {
   DevBuf<HitRec> hits;
   DevBuf<uint2> keys_a, keys_b;
   DevBuf<uint32_t> hit_count;
+  DevBuf<unsigned long long> work;
+  DevBuf<uint32_t> perm;
   DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
@@ -832,6 +846,11 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
                                                 m->info.tile_refs, T, m->info.num_angles, counts.p, offsets.p, class_cnt.p,
                                                 class_cur.p, m->entries.p, nullptr, 1);
   HIPCHK(hipGetLastError());
+  HIPCHK(m->bucket_total.reserve(std::max<uint32_t>(n_buckets, 1)));
+  if (n_buckets) {
+    k_bucket_total<<<dim3((n_buckets + 255) / 256), dim3(256), 0, st>>>(m->bucket_off.p, (int)n_buckets, T, m->bucket_total.p);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(st));
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
                          m->entries.bytes();
@@ -1045,6 +1064,9 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   HIPCHK(ws->keys_a.reserve((size_t)batch * n_paired));
   HIPCHK(ws->keys_b.reserve((size_t)batch * n_paired));
   HIPCHK(ws->hit_count.reserve(batch));
+  HIPCHK(ws->work.reserve(batch));
+  HIPCHK(ws->perm.reserve(batch));
+  va.bucket_total = m->bucket_total.p; va.work = ws->work.p; va.perm = ws->perm.p;
   va.frames = ws->frames.p; va.hits = ws->hits.p; va.hit_count = ws->hit_count.p; va.hit_cap = n_paired;
   va.keys_a = ws->keys_a.p; va.keys_b = ws->keys_b.p;
   va.key_bits = 1;
@@ -1070,6 +1092,8 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
     k_pairs<<<dim3(pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), 0, st>>>(va);
+    HIPCHK(hipGetLastError());
+    k_order<<<dim3(1), dim3(1024), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[1], st));
     k_vote<<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
@@ -1352,6 +1376,14 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   if (s == PPF_OK) s = up(m->bucket_off, boff);
   if (s == PPF_OK) s = up(m->bucket_slot, bslot);
   if (s == PPF_OK) s = up(m->entries, ent);
+  if (s == PPF_OK) {
+    hipError_t e = m->bucket_total.reserve(std::max<uint32_t>(m->info.n_buckets, 1));
+    if (e != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: %s", hipGetErrorString(e));
+    else if (m->info.n_buckets) {
+      k_bucket_total<<<dim3((m->info.n_buckets + 255) / 256), dim3(256)>>>(m->bucket_off.p, (int)m->info.n_buckets, m->info.n_tiles, m->bucket_total.p);
+      if (hipDeviceSynchronize() != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: bucket totals failed");
+    }
+  }
   if (s != PPF_OK) {
     delete m;
     return s;

@@ -89,6 +89,9 @@ struct MatchArgs {
   uint2* keys_b;           /* [n_ref][hit_cap] ping-pong */
   int hit_cap;
   int key_bits;            /* bits of a bucket id */
+  const uint32_t* bucket_total; /* [n_buckets] entries of a bucket over all tiles */
+  unsigned long long* work;     /* [n_ref] votes the reference point will cast (sum of its hits' bucket sizes) */
+  uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first */
   /* results, indexed by global r */
   uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
@@ -194,6 +197,22 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const int r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t n = a.hit_count[r];
+  {
+    /* exact number of votes this reference point will cast: used to launch the heaviest first */
+    __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
+    const uint2* k0 = a.keys_a + (size_t)r * a.hit_cap;
+    unsigned long long w = 0;
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) w += a.bucket_total[k0[i].x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
+    if (lane == 0) wsum[wave] = w;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long t = 0;
+      for (int k = 0; k < GROUP_BLOCK / 64; k++) t += wsum[k];
+      a.work[r] = t;
+    }
+  }
   if (n < 2) return;
   uint2* src = a.keys_a + (size_t)r * a.hit_cap;
   uint2* dst = a.keys_b + (size_t)r * a.hit_cap;
@@ -257,6 +276,21 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     uint2* ka = a.keys_a + (size_t)r * a.hit_cap;
     const uint2* kb = a.keys_b + (size_t)r * a.hit_cap;
     for (uint32_t i = tid; i < n; i += GROUP_BLOCK) ka[i] = kb[i];
+  }
+}
+
+/* k_order: rank the batch's reference points by work (descending, ties by index) so the dispatcher starts
+ * the heaviest workgroups first and the tail of k_vote is made of light ones.  One workgroup, O(n^2). */
+__global__ __launch_bounds__(1024) void k_order(MatchArgs a) {
+  const int n = a.n_ref;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const unsigned long long wi = a.work[i];
+    uint32_t rank = 0;
+    for (int j = 0; j < n; j++) {
+      const unsigned long long wj = a.work[j];
+      rank += (wj > wi || (wj == wi && j < i)) ? 1u : 0u;
+    }
+    a.perm[rank] = (uint32_t)i;
   }
 }
 
@@ -344,7 +378,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* scalar: the work-item loop is wave-uniform */
-  const int r = blockIdx.x / a.n_tiles, tile = blockIdx.x - r * a.n_tiles;
+  const int slot = blockIdx.x / a.n_tiles, tile = blockIdx.x - slot * a.n_tiles;
+  const int r = (int)a.perm[slot]; /* heaviest reference points first */
   const int rg = a.ref_base + r;
   const int tile_base = tile * a.tile_refs;
   const int refs_here = min(a.tile_refs, a.n_model - tile_base);
