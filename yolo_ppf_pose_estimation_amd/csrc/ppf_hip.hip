@@ -363,12 +363,19 @@ struct ClusterArgs {
   int n, num_poses;
   double pos_thr, rot_thr;
   int weighted;
+  /* global scratch */
   uint32_t* order;    /* [n] rank -> pose */
   uint32_t* assign;   /* [n] rank position -> cluster */
+  uint32_t* rin;      /* [n] rank position -> joining index inside its cluster */
   uint32_t* head;     /* [n] cluster -> pose index of its first member */
-  unsigned long long* cvotes; /* [n] */
   uint32_t* crank;    /* [n] cluster -> output slot */
-  double* soa;        /* [8n] ranked poses tx,ty,tz,angle | cluster heads hx,hy,hz,hangle */
+  uint32_t* coff;     /* [n+1] cluster -> first member slot */
+  uint32_t* gvotes;   /* [n] votes of the members, in member-slot order */
+  uint32_t* g_heads_u32; /* [n] cluster sizes when the LDS variant does not fit */
+  unsigned long long* cvotes; /* [n] */
+  double* ranked;     /* [4n] tx,ty,tz,angle in rank order */
+  double* gq;         /* [7n] q0..q3,t0..t2 of the members, in member-slot order */
+  double* g_heads;    /* [4n] cluster heads when the LDS variant does not fit */
   ppf_pose* out;      /* [n] */
   uint32_t* n_out;
 };
@@ -377,34 +384,51 @@ struct ClusterArgs {
  * Step 2 without 2,500 serial barrier rounds: poses are taken 1024 at a time (rank order).
  *   A. every thread looks its pose up among the clusters that existed BEFORE the block; a hit there is
  *      final, because clusters opened later have larger indices and the rule is "first cluster".
- *   B. one wave then walks the block's unmatched poses in order; each is compared (64 lanes in
+ *   B. one wave then walks the block's poses in order; an unmatched one is compared (64 lanes in
  *      parallel) only with the clusters opened inside this block, joins the first match or opens one.
- * The serial part is proportional to the number of clusters opened, not to the number of poses.
+ * The serial part is proportional to the number of clusters opened, not to the number of poses, and it
+ * only touches LDS: cluster heads + sizes (36 B per pose, IN_LDS when n <= CLUSTER_LDS_MAX) and a
+ * 1024-pose exchange buffer.  Everything the parallel phases use stays in global memory.
  */
+constexpr int CLUSTER_LDS_MAX = 3200;
+
+template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char csm[];
-  uint32_t* s_votes = reinterpret_cast<uint32_t*>(csm); /* [n] votes, later cluster votes (low words) */
   __shared__ uint32_t s_nclusters;
-  __shared__ uint32_t s_match[1024];
+  __shared__ uint32_t s_match[1024], s_order[1024];
+  __shared__ double s_pose[4][1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.n;
   const int np = min(a.num_poses, n);
-  double* px = a.soa; double* py = px + n; double* pz = py + n; double* pa = pz + n;
-  double* hx = pa + n; double* hy = hx + n; double* hz = hy + n; double* ha = hz + n;
-  /* 1. ranks by (votes desc, index asc) */
-  for (int i = tid; i < n; i += 1024) s_votes[i] = a.in[i].num_votes;
+  double* hx;
+  uint32_t* csize;
+  if constexpr (IN_LDS) {
+    hx = reinterpret_cast<double*>(csm);
+    csize = reinterpret_cast<uint32_t*>(hx + 4 * n);
+  } else {
+    hx = a.g_heads;
+    csize = a.g_heads_u32;
+  }
+  double* hy = hx + n; double* hz = hy + n; double* ha = hz + n;
+  double* px = a.ranked; double* py = px + n; double* pz = py + n; double* pa = pz + n;
+  /* 1. ranks by (votes desc, index asc); csize[] is borrowed for the votes */
+  for (int i = tid; i < n; i += 1024) csize[i] = a.in[i].num_votes;
   __syncthreads();
   for (int i = tid; i < n; i += 1024) {
-    const uint32_t vi = s_votes[i];
+    const uint32_t vi = csize[i];
     uint32_t rank = 0;
     for (int j = 0; j < n; j++) {
-      const uint32_t vj = s_votes[j];
+      const uint32_t vj = csize[j];
       rank += (vj > vi || (vj == vi && j < i)) ? 1u : 0u;
     }
     a.order[rank] = (uint32_t)i;
     px[rank] = a.in[i].t[0]; py[rank] = a.in[i].t[1]; pz[rank] = a.in[i].t[2]; pa[rank] = a.in[i].angle;
   }
   if (tid == 0) s_nclusters = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) csize[i] = 0; /* from here on: cluster sizes */
+  __threadfence_block();
   __syncthreads();
   /* 2. greedy first-match assignment */
   for (int s0 = 0; s0 < np; s0 += 1024) {
@@ -413,6 +437,8 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
     uint32_t mine = 0xFFFFFFFFu;
     if (s < np) {
       const double tx = px[s], ty = py[s], tz = pz[s], ang = pa[s];
+      s_pose[0][tid] = tx; s_pose[1][tid] = ty; s_pose[2][tid] = tz; s_pose[3][tid] = ang;
+      s_order[tid] = a.order[s];
       for (uint32_t c = 0; c < nc0; c++) {
         const double dx = hx[c] - tx, dy = hy[c] - ty, dz = hz[c] - tz;
         const double dn = ppf_sqrt(dx * dx + dy * dy + dz * dz);
@@ -427,9 +453,8 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
       uint32_t nc = nc0;
       for (int k = 0; k < cnt; k++) {
         uint32_t m = s_match[k];
-        const int sk = s0 + k;
         if (m == 0xFFFFFFFFu) {
-          const double tx = px[sk], ty = py[sk], tz = pz[sk], ang = pa[sk];
+          const double tx = s_pose[0][k], ty = s_pose[1][k], tz = s_pose[2][k], ang = s_pose[3][k];
           for (uint32_t cb = nc0; cb < nc && m == 0xFFFFFFFFu; cb += 64) {
             const uint32_t c = cb + lane;
             bool hit = false;
@@ -445,8 +470,7 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
           if (m == 0xFFFFFFFFu) { /* open a cluster */
             m = nc;
             if (lane == 0) {
-              a.head[m] = a.order[sk];
-              a.cvotes[m] = 0;
+              a.head[m] = s_order[k];
               hx[m] = tx; hy[m] = ty; hz[m] = tz; ha[m] = ang;
             }
             nc++;
@@ -455,9 +479,11 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           }
         }
-        if (lane == 0) {
-          a.assign[sk] = m;
-          a.cvotes[m] += a.in[a.order[sk]].num_votes;
+        if (lane == 0) { /* joining order inside the cluster: needed for the in-order means */
+          const uint32_t sz = csize[m];
+          a.assign[s0 + k] = m;
+          a.rin[s0 + k] = sz;
+          csize[m] = sz + 1;
         }
       }
       if (lane == 0) s_nclusters = nc;
@@ -466,6 +492,32 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
     __syncthreads();
   }
   const int nc = (int)s_nclusters;
+  /* member slots in joining (rank) order: offsets from the cluster sizes, then a parallel gather of the
+   * members' q, t, votes into slot order so the in-order sums stream contiguous memory */
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int c = 0; c < nc; c++) { a.coff[c] = run; run += csize[c]; }
+    a.coff[nc] = run;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int s = tid; s < np; s += 1024) {
+    const uint32_t slot = a.coff[a.assign[s]] + a.rin[s];
+    const ppf_pose& p = a.in[a.order[s]];
+    double* g = a.gq + (size_t)slot * 7;
+    g[0] = p.q[0]; g[1] = p.q[1]; g[2] = p.q[2]; g[3] = p.q[3]; g[4] = p.t[0]; g[5] = p.t[1]; g[6] = p.t[2];
+    a.gvotes[slot] = p.num_votes;
+  }
+  __threadfence_block();
+  __syncthreads();
+  /* cluster votes (exact integer sums) */
+  for (int c = tid; c < nc; c += 1024) {
+    unsigned long long v = 0;
+    for (uint32_t k = a.coff[c]; k < a.coff[c + 1]; k++) v += a.gvotes[k];
+    a.cvotes[c] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
   /* 4a. cluster ranks by (votes desc, creation order asc) */
   for (int c = tid; c < nc; c += 1024) {
     const unsigned long long vc = a.cvotes[c];
@@ -476,33 +528,30 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
     }
     a.crank[c] = rank;
   }
-  __syncthreads();
-  /* 3 + 4b. averages in joining order, rebuild the pose, write to the ranked slot */
+  /* 3 + 4b. means in joining order, rebuild the pose, write to the ranked slot */
   for (int c = tid; c < nc; c += 1024) {
     double q[4] = {0, 0, 0, 0}, t[3] = {0, 0, 0}, wsum = 0;
-    int members = 0;
-    for (int s = 0; s < np; s++) {
-      if (a.assign[s] != (uint32_t)c) continue;
-      const ppf_pose& p = a.in[a.order[s]];
+    const uint32_t k0 = a.coff[c], k1 = a.coff[c + 1];
+    for (uint32_t k = k0; k < k1; k++) {
+      const double* g = a.gq + (size_t)k * 7;
       if (a.weighted) {
-        const double w = (double)p.num_votes;
-        for (int k = 0; k < 4; k++) q[k] += w * p.q[k];
-        for (int k = 0; k < 3; k++) t[k] += w * p.t[k];
+        const double w = (double)a.gvotes[k];
+        for (int j = 0; j < 4; j++) q[j] += w * g[j];
+        for (int j = 0; j < 3; j++) t[j] += w * g[4 + j];
         wsum += w;
       } else {
-        for (int k = 0; k < 4; k++) q[k] += p.q[k];
-        for (int k = 0; k < 3; k++) t[k] += p.t[k];
+        for (int j = 0; j < 4; j++) q[j] += g[j];
+        for (int j = 0; j < 3; j++) t[j] += g[4 + j];
       }
-      members++;
     }
-    const double inv = a.weighted ? 1.0 / wsum : 1.0 / members;
-    for (int k = 0; k < 3; k++) t[k] *= inv;
-    for (int k = 0; k < 4; k++) q[k] *= inv;
+    const double inv = a.weighted ? 1.0 / wsum : 1.0 / (int)(k1 - k0);
+    for (int j = 0; j < 3; j++) t[j] *= inv;
+    for (int j = 0; j < 4; j++) q[j] *= inv;
     ppf_pose P = a.in[a.head[c]];
     double R[9];
     ppf_quat_to_dcm(q, R);
-    for (int k = 0; k < 4; k++) P.q[k] = q[k];
-    for (int k = 0; k < 3; k++) P.t[k] = t[k];
+    for (int j = 0; j < 4; j++) P.q[j] = q[j];
+    for (int j = 0; j < 3; j++) P.t[j] = t[j];
     ppf_rt_to_pose(R, t, P.pose);
     P.angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
     P.num_votes = (uint32_t)a.cvotes[c];
@@ -688,27 +737,30 @@ void resolve_thresholds(const ppf_model* m, const ppf_match_params* p, double* p
 
 ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int num_poses, double pos, double rot,
                            bool weighted, hipStream_t st) {
-  HIPCHK(ws->d_final.reserve(std::max(n, 1)));
-  HIPCHK(ws->cl_u32.reserve((size_t)4 * std::max(n, 1) + 1));
-  HIPCHK(ws->cl_votes.reserve(std::max(n, 1)));
-  HIPCHK(ws->cl_soa.reserve((size_t)8 * std::max(n, 1)));
-  if ((size_t)n * 4 > 120 * 1024) return fail(PPF_ERR_INVALID, "clustering more than 30720 poses per call is not supported");
+  const size_t nn = (size_t)std::max(n, 1);
+  HIPCHK(ws->d_final.reserve(nn));
+  HIPCHK(ws->cl_u32.reserve(8 * nn + 4)); /* n_out | order | assign | rin | head | crank | gvotes | sizes | coff[n+1] */
+  HIPCHK(ws->cl_votes.reserve(nn));
+  HIPCHK(ws->cl_soa.reserve(15 * nn));    /* ranked 4n | member q,t 7n | heads 4n */
   ClusterArgs ca;
-  ca.soa = ws->cl_soa.p;
   ca.in = d_in; ca.n = n; ca.num_poses = num_poses; ca.pos_thr = pos; ca.rot_thr = rot; ca.weighted = weighted ? 1 : 0;
-  ca.order = ws->cl_u32.p; ca.assign = ca.order + n; ca.head = ca.assign + n; ca.crank = ca.head + n;
-  ca.n_out = ca.crank + n;
+  uint32_t* u = ws->cl_u32.p;
+  ca.n_out = u; u += 1;
+  ca.order = u; u += n; ca.assign = u; u += n; ca.rin = u; u += n; ca.head = u; u += n; ca.crank = u; u += n;
+  ca.gvotes = u; u += n; ca.g_heads_u32 = u; u += n; ca.coff = u;
   ca.cvotes = ws->cl_votes.p;
+  ca.ranked = ws->cl_soa.p; ca.gq = ca.ranked + 4 * nn; ca.g_heads = ca.gq + 7 * nn;
   ca.out = ws->d_final.p;
   HIPCHK(hipMemsetAsync(ca.n_out, 0, sizeof(uint32_t), st));
   if (n > 0) {
     static std::once_flag once_c;
     static hipError_t attr_c = hipSuccess;
     std::call_once(once_c, [] {
-      attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 116 * 1024);
     });
     HIPCHK(attr_c);
-    k_cluster<<<dim3(1), dim3(1024), (size_t)n * 4, st>>>(ca);
+    if (n <= CLUSTER_LDS_MAX) k_cluster<true><<<dim3(1), dim3(1024), (size_t)n * 36 + 64, st>>>(ca);
+    else k_cluster<false><<<dim3(1), dim3(1024), 0, st>>>(ca);
     HIPCHK(hipGetLastError());
   }
   return PPF_OK;
@@ -1148,7 +1200,7 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
   if ((poses || n_poses) && !ws->params.skip_clustering && ws->clustered) {
     if (ws->final_poses.empty() && nr > 0) {
       uint32_t nf = 0;
-      HIPCHK(hipMemcpy(&nf, ws->cl_u32.p + (size_t)4 * nr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
       ws->final_poses.resize(nf);
       if (nf) HIPCHK(hipMemcpy(ws->final_poses.data(), ws->d_final.p, (size_t)nf * sizeof(ppf_pose), hipMemcpyDeviceToHost));
     }
@@ -1250,7 +1302,7 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
   if (s != PPF_OK) return s;
   HIPCHK(hipStreamSynchronize(nullptr));
   uint32_t nf = 0;
-  HIPCHK(hipMemcpy(&nf, ws.cl_u32.p + (size_t)4 * n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&nf, ws.cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
   *n_out = (int)nf;
   if (out) {
     if (cap < (int)nf) return fail(PPF_ERR_CAPACITY, "ppf_cluster_poses: need room for %d poses", (int)nf);

@@ -282,13 +282,20 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
 /* k_order: rank the batch's reference points by work (descending, ties by index) so the dispatcher starts
  * the heaviest workgroups first and the tail of k_vote is made of light ones.  One workgroup, O(n^2). */
 __global__ __launch_bounds__(1024) void k_order(MatchArgs a) {
+  __shared__ unsigned long long w[4096];
   const int n = a.n_ref;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    const unsigned long long wi = a.work[i];
     uint32_t rank = 0;
-    for (int j = 0; j < n; j++) {
-      const unsigned long long wj = a.work[j];
-      rank += (wj > wi || (wj == wi && j < i)) ? 1u : 0u;
+    const unsigned long long wi = a.work[i];
+    for (int j0 = 0; j0 < n; j0 += 4096) { /* stage 4096 work values at a time in LDS */
+      __syncthreads();
+      for (int j = threadIdx.x; j < min(4096, n - j0); j += 1024) w[j] = a.work[j0 + j];
+      __syncthreads();
+      const int lim = min(4096, n - j0);
+      for (int j = 0; j < lim; j++) {
+        const unsigned long long wj = w[j];
+        rank += (wj > wi || (wj == wi && (j0 + j) < i)) ? 1u : 0u;
+      }
     }
     a.perm[rank] = (uint32_t)i;
   }
