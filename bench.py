@@ -49,6 +49,21 @@ def algorithmic_bytes(n_ref, n_model, num_angles, n_pairs, n_votes):
     return n_ref * (24 + 2 * 4 * n_model * num_angles + 12) + n_pairs * 32 + n_votes * 16
 
 
+def measured_traffic(n_votes):
+    """HBM/fabric bytes per k_vote launch from the committed PMC passes (profiles/*_pmc_traffic.json), if they
+    were taken on this exact workload; otherwise None.  bench.py cannot collect PMC counters on itself."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            t = json.load(open(f))
+            if t.get("n_votes_per_launch") == n_votes:
+                best = t["hbm_bytes_per_launch_k_vote"]["gfx950_corrected_2xFETCH"]
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(bottle, scene, n_ref_total, target_seconds=15.0):
     """Oracle (CPU restatement) on a bounded sample of the step's reference points."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -203,7 +218,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(st["n_votes"]) if world == 1 else None,
                 "algorithmic_bytes_per_launch": abytes,
                 "hbm_only_algorithmic_bytes_per_launch": hbm_only,
                 "avg_kernel_ms": avg_vote_s * 1e3,
