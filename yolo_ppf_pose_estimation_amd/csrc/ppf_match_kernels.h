@@ -63,9 +63,73 @@ constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + r
 
 struct HitRec {
   uint32_t bucket;   /* dense bucket id */
-  uint32_t alpha32;  /* (float)alpha_s bits, for the fp32 fast path */
-  double alpha_s;    /* exact alpha_s */
+  uint32_t alpha32;  /* k_pairs: index j of the paired point; after k_group: (float)alpha_s bits for the fp32 vote path */
+  double alpha_s;    /* exact alpha_s (k_group) */
 };
+
+/* fp32 acos for BIN SELECTION only: acos(|x|) = sqrt(1-|x|) * P(|x|), degree-7 least-squares/minimax fit,
+ * measured max error 3.4e-7 rad including fp32 evaluation (tests/test_gpu_fastkeys.py re-checks the keys
+ * against the exact path).  `t` = 1-|x| is formed in fp64 so the estimate stays relative-accurate near |x| = 1. */
+__device__ __forceinline__ float acos32_estimate(double x) {
+  const double ax = ppf_fabs(x);
+  const float xf = (float)ax;
+  const float t = fmaxf((float)(1.0 - ax), 0.0f);
+  float p = -0.001441536471247673f;
+  p = __builtin_fmaf(p, xf, 0.007245631422847509f);
+  p = __builtin_fmaf(p, xf, -0.01780921407043934f);
+  p = __builtin_fmaf(p, xf, 0.03133561089634895f);
+  p = __builtin_fmaf(p, xf, -0.0503128282725811f);
+  p = __builtin_fmaf(p, xf, 0.08899927139282227f);
+  p = __builtin_fmaf(p, xf, -0.21459989249706268f);
+  p = __builtin_fmaf(p, xf, 1.5707963705062866f);
+  const float a = __builtin_sqrtf(t) * p;
+  return x >= 0.0 ? a : 3.14159274101257324f - a;
+}
+
+/* Quantised key of a scene pair, exactly the integers of ppf_hash_feature(ppf_pair_feature(...)).
+ * Fast path (every lane, branch-free): angles binned from the fp32 estimate, distance binned with a
+ * reciprocal multiply; a lane whose value lies within a guard band of a bin edge (or is degenerate /
+ * out of acos range) recomputes the fp64 chain.  Guards: angle 2e-5 bins-units-equivalent >> the 1.6e-6
+ * estimate error; distance 1e-9 >> 1e-13. */
+struct FastKeyConsts {
+  float rstep32;   /* 1 / angle_step */
+  float gq;        /* angle guard in bin units */
+  double rdstep;   /* 1 / dist_step */
+};
+
+__device__ __forceinline__ uint32_t pair_slot_hash(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2,
+                                                   const ppf_vec3& n2, const double angle_step, const double dist_step,
+                                                   const FastKeyConsts& fk) {
+  const double dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+  const double f3 = ppf_sqrt(dx * dx + dy * dy + dz * dz);
+  double rinv = __builtin_amdgcn_rcp(f3);
+  rinv = rinv * (2.0 - f3 * rinv); /* one Newton step: ~1e-16 relative, far inside the guard */
+  const double x0 = (n1.x * dx + n1.y * dy + n1.z * dz) * rinv;
+  const double x1 = (n2.x * dx + n2.y * dy + n2.z * dz) * rinv;
+  const double x2 = ppf_dot3(n1, n2); /* same expression as the exact path: bit-identical */
+  bool slow = !(f3 > PPF_EPS) || !(ppf_fabs(x0) <= 1.0 - 1e-12) || !(ppf_fabs(x1) <= 1.0 - 1e-12) || !(ppf_fabs(x2) <= 1.0);
+  int32_t k[4];
+  {
+    const float q0 = acos32_estimate(x0) * fk.rstep32, q1 = acos32_estimate(x1) * fk.rstep32,
+                q2 = acos32_estimate(x2) * fk.rstep32;
+    k[0] = (int)q0; k[1] = (int)q1; k[2] = (int)q2;
+    const float lim = 0.5f - fk.gq;
+    slow |= (__builtin_fabsf(__builtin_amdgcn_fractf(q0) - 0.5f) > lim) |
+            (__builtin_fabsf(__builtin_amdgcn_fractf(q1) - 0.5f) > lim) |
+            (__builtin_fabsf(__builtin_amdgcn_fractf(q2) - 0.5f) > lim);
+    const double q3 = f3 * fk.rdstep;
+    k[3] = (int)q3;
+    const double fr3 = q3 - (double)k[3];
+    slow |= !(fr3 > 1e-9 && fr3 < 1.0 - 1e-9) || !(q3 < 2.0e9);
+  }
+  if (slow) {
+    double f[4] = {0, 0, 0, 0};
+    ppf_pair_feature(p1, n1, p2, n2, f);
+    k[0] = ppf_d2i(f[0] / angle_step); k[1] = ppf_d2i(f[1] / angle_step); k[2] = ppf_d2i(f[2] / angle_step);
+    k[3] = ppf_d2i(f[3] / dist_step);
+  }
+  return ppf_murmur_key16(k[0], k[1], k[2], k[3]);
+}
 
 struct MatchArgs {
   CloudSoA surf;   /* reference points come from here */
@@ -123,9 +187,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   const int lane = threadIdx.x & 63;
   const int i_ref = ref_row(a, r);
   const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
-  const double* __restrict__ fr = a.frames + (size_t)r * 12;
-  /* rows 1 and 2 of Rsg and tsg.y/z are all alpha_s needs */
-  const double R10 = fr[3], R11 = fr[4], R12 = fr[5], R20 = fr[6], R21 = fr[7], R22 = fr[8], ty = fr[10], tz = fr[11];
+  FastKeyConsts fk;
+  fk.rstep32 = (float)(1.0 / a.angle_step);
+  fk.gq = 4.0e-6f * fk.rstep32; /* 4e-6 rad: > 10x the 3.4e-7 rad estimate error; 1.9e-5 bins at 12 degrees */
+  fk.rdstep = 1.0 / a.dist_step;
   HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
   unsigned long long my_pairs = 0;
   const int j0 = blockIdx.x * (PAIR_BLOCK * PAIRS_PER_THREAD) + threadIdx.x;
@@ -134,8 +199,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
     const int j = j0 + it * PAIR_BLOCK;
     if ((j - lane) >= a.paired.n) break; /* whole wave past the end */
     bool hit = false;
-    HitRec rec;
-    rec.bucket = 0; rec.alpha32 = 0; rec.alpha_s = 0.0;
+    uint32_t bucket = 0;
     if (j < a.paired.n && !(a.same_cloud && j == i_ref)) {
       const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
       const ppf_vec3 n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
@@ -145,26 +209,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
       const bool self_pair = !a.same_cloud && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x &&
                              n2.y == n1.y && n2.z == n1.z;
       if (!self_pair) {
-      double f[4] = {0, 0, 0, 0};
-      ppf_pair_feature(p1, n1, p2, n2, f);
-      const uint32_t slot = ppf_hash_feature(f, a.angle_step, a.dist_step) & a.slot_mask;
-      const int b = slot_to_bucket(a.slotmap, slot);
-      /* alpha_s = angle of (tsg + Rsg p2) about x; the reference skips the pair when it is NaN.
-       * For finite clouds it never is, so it is only evaluated for pairs that found a bucket;
-       * `pairs` counts pairs hashed. */
-      const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
-      const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
-      const bool finite_q = (qy == qy) && (qz == qz);
-      my_pairs += finite_q ? 1u : 0u;
-      if (b >= 0 && finite_q) {
-        double as;
-        if (ppf_alpha_in_frame(qy, qz, &as)) {
-          hit = true;
-          rec.bucket = (uint32_t)b;
-          rec.alpha32 = __float_as_uint((float)as);
-          rec.alpha_s = as;
-        }
-      }
+        const uint32_t slot = pair_slot_hash(p1, n1, p2, n2, a.angle_step, a.dist_step, fk) & a.slot_mask;
+        const int b = slot_to_bucket(a.slotmap, slot);
+        /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
+         * computed later (k_group), only for the ~6 % of pairs that found a bucket. */
+        my_pairs += 1u;
+        if (b >= 0) { hit = true; bucket = (uint32_t)b; }
       }
     }
     const unsigned long long m = __ballot(hit);
@@ -174,8 +224,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
       if (hit) {
         const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        HitRec rec;
+        rec.bucket = bucket; rec.alpha32 = (uint32_t)j; rec.alpha_s = 0.0;
         hits[base + rank] = rec;
-        a.keys_a[(size_t)r * a.hit_cap + base + rank] = make_uint2(rec.bucket, base + rank);
+        a.keys_a[(size_t)r * a.hit_cap + base + rank] = make_uint2(bucket, base + rank);
       }
     }
   }
@@ -198,11 +250,32 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t n = a.hit_count[r];
   {
+    /* alpha_s of every hit (dense: only pairs that found a bucket): angle of (tsg + Rsg p2) about x.  A NaN
+     * alpha (non-finite cloud) makes the reference skip the pair: the hit is retired by emptying its key. */
+    const double* __restrict__ fr = a.frames + (size_t)r * 12;
+    const double R10 = fr[3], R11 = fr[4], R12 = fr[5], R20 = fr[6], R21 = fr[7], R22 = fr[8], ty = fr[10], tz = fr[11];
+    HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
+    uint2* kk = a.keys_a + (size_t)r * a.hit_cap;
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) {
+      const int j = (int)hits[i].alpha32;
+      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
+      const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
+      const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
+      double as = 0.0;
+      if (ppf_alpha_in_frame(qy, qz, &as)) {
+        hits[i].alpha32 = __float_as_uint((float)as);
+        hits[i].alpha_s = as;
+      } else {
+        hits[i].alpha32 = 0; hits[i].alpha_s = 0.0;
+        kk[i].x = 0xFFFFFFFFu; /* sorts last; k_vote gives it no entries */
+      }
+    }
+    __syncthreads();
     /* exact number of votes this reference point will cast: used to launch the heaviest first */
     __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
     const uint2* k0 = a.keys_a + (size_t)r * a.hit_cap;
     unsigned long long w = 0;
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) w += a.bucket_total[k0[i].x];
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) w += (k0[i].x == 0xFFFFFFFFu) ? 0u : a.bucket_total[k0[i].x];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
     if (lane == 0) wsum[wave] = w;
@@ -420,8 +493,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     if (tid < n_seg) {
       const uint2 key = keys[seg0 + tid];
       const HitRec h = hits[key.y];
-      off = boff[key.x];
-      cnt = boff[key.x + 1] - off;
+      if (key.x != 0xFFFFFFFFu) {
+        off = boff[key.x];
+        cnt = boff[key.x + 1] - off;
+      }
       seg_a32[tid] = h.alpha32;
       seg_a64[tid] = h.alpha_s;
       is_start = (tid == 0) || (keys[seg0 + tid - 1].x != key.x);
