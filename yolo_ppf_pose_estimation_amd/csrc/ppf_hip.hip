@@ -358,22 +358,47 @@ __global__ void k_finalize(FinalArgs a) {
  *    quaternion; cluster votes = sum of member votes.
  * 4. clusters ranked by (votes desc, creation order asc) and written out.
  */
+/* Generic ranking: perm[rank] = i and rank_of[i] = rank for keys sorted (key desc, index asc).  n may live on the
+ * device (n_dev != nullptr).  O(n^2) over many workgroups; the inner index is wave-uniform (scalar loads). */
+__global__ __launch_bounds__(256) void k_rank(const unsigned long long* __restrict__ keys, int n_host,
+                                              const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ perm,
+                                              uint32_t* __restrict__ rank_of) {
+  const int n = n_dev ? (int)*n_dev : n_host;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long ki = keys[i];
+  uint32_t rank = 0;
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    const unsigned long long k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+    rank += (k0 > ki || (k0 == ki && j < i)) ? 1u : 0u;
+    rank += (k1 > ki || (k1 == ki && j + 1 < i)) ? 1u : 0u;
+    rank += (k2 > ki || (k2 == ki && j + 2 < i)) ? 1u : 0u;
+    rank += (k3 > ki || (k3 == ki && j + 3 < i)) ? 1u : 0u;
+  }
+  for (; j < n; j++) {
+    const unsigned long long kj = keys[j];
+    rank += (kj > ki || (kj == ki && j < i)) ? 1u : 0u;
+  }
+  if (perm) perm[rank] = (uint32_t)i;
+  if (rank_of) rank_of[i] = rank;
+}
+
 struct ClusterArgs {
   const ppf_pose* in;
   int n, num_poses;
   double pos_thr, rot_thr;
   int weighted;
   /* global scratch */
-  uint32_t* order;    /* [n] rank -> pose */
+  const uint32_t* order; /* [n] rank -> pose (k_rank on the vote keys) */
   uint32_t* assign;   /* [n] rank position -> cluster */
   uint32_t* rin;      /* [n] rank position -> joining index inside its cluster */
   uint32_t* head;     /* [n] cluster -> pose index of its first member */
-  uint32_t* crank;    /* [n] cluster -> output slot */
+  uint32_t* crank;    /* [n] cluster -> output slot (k_rank on the cluster votes) */
   uint32_t* coff;     /* [n+1] cluster -> first member slot */
   uint32_t* gvotes;   /* [n] votes of the members, in member-slot order */
-  uint32_t* g_heads_u32; /* [n] cluster sizes when the LDS variant does not fit */
+  uint32_t* g_sizes;  /* [n] cluster sizes when the LDS variant does not fit */
   unsigned long long* cvotes; /* [n] */
-  double* ranked;     /* [4n] tx,ty,tz,angle in rank order */
   double* gq;         /* [7n] q0..q3,t0..t2 of the members, in member-slot order */
   double* g_heads;    /* [4n] cluster heads when the LDS variant does not fit */
   ppf_pose* out;      /* [n] */
@@ -381,19 +406,19 @@ struct ClusterArgs {
 };
 
 /*
- * Step 2 without 2,500 serial barrier rounds: poses are taken 1024 at a time (rank order).
+ * Greedy first-match assignment (step 2 of clusterPoses) without one barrier round per pose: poses are
+ * taken 1024 at a time in rank order.
  *   A. every thread looks its pose up among the clusters that existed BEFORE the block; a hit there is
  *      final, because clusters opened later have larger indices and the rule is "first cluster".
  *   B. one wave then walks the block's poses in order; an unmatched one is compared (64 lanes in
  *      parallel) only with the clusters opened inside this block, joins the first match or opens one.
- * The serial part is proportional to the number of clusters opened, not to the number of poses, and it
- * only touches LDS: cluster heads + sizes (36 B per pose, IN_LDS when n <= CLUSTER_LDS_MAX) and a
- * 1024-pose exchange buffer.  Everything the parallel phases use stays in global memory.
+ * The serial part is proportional to the number of clusters opened and only touches LDS: cluster heads +
+ * sizes (36 B per pose, IN_LDS when n <= CLUSTER_LDS_MAX) and a 1024-pose exchange buffer.
  */
 constexpr int CLUSTER_LDS_MAX = 3200;
 
 template <bool IN_LDS>
-__global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
+__global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char csm[];
   __shared__ uint32_t s_nclusters;
   __shared__ uint32_t s_match[1024], s_order[1024];
@@ -408,37 +433,22 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
     csize = reinterpret_cast<uint32_t*>(hx + 4 * n);
   } else {
     hx = a.g_heads;
-    csize = a.g_heads_u32;
+    csize = a.g_sizes;
   }
   double* hy = hx + n; double* hz = hy + n; double* ha = hz + n;
-  double* px = a.ranked; double* py = px + n; double* pz = py + n; double* pa = pz + n;
-  /* 1. ranks by (votes desc, index asc); csize[] is borrowed for the votes */
-  for (int i = tid; i < n; i += 1024) csize[i] = a.in[i].num_votes;
-  __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const uint32_t vi = csize[i];
-    uint32_t rank = 0;
-    for (int j = 0; j < n; j++) {
-      const uint32_t vj = csize[j];
-      rank += (vj > vi || (vj == vi && j < i)) ? 1u : 0u;
-    }
-    a.order[rank] = (uint32_t)i;
-    px[rank] = a.in[i].t[0]; py[rank] = a.in[i].t[1]; pz[rank] = a.in[i].t[2]; pa[rank] = a.in[i].angle;
-  }
+  for (int i = tid; i < n; i += 1024) csize[i] = 0;
   if (tid == 0) s_nclusters = 0;
-  __syncthreads();
-  for (int i = tid; i < n; i += 1024) csize[i] = 0; /* from here on: cluster sizes */
   __threadfence_block();
   __syncthreads();
-  /* 2. greedy first-match assignment */
   for (int s0 = 0; s0 < np; s0 += 1024) {
     const uint32_t nc0 = s_nclusters;
     const int s = s0 + tid;
     uint32_t mine = 0xFFFFFFFFu;
     if (s < np) {
-      const double tx = px[s], ty = py[s], tz = pz[s], ang = pa[s];
+      const uint32_t pi = a.order[s];
+      const double tx = a.in[pi].t[0], ty = a.in[pi].t[1], tz = a.in[pi].t[2], ang = a.in[pi].angle;
       s_pose[0][tid] = tx; s_pose[1][tid] = ty; s_pose[2][tid] = tz; s_pose[3][tid] = ang;
-      s_order[tid] = a.order[s];
+      s_order[tid] = pi;
       for (uint32_t c = 0; c < nc0; c++) {
         const double dx = hx[c] - tx, dy = hy[c] - ty, dz = hz[c] - tz;
         const double dn = ppf_sqrt(dx * dx + dy * dy + dz * dz);
@@ -492,72 +502,66 @@ __global__ __launch_bounds__(1024) void k_cluster(ClusterArgs a) {
     __syncthreads();
   }
   const int nc = (int)s_nclusters;
-  /* member slots in joining (rank) order: offsets from the cluster sizes, then a parallel gather of the
-   * members' q, t, votes into slot order so the in-order sums stream contiguous memory */
+  /* member slots in joining order: offsets from the cluster sizes; cluster votes zeroed for the gather */
   if (tid == 0) {
     uint32_t run = 0;
     for (int c = 0; c < nc; c++) { a.coff[c] = run; run += csize[c]; }
     a.coff[nc] = run;
+    *a.n_out = (uint32_t)nc;
   }
-  __threadfence_block();
-  __syncthreads();
-  for (int s = tid; s < np; s += 1024) {
-    const uint32_t slot = a.coff[a.assign[s]] + a.rin[s];
-    const ppf_pose& p = a.in[a.order[s]];
-    double* g = a.gq + (size_t)slot * 7;
-    g[0] = p.q[0]; g[1] = p.q[1]; g[2] = p.q[2]; g[3] = p.q[3]; g[4] = p.t[0]; g[5] = p.t[1]; g[6] = p.t[2];
-    a.gvotes[slot] = p.num_votes;
-  }
-  __threadfence_block();
-  __syncthreads();
-  /* cluster votes (exact integer sums) */
-  for (int c = tid; c < nc; c += 1024) {
-    unsigned long long v = 0;
-    for (uint32_t k = a.coff[c]; k < a.coff[c + 1]; k++) v += a.gvotes[k];
-    a.cvotes[c] = v;
-  }
-  __threadfence_block();
-  __syncthreads();
-  /* 4a. cluster ranks by (votes desc, creation order asc) */
-  for (int c = tid; c < nc; c += 1024) {
-    const unsigned long long vc = a.cvotes[c];
-    uint32_t rank = 0;
-    for (int d = 0; d < nc; d++) {
-      const unsigned long long vd = a.cvotes[d];
-      rank += (vd > vc || (vd == vc && d < c)) ? 1u : 0u;
+  for (int c = tid; c < nc; c += 1024) a.cvotes[c] = 0;
+}
+
+/* gather the members' q, t, votes into member-slot (joining) order; cluster votes by integer atomics */
+__global__ __launch_bounds__(256) void k_cluster_members(ClusterArgs a) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int np = min(a.num_poses, a.n);
+  if (s >= np) return;
+  const uint32_t c = a.assign[s];
+  const uint32_t slot = a.coff[c] + a.rin[s];
+  const ppf_pose& p = a.in[a.order[s]];
+  double* g = a.gq + (size_t)slot * 7;
+  g[0] = p.q[0]; g[1] = p.q[1]; g[2] = p.q[2]; g[3] = p.q[3]; g[4] = p.t[0]; g[5] = p.t[1]; g[6] = p.t[2];
+  a.gvotes[slot] = p.num_votes;
+  atomicAdd(&a.cvotes[c], (unsigned long long)p.num_votes);
+}
+
+/* steps 3 + 4 of clusterPoses: means in joining order (fp64, sequential per cluster: bit-identical to the CPU
+ * restatement), pose rebuilt from the mean quaternion, written to the cluster's rank */
+__global__ __launch_bounds__(64) void k_cluster_finish(ClusterArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (int)*a.n_out) return;
+  double q[4] = {0, 0, 0, 0}, t[3] = {0, 0, 0}, wsum = 0;
+  const uint32_t k0 = a.coff[c], k1 = a.coff[c + 1];
+  for (uint32_t k = k0; k < k1; k++) {
+    const double* g = a.gq + (size_t)k * 7;
+    if (a.weighted) {
+      const double w = (double)a.gvotes[k];
+      for (int j = 0; j < 4; j++) q[j] += w * g[j];
+      for (int j = 0; j < 3; j++) t[j] += w * g[4 + j];
+      wsum += w;
+    } else {
+      for (int j = 0; j < 4; j++) q[j] += g[j];
+      for (int j = 0; j < 3; j++) t[j] += g[4 + j];
     }
-    a.crank[c] = rank;
   }
-  /* 3 + 4b. means in joining order, rebuild the pose, write to the ranked slot */
-  for (int c = tid; c < nc; c += 1024) {
-    double q[4] = {0, 0, 0, 0}, t[3] = {0, 0, 0}, wsum = 0;
-    const uint32_t k0 = a.coff[c], k1 = a.coff[c + 1];
-    for (uint32_t k = k0; k < k1; k++) {
-      const double* g = a.gq + (size_t)k * 7;
-      if (a.weighted) {
-        const double w = (double)a.gvotes[k];
-        for (int j = 0; j < 4; j++) q[j] += w * g[j];
-        for (int j = 0; j < 3; j++) t[j] += w * g[4 + j];
-        wsum += w;
-      } else {
-        for (int j = 0; j < 4; j++) q[j] += g[j];
-        for (int j = 0; j < 3; j++) t[j] += g[4 + j];
-      }
-    }
-    const double inv = a.weighted ? 1.0 / wsum : 1.0 / (int)(k1 - k0);
-    for (int j = 0; j < 3; j++) t[j] *= inv;
-    for (int j = 0; j < 4; j++) q[j] *= inv;
-    ppf_pose P = a.in[a.head[c]];
-    double R[9];
-    ppf_quat_to_dcm(q, R);
-    for (int j = 0; j < 4; j++) P.q[j] = q[j];
-    for (int j = 0; j < 3; j++) P.t[j] = t[j];
-    ppf_rt_to_pose(R, t, P.pose);
-    P.angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
-    P.num_votes = (uint32_t)a.cvotes[c];
-    a.out[a.crank[c]] = P;
-  }
-  if (tid == 0) *a.n_out = (uint32_t)nc;
+  const double inv = a.weighted ? 1.0 / wsum : 1.0 / (int)(k1 - k0);
+  for (int j = 0; j < 3; j++) t[j] *= inv;
+  for (int j = 0; j < 4; j++) q[j] *= inv;
+  ppf_pose P = a.in[a.head[c]];
+  double R[9];
+  ppf_quat_to_dcm(q, R);
+  for (int j = 0; j < 4; j++) P.q[j] = q[j];
+  for (int j = 0; j < 3; j++) P.t[j] = t[j];
+  ppf_rt_to_pose(R, t, P.pose);
+  P.angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
+  P.num_votes = (uint32_t)a.cvotes[c];
+  a.out[a.crank[c]] = P;
+}
+
+__global__ void k_vote_keys(const ppf_pose* __restrict__ in, int n, unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = in[i].num_votes;
 }
 
 /* ============================================================================================ */
@@ -740,27 +744,35 @@ ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int n
   const size_t nn = (size_t)std::max(n, 1);
   HIPCHK(ws->d_final.reserve(nn));
   HIPCHK(ws->cl_u32.reserve(8 * nn + 4)); /* n_out | order | assign | rin | head | crank | gvotes | sizes | coff[n+1] */
-  HIPCHK(ws->cl_votes.reserve(nn));
-  HIPCHK(ws->cl_soa.reserve(15 * nn));    /* ranked 4n | member q,t 7n | heads 4n */
+  HIPCHK(ws->cl_votes.reserve(2 * nn));   /* cluster votes | pose vote keys */
+  HIPCHK(ws->cl_soa.reserve(11 * nn));    /* member q,t 7n | heads 4n */
   ClusterArgs ca;
   ca.in = d_in; ca.n = n; ca.num_poses = num_poses; ca.pos_thr = pos; ca.rot_thr = rot; ca.weighted = weighted ? 1 : 0;
   uint32_t* u = ws->cl_u32.p;
   ca.n_out = u; u += 1;
-  ca.order = u; u += n; ca.assign = u; u += n; ca.rin = u; u += n; ca.head = u; u += n; ca.crank = u; u += n;
-  ca.gvotes = u; u += n; ca.g_heads_u32 = u; u += n; ca.coff = u;
+  uint32_t* order = u; u += n;
+  ca.order = order; ca.assign = u; u += n; ca.rin = u; u += n; ca.head = u; u += n; ca.crank = u; u += n;
+  ca.gvotes = u; u += n; ca.g_sizes = u; u += n; ca.coff = u;
   ca.cvotes = ws->cl_votes.p;
-  ca.ranked = ws->cl_soa.p; ca.gq = ca.ranked + 4 * nn; ca.g_heads = ca.gq + 7 * nn;
+  unsigned long long* vkeys = ws->cl_votes.p + nn;
+  ca.gq = ws->cl_soa.p; ca.g_heads = ca.gq + 7 * nn;
   ca.out = ws->d_final.p;
   HIPCHK(hipMemsetAsync(ca.n_out, 0, sizeof(uint32_t), st));
   if (n > 0) {
     static std::once_flag once_c;
     static hipError_t attr_c = hipSuccess;
     std::call_once(once_c, [] {
-      attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 116 * 1024);
+      attr_c = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cluster_assign<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 116 * 1024);
     });
     HIPCHK(attr_c);
-    if (n <= CLUSTER_LDS_MAX) k_cluster<true><<<dim3(1), dim3(1024), (size_t)n * 36 + 64, st>>>(ca);
-    else k_cluster<false><<<dim3(1), dim3(1024), 0, st>>>(ca);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    k_vote_keys<<<dim3(nb), dim3(256), 0, st>>>(d_in, n, vkeys);
+    k_rank<<<dim3(nb), dim3(256), 0, st>>>(vkeys, n, nullptr, order, nullptr);            /* (votes desc, index asc) */
+    if (n <= CLUSTER_LDS_MAX) k_cluster_assign<true><<<dim3(1), dim3(1024), (size_t)n * 36 + 64, st>>>(ca);
+    else k_cluster_assign<false><<<dim3(1), dim3(1024), 0, st>>>(ca);
+    k_cluster_members<<<dim3(nb), dim3(256), 0, st>>>(ca);
+    k_rank<<<dim3(nb), dim3(256), 0, st>>>(ca.cvotes, 0, ca.n_out, nullptr, ca.crank);    /* (cluster votes desc, creation asc) */
+    k_cluster_finish<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(ca);
     HIPCHK(hipGetLastError());
   }
   return PPF_OK;
@@ -1145,7 +1157,7 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
     HIPCHK(hipGetLastError());
     k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), 0, st>>>(va);
     HIPCHK(hipGetLastError());
-    k_order<<<dim3(1), dim3(1024), 0, st>>>(va);
+    k_rank<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
     if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[1], st));
     k_vote<<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);

@@ -155,7 +155,7 @@ struct MatchArgs {
   int key_bits;            /* bits of a bucket id */
   const uint32_t* bucket_total; /* [n_buckets] entries of a bucket over all tiles */
   unsigned long long* work;     /* [n_ref] votes the reference point will cast (sum of its hits' bucket sizes) */
-  uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first */
+  uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
   /* results, indexed by global r */
   uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
@@ -349,28 +349,6 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     uint2* ka = a.keys_a + (size_t)r * a.hit_cap;
     const uint2* kb = a.keys_b + (size_t)r * a.hit_cap;
     for (uint32_t i = tid; i < n; i += GROUP_BLOCK) ka[i] = kb[i];
-  }
-}
-
-/* k_order: rank the batch's reference points by work (descending, ties by index) so the dispatcher starts
- * the heaviest workgroups first and the tail of k_vote is made of light ones.  One workgroup, O(n^2). */
-__global__ __launch_bounds__(1024) void k_order(MatchArgs a) {
-  __shared__ unsigned long long w[4096];
-  const int n = a.n_ref;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    uint32_t rank = 0;
-    const unsigned long long wi = a.work[i];
-    for (int j0 = 0; j0 < n; j0 += 4096) { /* stage 4096 work values at a time in LDS */
-      __syncthreads();
-      for (int j = threadIdx.x; j < min(4096, n - j0); j += 1024) w[j] = a.work[j0 + j];
-      __syncthreads();
-      const int lim = min(4096, n - j0);
-      for (int j = 0; j < lim; j++) {
-        const unsigned long long wj = w[j];
-        rank += (wj > wi || (wj == wi && (j0 + j) < i)) ? 1u : 0u;
-      }
-    }
-    a.perm[rank] = (uint32_t)i;
   }
 }
 
