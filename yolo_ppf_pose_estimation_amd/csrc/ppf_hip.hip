@@ -392,7 +392,6 @@ struct ClusterArgs {
   /* global scratch */
   const uint32_t* order; /* [n] rank -> pose (k_rank on the vote keys) */
   uint32_t* assign;   /* [n] rank position -> cluster */
-  uint32_t* rin;      /* [n] rank position -> joining index inside its cluster */
   uint32_t* head;     /* [n] cluster -> pose index of its first member */
   uint32_t* crank;    /* [n] cluster -> output slot (k_rank on the cluster votes) */
   uint32_t* coff;     /* [n+1] cluster -> first member slot */
@@ -407,123 +406,185 @@ struct ClusterArgs {
 
 /*
  * Greedy first-match assignment (step 2 of clusterPoses) without one barrier round per pose: poses are
- * taken 1024 at a time in rank order.
- *   A. every thread looks its pose up among the clusters that existed BEFORE the block; a hit there is
- *      final, because clusters opened later have larger indices and the rule is "first cluster".
- *   B. one wave then walks the block's poses in order; an unmatched one is compared (64 lanes in
- *      parallel) only with the clusters opened inside this block, joins the first match or opens one.
- * The serial part is proportional to the number of clusters opened and only touches LDS: cluster heads +
- * sizes (36 B per pose, IN_LDS when n <= CLUSTER_LDS_MAX) and a 1024-pose exchange buffer.
+ * taken CL_BLOCK at a time in rank order.
+ *   A. the workgroup looks every pose of the round up among the clusters that existed BEFORE the round; a hit
+ *      there is final, because clusters opened later have larger indices and the rule is "first cluster".
+ *   B. one wave then walks the round's unmatched poses in order; each is compared only with the clusters
+ *      opened inside this round (held in registers), joins the first match or opens one.
+ * The serial part is proportional to the number of clusters opened and only touches LDS: cluster heads
+ * (32 B per pose, IN_LDS when n <= CLUSTER_LDS_MAX) and a 1024-pose exchange buffer.  Sizes, joining order and
+ * votes are computed afterwards in parallel (k_cluster_sizes / _offsets / _members).
  */
-constexpr int CLUSTER_LDS_MAX = 3200;
+constexpr int CLUSTER_LDS_MAX = 3600;
+
+/* matchPose(): |dt| < position_threshold && |angle difference| < rotation_threshold, with the reference's
+ * sqrt only evaluated when the squared distance is within 1e-12 (relative) of the squared threshold */
+__device__ __forceinline__ bool pose_matches(double hx, double hy, double hz, double ha, double tx, double ty, double tz,
+                                             double ang, double pos_thr, double pos_thr2, double rot_thr) {
+  const double dx = hx - tx, dy = hy - ty, dz = hz - tz;
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  const double phi = ppf_fabs(ang - ha);
+  if (!(phi < rot_thr)) return false;
+  if (d2 < pos_thr2 * (1.0 - 1e-12)) return true;
+  if (d2 > pos_thr2 * (1.0 + 1e-12)) return false;
+  return ppf_sqrt(d2) < pos_thr;
+}
+
+constexpr int CL_BLOCK = 256;            /* poses resolved per round */
+constexpr int CL_SLOTS = CL_BLOCK / 64;  /* clusters opened in a round, held in registers: slot i of lane l = i*64 + l */
 
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
   extern __shared__ __align__(16) unsigned char csm[];
   __shared__ uint32_t s_nclusters;
-  __shared__ uint32_t s_match[1024], s_order[1024];
-  __shared__ double s_pose[4][1024];
+  __shared__ uint32_t s_match[CL_BLOCK], s_order[CL_BLOCK];
+  __shared__ double s_pose[4][CL_BLOCK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.n;
   const int np = min(a.num_poses, n);
   double* hx;
-  uint32_t* csize;
-  if constexpr (IN_LDS) {
-    hx = reinterpret_cast<double*>(csm);
-    csize = reinterpret_cast<uint32_t*>(hx + 4 * n);
-  } else {
-    hx = a.g_heads;
-    csize = a.g_sizes;
-  }
+  if constexpr (IN_LDS) hx = reinterpret_cast<double*>(csm);
+  else hx = a.g_heads;
   double* hy = hx + n; double* hz = hy + n; double* ha = hz + n;
-  for (int i = tid; i < n; i += 1024) csize[i] = 0;
+  const double pos_thr2 = a.pos_thr * a.pos_thr;
   if (tid == 0) s_nclusters = 0;
-  __threadfence_block();
   __syncthreads();
-  for (int s0 = 0; s0 < np; s0 += 1024) {
+  for (int s0 = 0; s0 < np; s0 += CL_BLOCK) {
     const uint32_t nc0 = s_nclusters;
-    const int s = s0 + tid;
-    uint32_t mine = 0xFFFFFFFFu;
+    /* A. clusters that existed before this round: 4 threads per pose, each scanning every 4th cluster in
+     *    ascending order; the first match overall is the minimum over the 4 (atomicMin). */
+    const int pl = tid & (CL_BLOCK - 1), part = tid >> 8;
+    const int s = s0 + pl;
+    if (part == 0) {
+      if (s < np) {
+        const uint32_t pi = a.order[s];
+        s_pose[0][pl] = a.in[pi].t[0]; s_pose[1][pl] = a.in[pi].t[1]; s_pose[2][pl] = a.in[pi].t[2];
+        s_pose[3][pl] = a.in[pi].angle;
+        s_order[pl] = pi;
+      }
+      s_match[pl] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
     if (s < np) {
-      const uint32_t pi = a.order[s];
-      const double tx = a.in[pi].t[0], ty = a.in[pi].t[1], tz = a.in[pi].t[2], ang = a.in[pi].angle;
-      s_pose[0][tid] = tx; s_pose[1][tid] = ty; s_pose[2][tid] = tz; s_pose[3][tid] = ang;
-      s_order[tid] = pi;
-      for (uint32_t c = 0; c < nc0; c++) {
-        const double dx = hx[c] - tx, dy = hy[c] - ty, dz = hz[c] - tz;
-        const double dn = ppf_sqrt(dx * dx + dy * dy + dz * dz);
-        const double phi = ppf_fabs(ang - ha[c]);
-        if (phi < a.rot_thr && dn < a.pos_thr) { mine = c; break; }
+      const double tx = s_pose[0][pl], ty = s_pose[1][pl], tz = s_pose[2][pl], ang = s_pose[3][pl];
+      for (uint32_t c = (uint32_t)part; c < nc0; c += 4) {
+        if (pose_matches(hx[c], hy[c], hz[c], ha[c], tx, ty, tz, ang, a.pos_thr, pos_thr2, a.rot_thr)) {
+          atomicMin(&s_match[pl], c);
+          break;
+        }
       }
     }
-    s_match[tid] = mine;
     __syncthreads();
+    if (s < np && part == 0 && s_match[pl] != 0xFFFFFFFFu) a.assign[s] = s_match[pl]; /* final: older clusters win */
+    /* B. one wave resolves, in rank order, the poses no older cluster took, against the clusters opened in
+     *    this round (kept in registers) */
     if (wave == 0) {
-      const int cnt = min(1024, np - s0);
-      uint32_t nc = nc0;
-      for (int k = 0; k < cnt; k++) {
-        uint32_t m = s_match[k];
-        if (m == 0xFFFFFFFFu) {
-          const double tx = s_pose[0][k], ty = s_pose[1][k], tz = s_pose[2][k], ang = s_pose[3][k];
-          for (uint32_t cb = nc0; cb < nc && m == 0xFFFFFFFFu; cb += 64) {
-            const uint32_t c = cb + lane;
-            bool hit = false;
-            if (c < nc) {
-              const double dx = hx[c] - tx, dy = hy[c] - ty, dz = hz[c] - tz;
-              const double dn = ppf_sqrt(dx * dx + dy * dy + dz * dz);
-              const double phi = ppf_fabs(ang - ha[c]);
-              hit = phi < a.rot_thr && dn < a.pos_thr;
-            }
+      const int cnt = min(CL_BLOCK, np - s0);
+      double rx[CL_SLOTS], ry[CL_SLOTS], rz[CL_SLOTS], ra[CL_SLOTS];
+#pragma unroll
+      for (int i = 0; i < CL_SLOTS; i++) { rx[i] = 0; ry[i] = 0; rz[i] = 0; ra[i] = 0; }
+      uint32_t nnew = 0;
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int kk = min(c0 + lane, CL_BLOCK - 1);
+        const bool un = (c0 + lane) < cnt && s_match[kk] == 0xFFFFFFFFu;
+        const double ltx = s_pose[0][kk], lty = s_pose[1][kk], ltz = s_pose[2][kk], lang = s_pose[3][kk];
+        const uint32_t lpi = s_order[kk];
+        unsigned long long mask = __ballot(un);
+        while (mask) {
+          const int l = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          auto bc = [&](double v) { /* broadcast lane l's double */
+            const uint64_t b = ppf_d2bits(v);
+            return ppf_bits2d((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l) << 32));
+          };
+          const double tx = bc(ltx), ty = bc(lty), tz = bc(ltz), ang = bc(lang);
+          uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+          for (int i = 0; i < CL_SLOTS; i++) {
+            const bool live = (uint32_t)(i * 64 + lane) < nnew;
+            const bool hit = live && pose_matches(rx[i], ry[i], rz[i], ra[i], tx, ty, tz, ang, a.pos_thr, pos_thr2, a.rot_thr);
             const unsigned long long bal = __ballot(hit);
-            if (bal) m = cb + (uint32_t)(__ffsll((long long)bal) - 1);
+            if (bal && m == 0xFFFFFFFFu) m = nc0 + (uint32_t)(i * 64) + (uint32_t)(__ffsll((long long)bal) - 1);
           }
-          if (m == 0xFFFFFFFFu) { /* open a cluster */
-            m = nc;
+          if (m == 0xFFFFFFFFu) { /* open a cluster: lane (nnew & 63) keeps it in slot nnew >> 6 */
+            m = nc0 + nnew;
+#pragma unroll
+            for (int i = 0; i < CL_SLOTS; i++) {
+              if ((uint32_t)(i * 64 + lane) == nnew) { rx[i] = tx; ry[i] = ty; rz[i] = tz; ra[i] = ang; }
+            }
             if (lane == 0) {
-              a.head[m] = s_order[k];
+              a.head[m] = (uint32_t)__builtin_amdgcn_readlane((int)lpi, l);
               hx[m] = tx; hy[m] = ty; hz[m] = tz; ha[m] = ang;
             }
-            nc++;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            nnew++;
           }
-        }
-        if (lane == 0) { /* joining order inside the cluster: needed for the in-order means */
-          const uint32_t sz = csize[m];
-          a.assign[s0 + k] = m;
-          a.rin[s0 + k] = sz;
-          csize[m] = sz + 1;
+          if (lane == 0) a.assign[s0 + c0 + l] = m;
         }
       }
-      if (lane == 0) s_nclusters = nc;
+      if (lane == 0) s_nclusters = nc0 + nnew;
     }
     __threadfence_block();
     __syncthreads();
   }
   const int nc = (int)s_nclusters;
-  /* member slots in joining order: offsets from the cluster sizes; cluster votes zeroed for the gather */
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int c = 0; c < nc; c++) { a.coff[c] = run; run += csize[c]; }
-    a.coff[nc] = run;
-    *a.n_out = (uint32_t)nc;
-  }
-  for (int c = tid; c < nc; c += 1024) a.cvotes[c] = 0;
+  if (tid == 0) *a.n_out = (uint32_t)nc;
+  for (int c = tid; c < n; c += 1024) { a.cvotes[c] = 0; a.g_sizes[c] = 0; }
 }
 
-/* gather the members' q, t, votes into member-slot (joining) order; cluster votes by integer atomics */
+/* cluster sizes and votes (integer atomics: order-free) */
+__global__ __launch_bounds__(256) void k_cluster_sizes(ClusterArgs a) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int np = min(a.num_poses, a.n);
+  if (s >= np) return;
+  const uint32_t c = a.assign[s];
+  atomicAdd(&a.g_sizes[c], 1u);
+  atomicAdd(&a.cvotes[c], (unsigned long long)a.in[a.order[s]].num_votes);
+}
+
+/* exclusive scan of the cluster sizes -> member-slot offsets (one workgroup, chunks of 1024) */
+__global__ __launch_bounds__(1024) void k_cluster_offsets(ClusterArgs a) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = (int)*a.n_out;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nc; c0 += 1024) {
+    const int c = c0 + tid;
+    const uint32_t v = c < nc ? a.g_sizes[c] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = carry;
+    for (int k = 0; k < wave; k++) woff += wtot[k];
+    if (c < nc) a.coff[c] = woff + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = woff + incl;
+    __syncthreads();
+  }
+  if (tid == 0) a.coff[nc] = carry;
+}
+
+/* gather the members' q, t, votes into member-slot order = joining order: the joining index of a pose is
+ * the number of earlier (rank order) poses of the same cluster */
 __global__ __launch_bounds__(256) void k_cluster_members(ClusterArgs a) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int np = min(a.num_poses, a.n);
   if (s >= np) return;
   const uint32_t c = a.assign[s];
-  const uint32_t slot = a.coff[c] + a.rin[s];
+  uint32_t rin = 0;
+  for (int e = 0; e < np; e++) rin += (e < s && a.assign[e] == c) ? 1u : 0u; /* e is wave-uniform: scalar loads */
+  const uint32_t slot = a.coff[c] + rin;
   const ppf_pose& p = a.in[a.order[s]];
   double* g = a.gq + (size_t)slot * 7;
   g[0] = p.q[0]; g[1] = p.q[1]; g[2] = p.q[2]; g[3] = p.q[3]; g[4] = p.t[0]; g[5] = p.t[1]; g[6] = p.t[2];
   a.gvotes[slot] = p.num_votes;
-  atomicAdd(&a.cvotes[c], (unsigned long long)p.num_votes);
 }
 
 /* steps 3 + 4 of clusterPoses: means in joining order (fp64, sequential per cluster: bit-identical to the CPU
@@ -751,7 +812,7 @@ ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int n
   uint32_t* u = ws->cl_u32.p;
   ca.n_out = u; u += 1;
   uint32_t* order = u; u += n;
-  ca.order = order; ca.assign = u; u += n; ca.rin = u; u += n; ca.head = u; u += n; ca.crank = u; u += n;
+  ca.order = order; ca.assign = u; u += n; ca.head = u; u += n; ca.crank = u; u += n;
   ca.gvotes = u; u += n; ca.g_sizes = u; u += n; ca.coff = u;
   ca.cvotes = ws->cl_votes.p;
   unsigned long long* vkeys = ws->cl_votes.p + nn;
@@ -768,8 +829,10 @@ ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int n
     const unsigned nb = (unsigned)((n + 255) / 256);
     k_vote_keys<<<dim3(nb), dim3(256), 0, st>>>(d_in, n, vkeys);
     k_rank<<<dim3(nb), dim3(256), 0, st>>>(vkeys, n, nullptr, order, nullptr);            /* (votes desc, index asc) */
-    if (n <= CLUSTER_LDS_MAX) k_cluster_assign<true><<<dim3(1), dim3(1024), (size_t)n * 36 + 64, st>>>(ca);
+    if (n <= CLUSTER_LDS_MAX) k_cluster_assign<true><<<dim3(1), dim3(1024), (size_t)n * 32 + 64, st>>>(ca);
     else k_cluster_assign<false><<<dim3(1), dim3(1024), 0, st>>>(ca);
+    k_cluster_sizes<<<dim3(nb), dim3(256), 0, st>>>(ca);
+    k_cluster_offsets<<<dim3(1), dim3(1024), 0, st>>>(ca);
     k_cluster_members<<<dim3(nb), dim3(256), 0, st>>>(ca);
     k_rank<<<dim3(nb), dim3(256), 0, st>>>(ca.cvotes, 0, ca.n_out, nullptr, ca.crank);    /* (cluster votes desc, creation asc) */
     k_cluster_finish<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(ca);
