@@ -388,19 +388,22 @@ __device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes
                                            const float S, const float Ohg, const double* __restrict__ asd_lds,
                                            const float G2, const int A) {
   int k[U];
-  bool need = false;
+  float frmin = 1.0f;
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const float q = __builtin_fmaf(__uint_as_float(ent[u].y), S, Ohg);
     k[u] = (int)q;
-    need |= (__builtin_amdgcn_fractf(q) < G2);
+    frmin = fminf(frmin, __builtin_amdgcn_fractf(q)); /* folds into v_min3_f32 pairs */
   }
-  if (__builtin_expect(__any(need), 0)) {
+  if (__builtin_expect(__any(frmin < G2), 0)) {
     const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const float q = __builtin_fmaf(__uint_as_float(ent[u].y), S, Ohg);
-      if (__builtin_amdgcn_fractf(q) < G2) k[u] = ppf_alpha_bin_exact(__uint_as_float(ent[u].y), asd, A);
+      uint32_t am_bits = ent[u].y;
+      asm volatile("" : "+v"(am_bits)); /* keep the fp64 conversions of the rare path out of the hot loop */
+      const float am = __uint_as_float(am_bits);
+      const float q = __builtin_fmaf(am, S, Ohg);
+      if (__builtin_amdgcn_fractf(q) < G2) k[u] = ppf_alpha_bin_exact(am, asd, A);
     }
   }
 #pragma unroll
