@@ -162,3 +162,28 @@ def test_errors(bottle):
     # fewer sampled rows than the reference stride: one pose voted, zero clustered (reference quirk)
     tiny = scene[:15]
     assert det.match(tiny, 1.0 / 20.0, 0.05, presampled=True) == []
+
+
+def test_device_sampling_matches_oracle_on_large_clouds(bottle):
+    """Row A2 on the device (bbox -> cell keys -> stable radix sort -> per-cell fp64 sums in point order):
+    sampled model rows and sampled scene rows are bit-identical to the CPU restatement, 19,753- and 200,000-point
+    clouds, several grid resolutions, duplicate points and a flat (zero-extent) axis included."""
+    for step in (0.025, 0.036, 0.05, 0.1):
+        det = PPF3DDetector(step, 0.05).trainModel(bottle)
+        np.testing.assert_array_equal(det.sampled_model(), O.sample(bottle, step))
+    big, _ = synth.make_scene(bottle, n_points=200000, seed=31, n_instances=2)
+    big[1000:1100] = big[0]          # duplicates land in one cell, summed in index order
+    det = PPF3DDetector(0.07, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.07, 0.05).train_model(bottle)
+    got = det.raw_votes(big, 1.0 / 50.0, 0.02, presampled=False)
+    want = ora.match(big, relative_scene_sample_step=1.0 / 50.0, relative_scene_distance=0.02, presampled=False,
+                     cluster=False)
+    assert got["stats"]["n_scene_sampled"] == want["sampled_scene"].shape[0]
+    np.testing.assert_array_equal(got["triples"], want["triples"])
+    flat = big[:5000].copy()
+    flat[:, 2] = 0.5                 # zero z range: every point in z-cell 0
+    got = det.raw_votes(flat, 1.0 / 10.0, 0.05, presampled=False)
+    want = ora.match(flat, relative_scene_sample_step=1.0 / 10.0, relative_scene_distance=0.05, presampled=False,
+                     cluster=False)
+    assert got["stats"]["n_scene_sampled"] == want["sampled_scene"].shape[0]
+    np.testing.assert_array_equal(got["triples"], want["triples"])

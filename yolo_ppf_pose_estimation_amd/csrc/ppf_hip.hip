@@ -268,6 +268,7 @@ __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restric
   if (i < n) out[i] += block_off[i / 1024];
 }
 
+#include "ppf_sample_kernels.h"
 #include "ppf_match_kernels.h"
 
 /* ---- diagnostic: evaluate the deterministic math and the pair feature on the device ----------------- */
@@ -647,7 +648,8 @@ void bbox_host(const float* pc, int n, int stride, float lo[3], float hi[3]) {
 
 /* Row A2 (samplePCByQuantization + computeBboxStd) on the host: cell index in float arithmetic,
  * cells emitted in ascending index order, per-cell fp64 sums taken in ascending point order.
- * Implemented as a stable sort of point indices by cell.  (Device version: next row N1.) */
+ * Implemented as a stable sort of point indices by cell.  Host helper behind ppf_sample_cloud only; trainModel
+ * and match use the device version (ppf_sample_kernels.h). */
 std::vector<float> sample_cloud_host(const float* pc, int n, int stride, float step) {
   float lo[3], hi[3];
   bbox_host(pc, n, stride, lo, hi);
@@ -743,6 +745,66 @@ struct CloudDev {
     return PPF_OK;
   }
 };
+
+/* Row A2 on the device: d_src is a device AoS cloud; the sampled rows land in `dst` (SoA) and, when asked for,
+ * in `host_rows` (N' x 6).  One 4-byte read-back sizes the output. */
+ppf_status device_sample_cloud(const float* d_src, int n, int stride, float step, CloudDev& dst,
+                               std::vector<float>* host_rows, hipStream_t st) {
+  const int ns = (int)(1.0 / step);
+  DevBuf<uint32_t> bbox, keys, vals, keys2, vals2, hist, offs, flags, segid, starts;
+  HIPCHK(bbox.reserve(6));
+  const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  const unsigned nb256 = (unsigned)((n + 255) / 256);
+  k_bbox<<<dim3(std::min(nb256, 2048u)), dim3(256), 0, st>>>(d_src, n, stride, bbox.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(keys.reserve(n)); HIPCHK(vals.reserve(n)); HIPCHK(keys2.reserve(n)); HIPCHK(vals2.reserve(n));
+  k_cell_keys<<<dim3(nb256), dim3(256), 0, st>>>(d_src, n, stride, bbox.p, ns, keys.p, vals.p);
+  HIPCHK(hipGetLastError());
+  const unsigned long long max_key = (unsigned long long)ns * ns * ns + (unsigned long long)ns * ns + ns;
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) <= max_key) bits++;
+  const int nblk = (n + RS_BLOCK - 1) / RS_BLOCK;
+  HIPCHK(hist.reserve((size_t)256 * nblk)); HIPCHK(offs.reserve((size_t)256 * nblk));
+  uint32_t *ka = keys.p, *va = vals.p, *kb = keys2.p, *vb = vals2.p;
+  for (int shift = 0; shift < bits; shift += 8) {
+    k_rs_hist<<<dim3(nblk), dim3(RS_BLOCK), 0, st>>>(ka, n, shift, nblk, hist.p);
+    HIPCHK(hipGetLastError());
+    ppf_status s = device_exclusive_scan(hist.p, offs.p, (size_t)256 * nblk, st);
+    if (s != PPF_OK) return s;
+    k_rs_scatter<<<dim3(nblk), dim3(RS_BLOCK), 0, st>>>(ka, va, n, shift, nblk, offs.p, kb, vb);
+    HIPCHK(hipGetLastError());
+    std::swap(ka, kb); std::swap(va, vb);
+  }
+  HIPCHK(flags.reserve((size_t)n + 1)); HIPCHK(segid.reserve((size_t)n + 1));
+  HIPCHK(hipMemsetAsync(flags.p + n, 0, sizeof(uint32_t), st));
+  k_seg_flags<<<dim3(nb256), dim3(256), 0, st>>>(ka, n, flags.p);
+  HIPCHK(hipGetLastError());
+  ppf_status s = device_exclusive_scan(flags.p, segid.p, (size_t)n + 1, st);
+  if (s != PPF_OK) return s;
+  uint32_t n_rows = 0;
+  HIPCHK(hipMemcpyAsync(&n_rows, segid.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(starts.reserve(std::max<uint32_t>(n_rows, 1)));
+  k_seg_starts<<<dim3(nb256), dim3(256), 0, st>>>(flags.p, segid.p, n, starts.p);
+  HIPCHK(hipGetLastError());
+  dst.n = (int)n_rows;
+  dst.pitch = ((int)n_rows + 63) & ~63;
+  HIPCHK(dst.buf.reserve((size_t)6 * std::max(dst.pitch, 64)));
+  DevBuf<float> aos;
+  if (host_rows) HIPCHK(aos.reserve((size_t)std::max<uint32_t>(n_rows, 1) * 6));
+  if (n_rows) {
+    k_seg_sum<<<dim3((n_rows + 63) / 64), dim3(64), 0, st>>>(d_src, stride, va, starts.p, (int)n_rows, n, dst.buf.p, dst.pitch,
+                                                          host_rows ? aos.p : nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  if (host_rows) {
+    host_rows->resize((size_t)n_rows * 6);
+    if (n_rows) HIPCHK(hipMemcpyAsync(host_rows->data(), aos.p, host_rows->size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st)); /* the scratch buffers above die at scope exit */
+  return PPF_OK;
+}
 
 }  // namespace
 
@@ -1005,8 +1067,20 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   if (params->presampled) {
     m->sampled.resize((size_t)n * 6);
     for (int i = 0; i < n; i++) memcpy(&m->sampled[(size_t)i * 6], xyzn + (size_t)i * stride, 24);
-  } else {
-    m->sampled = sample_cloud_host(xyzn, n, stride, (float)params->relative_sampling_step);
+  }
+  hipStream_t st = nullptr;
+  {
+    ppf_status s0;
+    if (params->presampled) {
+      s0 = m->cloud.load_host(m->sampled.data(), n, st);
+    } else { /* A2 on the device: upload the raw model cloud, sample, keep a host copy of the sampled rows */
+      DevBuf<float> d_raw;
+      hipError_t e = d_raw.reserve((size_t)n * stride);
+      if (e == hipSuccess) e = hipMemcpy(d_raw.p, xyzn, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice);
+      s0 = e == hipSuccess ? device_sample_cloud(d_raw.p, n, stride, (float)params->relative_sampling_step, m->cloud, &m->sampled, st)
+                           : fail(PPF_ERR_HIP, "ppf_model_train: upload failed: %s", hipGetErrorString(e));
+    }
+    if (s0 != PPF_OK) { delete m; return s0; }
   }
   const int N = (int)(m->sampled.size() / 6);
   if (N < 2 || (uint64_t)N * N > 0x7FFFFFFFull) {
@@ -1030,9 +1104,7 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   }
   m->info.n_tiles = (N + max_refs - 1) / max_refs;
   m->info.tile_refs = (N + m->info.n_tiles - 1) / m->info.n_tiles;
-  hipStream_t st = nullptr;
-  ppf_status s = m->cloud.load_host(m->sampled.data(), N, st);
-  if (s == PPF_OK) s = build_table(m, st);
+  ppf_status s = build_table(m, st);
   if (s != PPF_OK) {
     delete m;
     return s;
@@ -1134,11 +1206,7 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   /* A2: sample the scene (and edge) cloud, or take the rows as they are */
   auto load = [&](CloudDev& dst, const float* d_src, int rows, int stride) -> ppf_status {
     if (params->presampled) return dst.load_device(d_src, rows, stride, st);
-    std::vector<float> host((size_t)rows * stride);
-    HIPCHK(hipMemcpyAsync(host.data(), d_src, host.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<float> smp = sample_cloud_host(host.data(), rows, stride, (float)params->relative_scene_distance);
-    return dst.load_host(smp.data(), (int)(smp.size() / 6), st);
+    return device_sample_cloud(d_src, rows, stride, (float)params->relative_scene_distance, dst, nullptr, st);
   };
   s = load(ws->surf, d_scene, ns, sstride);
   if (s != PPF_OK) return s;
