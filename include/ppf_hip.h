@@ -20,6 +20,8 @@
  *                                   parity surface {refIndMax, alphaIndMax, maxVotes}
  *   ppf_match_device (+workspace)   same as ppf_match with clouds already resident in HBM and an
  *                                   explicit HIP stream: the entry bench.py times
+ *   ppf_match_batch                 the per-object loop around Matching (CloudProcessing.h:41-45 holds one cloud
+ *                                   per detected object, :58 one detector per model): crops x models
  *   ppf_sample_cloud                samplePCByQuantization inside trainModel/match (A2)
  *   ppf_transform_pc_pose           transformPCPose, src/YOLO_cropping_ppf_test.cpp:125
  *
@@ -164,6 +166,11 @@ ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride
 ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
                          int estride, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
                          int* n_ref, ppf_match_stats* stats);
+
+/* Many crops x many models (BASELINE config C5): every scene is uploaded and sampled once and matched against
+ * every model.  out holds n_scenes x n_models blocks of `cap` poses (best first), n_out the count of each block. */
+ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
+                           int sstride, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
 
 /* ---- matching, device-resident clouds + explicit stream ---------------------------------- */
 ppf_status ppf_workspace_create(ppf_workspace** out);

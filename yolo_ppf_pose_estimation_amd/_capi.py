@@ -78,6 +78,8 @@ _SIGNATURES = {
     "ppf_model_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ppf_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                             C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
+    "ppf_match_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                  C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_raw_votes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.POINTER(MatchParams), C.POINTER(Vote), C.POINTER(Pose), C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(MatchStats)]),

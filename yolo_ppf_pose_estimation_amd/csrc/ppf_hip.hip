@@ -849,6 +849,7 @@ struct ppf_workspace {
   bool timing = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool pending = false;
+  bool has_edge = false;
   uint32_t* acc_dump = nullptr; /* set by ppf_debug_accumulators for one call */
 };
 
@@ -1189,6 +1190,22 @@ static ppf_status check_match_args(const ppf_model* m, const void* scene, int ns
   return PPF_OK;
 }
 
+/* A2: sample the scene (and edge) cloud into the workspace, or take the rows as they are */
+static ppf_status prepare_scene(ppf_workspace* ws, const float* d_scene, int ns, int sstride, const float* d_edge, int ne,
+                                int estride, const ppf_match_params* params, hipStream_t st) {
+  auto load = [&](CloudDev& dst, const float* d_src, int rows, int stride) -> ppf_status {
+    if (params->presampled) return dst.load_device(d_src, rows, stride, st);
+    return device_sample_cloud(d_src, rows, stride, (float)params->relative_scene_distance, dst, nullptr, st);
+  };
+  ppf_status s = load(ws->surf, d_scene, ns, sstride);
+  if (s != PPF_OK) return s;
+  if (d_edge) s = load(ws->edge, d_edge, ne, estride);
+  ws->has_edge = d_edge != nullptr;
+  return s;
+}
+
+static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st);
+
 ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride,
                             const float* d_edge, int ne, int estride, const ppf_match_params* params, void* stream) {
   if (!ws) return fail(PPF_ERR_INVALID, "ppf_match_device: workspace is NULL");
@@ -1196,24 +1213,21 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
   if (s != PPF_OK) return s;
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_device: no HIP device (this engine has no CPU fallback)");
   hipStream_t st = (hipStream_t)stream;
+  s = prepare_scene(ws, d_scene, ns, sstride, d_edge, ne, estride, params, st);
+  if (s != PPF_OK) return s;
+  return match_prepared(m, ws, params, st);
+}
+
+/* everything after A2: frames -> pairs -> group -> rank -> vote -> finalize -> cluster, on the clouds held by ws */
+static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st) {
+  ppf_status s = PPF_OK;
+  const bool d_edge = ws->has_edge;
   ws->model = m;
   ws->params = *params;
   ws->stream = st;
   ws->clustered = false;
   ws->final_poses.clear();
   memset(&ws->stats, 0, sizeof(ws->stats));
-
-  /* A2: sample the scene (and edge) cloud, or take the rows as they are */
-  auto load = [&](CloudDev& dst, const float* d_src, int rows, int stride) -> ppf_status {
-    if (params->presampled) return dst.load_device(d_src, rows, stride, st);
-    return device_sample_cloud(d_src, rows, stride, (float)params->relative_scene_distance, dst, nullptr, st);
-  };
-  s = load(ws->surf, d_scene, ns, sstride);
-  if (s != PPF_OK) return s;
-  if (d_edge) {
-    s = load(ws->edge, d_edge, ne, estride);
-    if (s != PPF_OK) return s;
-  }
   const int rows = ws->surf.n;
   const int scene_step = (int)(1.0 / params->relative_scene_sample_step);
   const int n_ref_total = (rows + scene_step - 1) / scene_step;
@@ -1483,6 +1497,37 @@ ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride
   for (auto& e : ws.ev)
     if (e) (void)hipEventDestroy(e);
   return s;
+}
+
+ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
+                           int sstride, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
+  if (!models || n_models <= 0 || !scenes || !ns || n_scenes <= 0 || !params || !out || cap <= 0 || !n_out)
+    return fail(PPF_ERR_INVALID, "ppf_match_batch: bad argument");
+  for (int k = 0; k < n_models; k++)
+    if (!models[k]) return fail(PPF_ERR_NOT_TRAINED, "ppf_match_batch: model %d is not trained", k);
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_batch: no HIP device (this engine has no CPU fallback)");
+  ppf_workspace ws;
+  DevBuf<float> d_scene;
+  for (int c = 0; c < n_scenes; c++) {
+    ppf_status s = check_match_args(models[0], scenes[c], ns[c], sstride, nullptr, 0, 6, params);
+    if (s != PPF_OK) return s;
+    HIPCHK(d_scene.reserve((size_t)ns[c] * sstride));
+    HIPCHK(hipMemcpy(d_scene.p, scenes[c], (size_t)ns[c] * sstride * sizeof(float), hipMemcpyHostToDevice));
+    s = prepare_scene(&ws, d_scene.p, ns[c], sstride, nullptr, 0, 6, params, nullptr); /* sampled once per crop */
+    if (s != PPF_OK) return s;
+    for (int k = 0; k < n_models; k++) {
+      s = match_prepared(models[k], &ws, params, nullptr);
+      if (s != PPF_OK) return s;
+      int n = 0;
+      ppf_pose* dst = out + ((size_t)c * n_models + k) * cap;
+      s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, nullptr, 0, &n, nullptr);
+      if (s != PPF_OK) return s;
+      const int take = std::min(n, cap); /* poses are sorted by votes: keep the best `cap` */
+      if (take) memcpy(dst, ws.final_poses.data(), (size_t)take * sizeof(ppf_pose));
+      n_out[(size_t)c * n_models + k] = take;
+    }
+  }
+  return PPF_OK;
 }
 
 ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,

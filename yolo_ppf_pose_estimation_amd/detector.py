@@ -269,6 +269,27 @@ class PPF3DDetector:
         return [Pose3D(out[i]) for i in range(nout.value)]
 
 
+def match_batch(detectors: List[PPF3DDetector], scenes: List[np.ndarray], relativeSceneSampleStep: float = 1.0 / 5.0,
+                relativeSceneDistance: float = 0.03, *, presampled: bool = False, top_k: int = 5) -> List[List[List[Pose3D]]]:
+    """ppf_match_batch: result[c][k] = best `top_k` poses of crop c against detectors[k] (BASELINE config C5)."""
+    for d in detectors:
+        d._require_trained()
+    clouds = [_cloud(sc, "scene") for sc in scenes]
+    stride = clouds[0].shape[1]
+    if any(c.shape[1] != stride for c in clouds):
+        raise PPFError(_capi.PPF_ERR_INVALID, "all scenes must share one row pitch")
+    nm, nc = len(detectors), len(clouds)
+    models = (C.c_void_p * nm)(*[d._model.ptr for d in detectors])
+    ptrs = (C.c_void_p * nc)(*[c.ctypes.data for c in clouds])
+    ns = (C.c_int * nc)(*[c.shape[0] for c in clouds])
+    mp = detectors[0]._params(relativeSceneSampleStep, relativeSceneDistance, presampled)
+    out = (Pose * (nc * nm * top_k))()
+    n_out = (C.c_int * (nc * nm))()
+    check(lib().ppf_match_batch(models, nm, ptrs, ns, stride, nc, C.byref(mp), out, top_k, n_out))
+    return [[[Pose3D(out[(c * nm + k) * top_k + i]) for i in range(n_out[c * nm + k])] for k in range(nm)]
+            for c in range(nc)]
+
+
 def samplePCByQuantization(pc: np.ndarray, relative_step: float) -> np.ndarray:
     a = _cloud(pc, "cloud")
     n = C.c_int(0)
