@@ -114,12 +114,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal knobs (one-GPU box): PPF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, PPF_BENCH_BACKEND=gloo swaps
+    # RCCL for gloo.  The driver's multi-GPU runs use neither: one rank per GPU over RCCL ("nccl").
+    one_device = os.environ.get("PPF_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("PPF_BENCH_BACKEND", "nccl")
+    device_index = 0 if one_device else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     from yolo_ppf_pose_estimation_amd import parallel, synth
     from yolo_ppf_pose_estimation_amd._capi import Pose
@@ -145,7 +153,7 @@ def main():
             fin, k_top, n_clusters, st = ws.top_poses(TOP_K)
             if world > 1:
                 # the path's only collective: all_gather (RCCL) of each rank's top poses, 5 x 216 B per rank
-                parallel.gather_poses(parallel.poses_to_array(fin, k_top, TOP_K), device="cuda")
+                parallel.gather_poses(parallel.poses_to_array(fin, k_top, TOP_K), device="cuda" if backend == "nccl" else None)
         return {"stats": st, "n_clusters": n_clusters}
 
     def sync():
@@ -169,8 +177,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     n_poses_clustered = res["n_clusters"]
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(votes), float(pairs)], dtype=torch.float64, device="cuda")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(votes), float(pairs)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
