@@ -35,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# ds_add_u32 ceiling measured with profiles/ubench_valu_lds.hip: 14.6 lanes/clk/CU x 256 CUs x 2.4 GHz
+LDS_ATOMIC_PEAK = 8.97e12
 
 MODEL_STEP = 0.036      # bottle -> 2,000 sampled model points
 SCENE_POINTS = 50000
@@ -235,6 +237,11 @@ def main():
                         "hbm_only_* removes the LDS part (8 B/vote + clear/scan)",
             },
         }
+        # what actually bounds k_vote: one LDS atomic per vote (plus ~5 VALU); reported beside the contract's
+        # HBM roofline because the accumulator never leaves LDS
+        line["lds_atomic_roofline"] = {"kernel": "k_vote", "achieved": st["n_votes"] / avg_vote_s, "peak": LDS_ATOMIC_PEAK,
+                                       "unit": "votes/s", "frac": st["n_votes"] / avg_vote_s / LDS_ATOMIC_PEAK,
+                                       "source": "profiles/r01_ubench_valu_lds.txt"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(bottle, scene, n_ref_total, args.cpu_seconds)
         else:

@@ -409,7 +409,11 @@ __device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes
 #pragma unroll
   for (int u = 0; u < U; u++) {
     if (u < n_valid) {
-      const int adr = (int)ent[u].x + k[u] * 4;
+      int adr = (int)ent[u].x + k[u] * 4;
+#if PPF_ABL == 1 /* diagnostic: same instruction stream, conflict-free addresses */
+      asm volatile("" ::"v"(adr));
+      adr = (int)((threadIdx.x & 63) * 4 + u * 256 + 1024);
+#endif
 #if PPF_ABL == 2 || PPF_ABL == 5 /* diagnostic: no atomics */
       asm volatile("" ::"v"(adr));
 #else
