@@ -1,0 +1,70 @@
+"""BASELINE config C1: the reference's own data, the reference's own parameters.
+
+Model  = data/bottle_remesh_meter_normalized.ply (tests/golden/bottle_model_xyzn.npy)
+Scene  = crop of data/1_depth.exr around the bottle, deprojected with the reference's intrinsics
+         (tests/golden/c1_crop_xyzn.npy, c1_edge_xyzn.npy; generator tests/golden/make_c1_fixture.py)
+Params = CloudProcessor defaults 0.025 / 0.05 (CloudProcessing.h:64-65), Matching_S2B(…, 0.05, 0.05) (:481-482),
+         Matching(…, 0.0714, 0.05) (:428-429), top-5 poses (:455,508).
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+import oracle_lib as O
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def c1():
+    return (np.load(os.path.join(GOLDEN, "c1_crop_xyzn.npy")), np.load(os.path.join(GOLDEN, "c1_edge_xyzn.npy")))
+
+
+@pytest.fixture(scope="module")
+def oracle_c1(bottle, c1):
+    det = O.OracleDetector(0.025, 0.05).train_model(bottle)
+    crop, edge = c1
+    return det, det.match(crop, relative_scene_sample_step=0.0714, relative_scene_distance=0.05), \
+        det.match(crop, edge=edge, relative_scene_sample_step=0.05, relative_scene_distance=0.05)
+
+
+def test_c1_fixture_shape(c1):
+    crop, edge = c1
+    assert crop.shape == (9906, 6) and edge.shape == (1456, 6)
+    np.testing.assert_allclose(np.linalg.norm(crop[:, 3:], axis=1), 1.0, atol=1e-5)
+    assert 0.5 < crop[:, 2].min() < 0.6  # the bottle stands ~0.6 m from the camera, like the model (z in [0.558, 0.682])
+
+
+def test_c1_oracle_places_the_bottle_on_the_crop(bottle, c1, oracle_c1):
+    det, r_match, r_s2b = oracle_c1
+    crop, _ = c1
+    assert det.info()["n_ref"] == 3870
+    tree = cKDTree(crop[:, :3].astype(np.float64))
+    for r in (r_match, r_s2b):
+        assert r["n_final"] >= 5
+        best = min(np.median(tree.query(bottle[::20, :3].astype(np.float64) @ p["pose"][:3, :3].T + p["pose"][:3, 3])[0])
+                   for p in r["poses"][:5])
+        # one of the five poses the reference would hand to ICP puts the model surface within ~2 cm of the data
+        assert best < 0.02, best
+
+
+@pytest.mark.gpu
+def test_c1_gpu_parity(bottle, c1, oracle_c1):
+    from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+    _, r_match, r_s2b = oracle_c1
+    crop, edge = c1
+    det = PPF3DDetector(0.025, 0.05).trainModel(bottle)
+    assert det.info()["n_ref"] == 3870 and det.info()["n_tiles"] == 4
+    a = det.raw_votes(crop, 0.0714, 0.05)
+    np.testing.assert_array_equal(a["triples"], r_match["triples"])
+    assert a["stats"]["n_votes"] == int(r_match["votes_per_ref"].sum())
+    b = det.raw_votes(crop, 0.05, 0.05, edge=edge)
+    np.testing.assert_array_equal(b["triples"], r_s2b["triples"])
+    assert b["stats"]["n_votes"] == int(r_s2b["votes_per_ref"].sum())
+    poses = det.match_S2B(crop, edge, 0.05, 0.05)   # the call main() makes (src/YOLO_cropping_ppf_test.cpp:122)
+    assert len(poses) == r_s2b["n_final"]
+    for g, w in zip(poses[:5], r_s2b["poses"][:5]):
+        assert g.numVotes == w["num_votes"]
+        np.testing.assert_allclose(g.pose, w["pose"], rtol=0, atol=1e-12)
