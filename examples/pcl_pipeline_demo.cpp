@@ -1,0 +1,52 @@
+/*
+ * pcl_pipeline_demo.cpp — PCL's ppf_object_recognition call sequence on the HIP engine through
+ * include/ppf_pcl.hpp (no PCL needed to build).  usage: pcl_pipeline_demo model.ply scene.ply
+ */
+#include <iostream>
+
+#include "ppf_pcl.hpp"
+
+using namespace ppfhip;
+using namespace ppfhip::pcl_shaped;
+
+static PointCloud<PointNormal>::Ptr load(const char* path) {
+  ppf_match_3d::Mat m = ppf_match_3d::loadPLYSimple(path, 1);
+  PointCloud<PointNormal>::Ptr c(new PointCloud<PointNormal>());
+  c->points.resize((size_t)m.rows);
+  for (int i = 0; i < m.rows; i++) {
+    const float* r = m.ptr<float>(i);
+    c->points[(size_t)i] = PointNormal{r[0], r[1], r[2], r[3], r[4], r[5]};
+  }
+  return c;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { std::cerr << "usage: " << argv[0] << " model.ply scene.ply" << std::endl; return 1; }
+  try {
+    PointCloud<PointNormal>::Ptr cloud_model = load(argv[1]), cloud_scene = load(argv[2]);
+    PPFFeatureCloud::Ptr cloud_model_ppf(new PPFFeatureCloud());
+    PPFEstimation<PointNormal, PointNormal, PPFSignature> ppf_estimator;
+    ppf_estimator.setInputCloud(cloud_model);
+    ppf_estimator.setInputNormals(cloud_model);
+    ppf_estimator.compute(*cloud_model_ppf);
+    PPFHashMapSearch::Ptr hashmap_search(new PPFHashMapSearch(12.0f / 180.0f * 3.14159265f, 0.012f));
+    hashmap_search->setInputFeatureCloud(cloud_model_ppf);
+    PPFRegistration<PointNormal, PointNormal> ppf_registration;
+    ppf_registration.setSceneReferencePointSamplingRate(20);
+    ppf_registration.setPositionClusteringThreshold(0.05f);
+    ppf_registration.setRotationClusteringThreshold(30.0f / 180.0f * 3.14159265f);
+    ppf_registration.setSearchMethod(hashmap_search);
+    ppf_registration.setInputSource(cloud_model);
+    ppf_registration.setInputTarget(cloud_scene);
+    PointCloud<PointNormal> cloud_output;
+    ppf_registration.align(cloud_output);
+    auto T = ppf_registration.getFinalTransformation();
+    std::cout << "RESULT converged=" << ppf_registration.hasConverged() << " votes="
+              << (ppf_registration.getBestPoseCandidates().empty() ? 0u : ppf_registration.getBestPoseCandidates()[0].votes)
+              << " t=" << T[3] << "," << T[7] << "," << T[11] << std::endl;
+  } catch (const ppf_match_3d::Error& e) {
+    std::cerr << "ppf error " << (int)e.status << ": " << e.what() << std::endl;
+    return 10 + (int)e.status;
+  }
+  return 0;
+}

@@ -12,10 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "yolo_ppf_pose_estimation_amd", "csrc")
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "cloud_processor_demo")
+def _build(tmp_path, name="cloud_processor_demo"):
+    exe = str(tmp_path / name)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "cloud_processor_demo.cpp"), "-L", CSRC, "-lppf_hip",
+                    os.path.join(ROOT, "examples", name + ".cpp"), "-L", CSRC, "-lppf_hip",
                     f"-Wl,-rpath,{CSRC}", "-o", exe], check=True)
     return exe
 
@@ -57,3 +57,33 @@ def test_facade_matches_python_binding(tmp_path, bottle):
     # S2B through the facade: edge == scene gives the same top pose
     r2 = subprocess.run([exe, m, s, s, out, "0.05"], capture_output=True, text=True)
     assert r2.returncode == 0 and int(r2.stdout.split("RESULT votes=")[1].split()[0]) == votes
+
+
+def test_pcl_shaped_facade_compiles_and_fails_loudly_without_gpu(tmp_path, bottle):
+    exe = _build(tmp_path, "pcl_pipeline_demo")
+    if _capi.lib().ppf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    m, s = _inputs(tmp_path, bottle)
+    r = subprocess.run([exe, m, s], capture_output=True, text=True)
+    assert r.returncode == 10 + _capi.PPF_ERR_HIP and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_pcl_shaped_facade_runs(tmp_path, bottle):
+    """PPFEstimation -> PPFHashMapSearch -> PPFRegistration: the same engine call as the Python binding with the
+    equivalent parameters (model rows as given, absolute distance step, sampling rate 20)."""
+    from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+    exe = _build(tmp_path, "pcl_pipeline_demo")
+    m, s = _inputs(tmp_path, bottle)
+    r = subprocess.run([exe, m, s], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "converged=1" in r.stdout
+    votes = int(r.stdout.split("votes=")[1].split()[0])
+    model, scene = ply.load_ply_simple(m), ply.load_ply_simple(s)
+    diameter = float(np.linalg.norm((model[:, :3].max(0) - model[:, :3].min(0)).astype(np.float32)))
+    rel = float(np.float32(0.012)) / float(np.float32(diameter))
+    det = PPF3DDetector(rel, rel, 2.0 * np.pi / float(np.float32(12.0 / 180.0 * 3.14159265)), distance_from_distance_step=True)
+    det.trainModel(model, presampled=True)
+    det.setSearchParams(float(np.float32(0.05)), float(np.float32(30.0 / 180.0 * 3.14159265)))
+    poses = det.match(scene, 1.0 / 20.0, 0.05, presampled=True)
+    assert votes == poses[0].numVotes
