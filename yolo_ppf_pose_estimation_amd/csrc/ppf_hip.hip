@@ -12,8 +12,9 @@
  *                 in one 16-byte load (the reference indexes 2^k slots by hash % slots and never
  *                 compares keys, so only "which slots are non-empty" has to be kept)
  *   bucket_off    n_tiles x (n_buckets+1) u32 CSR offsets, one CSR per accumulator tile
- *   (each bucket's entries are stored interleaved over their 32 LDS bank classes, see place_entry)
- *   entries       {u32 LDS byte offset of the model ref's accumulator row = (guard + local_ref*pitch)*4, f32 alpha_m}: 8 B per model pair
+ *   records       pair records {row_a, row_b, alpha_a, alpha_b}: row = u32 LDS byte offset of the model ref's accumulator
+ *                 row (guard + local_ref*pitch)*4, alpha = f32 alpha_m; 8 B per model pair, bank- and phase-interleaved
+ *                 (see place_entry); bucket_off counts records
  *   accumulator   LDS, tile_refs x numAngles u32 per workgroup (one workgroup = one scene
  *                 reference point x one tile of model reference points)
  *
@@ -177,44 +178,67 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
 }
 
 /* phase 0: count entries per (tile, bucket); phase 1: scatter through cursors */
-/* LDS bank class of a table entry: the bank its vote lands on when alpha_s == 0.  For any other
- * alpha_s the bins of a bucket's entries shift together (up to one bin of jitter), so entries of
- * distinct classes keep landing on distinct banks. */
-__device__ __forceinline__ uint32_t entry_bank_class(uint32_t row_bytes, float alpha_m, int num_angles) {
-  const int bin0 = (int)(alpha_m * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles);
-  return (row_bytes / 4u + (uint32_t)bin0) & 31u;
+/* ---- table layout (see also ppf_match_kernels.h) -------------------------------------------------------------
+ * The entries of a (tile, bucket) are stored as PAIR RECORDS {row_a, row_b, alpha_a, alpha_b} (16 B): a lane of
+ * k_vote loads one record (global_load_dwordx4), computes both alpha bins with one v_pk_fma_f32 and casts two
+ * LDS atomics.  One ds_add_u32 wave-instruction therefore covers the a-slots (or the b-slots) of 64 consecutive
+ * records, i.e. two groups of 32 as far as LDS banking is concerned.  Entries are first put in a DEALING ORDER
+ * in which 32 consecutive entries hit 32 different LDS banks for (almost) every alpha_s:
+ *   - bank class  c = (row_word + bin0(alpha_m)) mod 32: the bank of the vote when alpha_s == 0; for another
+ *     alpha_s all bins shift together, up to one bin of jitter decided by where alpha_m sits inside its bin;
+ *   - phase level lv = that position inside the bin, quantised to TABLE_LEVELS: entries of one level jitter together;
+ *   - order = (level, round k = rank of the entry inside its (level, class), class): round k of a level holds one
+ *     entry of every class that still has one.
+ * Dealing position j -> record 32*(j/64) + j%32, slot (j%64)/32: 32 consecutive dealing positions share a slot of
+ * 32 consecutive records.  Unused slots of the last records hold dummies that vote into the LDS guard words.
+ */
+constexpr int TABLE_LEVELS_MAX = 4;
+
+__device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
+                                                  uint32_t* cls, uint32_t* lvl) {
+  const float q = alpha_m * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
+  const float fl = floorf(q);
+  *cls = (row_bytes / 4u + (uint32_t)(int)fl) & 31u;
+  *lvl = min((uint32_t)((q - fl) * (float)levels), (uint32_t)(levels - 1));
 }
 
-/* Place one entry.  Buckets are stored bank-interleaved: the entries of a (tile, bucket) are dealt
- * round-robin over their 32 bank classes, so 32 consecutive entries (one LDS lane group of a wave's
- * ds_add) address 32 different banks and never the same cell twice.  With per-class counts cc[] and
- * the entry's rank k inside its class c, its slot is  sum_c' min(cc[c'], k) + #{c' < c : cc[c'] > k}. */
-__device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_bytes, float am, int num_angles,
-                                            uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+__host__ __device__ __forceinline__ uint32_t records_for(uint32_t n_entries) {
+  return 32u * (n_entries / 64u) + min(32u, n_entries % 64u);
+}
+
+/* phase 0: count; phase 1: place (rec_off = record offset of the (tile, bucket)) */
+__device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_bytes, float am, int num_angles, int levels,
+                                            uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
                                             uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
-                                            uint2* __restrict__ entries) {
-  const uint32_t c = entry_bank_class(row_bytes, am, num_angles);
+                                            uint4* __restrict__ records) {
+  uint32_t c, lv;
+  entry_class_level(row_bytes, am, num_angles, levels, &c, &lv);
+  const size_t cbase = tb * (size_t)levels * 32;
   if (phase == 0) {
     atomicAdd(&counts[tb], 1u);
-    atomicAdd(&class_cnt[tb * 32 + c], 1u);
+    atomicAdd(&class_cnt[cbase + lv * 32 + c], 1u);
     return;
   }
-  const uint32_t k = atomicAdd(&class_cur[tb * 32 + c], 1u);
-  uint32_t pos = 0;
+  const uint32_t k = atomicAdd(&class_cur[cbase + lv * 32 + c], 1u);
+  uint32_t j = 0;
+  for (uint32_t l = 0; l < lv; l++)
+    for (uint32_t cc = 0; cc < 32; cc++) j += class_cnt[cbase + l * 32 + cc];
 #pragma unroll 8
   for (uint32_t cc = 0; cc < 32; cc++) {
-    const uint32_t n = class_cnt[tb * 32 + cc];
-    pos += min(n, k) + ((cc < c && n > k) ? 1u : 0u);
+    const uint32_t n = class_cnt[cbase + lv * 32 + cc];
+    j += min(n, k) + ((cc < c && n > k) ? 1u : 0u);
   }
-  entries[offsets[tb] + pos] = make_uint2(row_bytes, __float_as_uint(am));
+  uint32_t* rec = reinterpret_cast<uint32_t*>(&records[rec_off[tb] + 32u * (j / 64u) + (j % 32u)]);
+  const uint32_t slot = (j % 64u) / 32u;
+  rec[slot] = row_bytes;
+  rec[2 + slot] = __float_as_uint(am);
 }
 
-/* phase 0: count entries per (tile, bucket) and per bank class; phase 1: place them */
 __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
                             const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int n_tiles,
-                            int num_angles, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                            int num_angles, int levels, uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
                             uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
-                            uint2* __restrict__ entries, uint32_t* __restrict__ bucket_slot, int phase) {
+                            uint4* __restrict__ records, uint32_t* __restrict__ bucket_slot, int phase) {
   const size_t total = (size_t)n_model * n_model;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -227,12 +251,26 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
   if (phase == 0 && bucket_slot) bucket_slot[b] = slot;
   place_entry(phase, (size_t)tile * n_buckets + b,
               (uint32_t)((vote_guard(num_angles) + (i - tile * tile_refs) * vote_pitch(num_angles)) * 4), am, num_angles,
-              counts, offsets, class_cnt, class_cur, entries);
+              levels, counts, rec_off, class_cnt, class_cur, records);
   /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
    * that point lives in the next tile, the entry is mirrored there: bin A -> cell 0, others -> guard. */
   if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1)
     place_entry(phase, (size_t)(tile + 1) * n_buckets + b, (uint32_t)((vote_guard(num_angles) - num_angles) * 4), am,
-                num_angles, counts, offsets, class_cnt, class_cur, entries);
+                num_angles, levels, counts, rec_off, class_cnt, class_cur, records);
+}
+
+__global__ void k_record_counts(const uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_cnt, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rec_cnt[i] = records_for(counts[i]);
+}
+
+/* every slot starts as a dummy: row = one of the first 64 guard words (never a cell), alpha = 0 */
+__global__ void k_record_init(uint4* __restrict__ records, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t w = (uint32_t)(i & 63u) * 4u;
+    records[i] = make_uint4(w, w, 0u, 0u);
+  }
 }
 
 /* ---- exclusive scan (u32), 1024 elements per block ------------------------------------------- */
@@ -818,7 +856,9 @@ struct ppf_model {
   DevBuf<uint32_t> bucket_off;  /* n_tiles * (n_buckets + 1) */
   DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
   DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
-  DevBuf<uint2> entries;
+  DevBuf<uint4> records;          /* pair records, see place_entry */
+  uint64_t n_records = 0;
+  int levels = 1;
   int device = 0;
 };
 
@@ -1005,36 +1045,57 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
 
   const int T = m->info.n_tiles;
   const size_t ncnt = (size_t)T * n_buckets + 1;
+  DevBuf<uint32_t> rec_cnt;
   HIPCHK(counts.reserve(ncnt));
+  HIPCHK(rec_cnt.reserve(ncnt));
   HIPCHK(offsets.reserve(ncnt));
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
-  DevBuf<uint32_t> class_cnt, class_cur; /* per (tile, bucket, bank class) */
-  HIPCHK(class_cnt.reserve(ncnt * 32));
-  HIPCHK(class_cur.reserve(ncnt * 32));
-  HIPCHK(hipMemsetAsync(class_cnt.p, 0, ncnt * 32 * sizeof(uint32_t), st));
-  HIPCHK(hipMemsetAsync(class_cur.p, 0, ncnt * 32 * sizeof(uint32_t), st));
+  /* per (tile, bucket, phase level, bank class) counters; fewer levels when they would not fit 2 GiB */
+  int levels = TABLE_LEVELS_MAX;
+  while (levels > 1 && ncnt * (size_t)levels * 32 * sizeof(uint32_t) * 2 > (2ull << 30)) levels >>= 1;
+  m->levels = levels;
+  const size_t ncls = ncnt * (size_t)levels * 32;
+  DevBuf<uint32_t> class_cnt, class_cur;
+  HIPCHK(class_cnt.reserve(ncls));
+  HIPCHK(class_cur.reserve(ncls));
+  HIPCHK(hipMemsetAsync(class_cnt.p, 0, ncls * sizeof(uint32_t), st));
+  HIPCHK(hipMemsetAsync(class_cur.p, 0, ncls * sizeof(uint32_t), st));
   const unsigned nblk = (unsigned)((NN + 255) / 256);
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
-                                                m->info.tile_refs, T, m->info.num_angles, counts.p, nullptr, class_cnt.p,
-                                                class_cur.p, nullptr, m->bucket_slot.p, 0);
+                                                m->info.tile_refs, T, m->info.num_angles, levels, counts.p, nullptr,
+                                                class_cnt.p, class_cur.p, nullptr, m->bucket_slot.p, 0);
   HIPCHK(hipGetLastError());
+  /* real entries (N(N-1) + mirrored spill entries) */
   s = device_exclusive_scan(counts.p, offsets.p, ncnt, st);
   if (s != PPF_OK) return s;
   uint32_t n_entries = 0;
   HIPCHK(hipMemcpyAsync(&n_entries, offsets.p + (ncnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  /* record offsets */
+  k_record_counts<<<dim3((unsigned)((ncnt + 255) / 256)), dim3(256), 0, st>>>(counts.p, rec_cnt.p, ncnt - 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(rec_cnt.p + (ncnt - 1), 0, sizeof(uint32_t), st));
+  s = device_exclusive_scan(rec_cnt.p, offsets.p, ncnt, st);
+  if (s != PPF_OK) return s;
+  uint32_t n_records = 0;
+  HIPCHK(hipMemcpyAsync(&n_records, offsets.p + (ncnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   m->info.n_entries = n_entries;
-  /* per-tile CSR rows of n_buckets+1 offsets: row t = offsets[t*NB .. t*NB+NB] (the next row's first
+  m->n_records = n_records;
+  /* per-tile CSR rows of n_buckets+1 RECORD offsets: row t = offsets[t*NB .. t*NB+NB] (the next row's first
    * element closes the last bucket), materialised with an explicit copy per tile */
   HIPCHK(m->bucket_off.reserve((size_t)T * (n_buckets + 1)));
   for (int t = 0; t < T; t++)
     HIPCHK(hipMemcpyAsync(m->bucket_off.p + (size_t)t * (n_buckets + 1), offsets.p + (size_t)t * n_buckets,
                           (size_t)(n_buckets + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-  HIPCHK(m->entries.reserve(std::max<uint32_t>(n_entries, 1)));
+  HIPCHK(m->records.reserve(std::max<uint32_t>(n_records, 1)));
+  if (n_records) {
+    k_record_init<<<dim3((n_records + 255) / 256), dim3(256), 0, st>>>(m->records.p, n_records);
+    HIPCHK(hipGetLastError());
+  }
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
-                                                m->info.tile_refs, T, m->info.num_angles, counts.p, offsets.p, class_cnt.p,
-                                                class_cur.p, m->entries.p, nullptr, 1);
+                                                m->info.tile_refs, T, m->info.num_angles, levels, counts.p, offsets.p,
+                                                class_cnt.p, class_cur.p, m->records.p, nullptr, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(m->bucket_total.reserve(std::max<uint32_t>(n_buckets, 1)));
   if (n_buckets) {
@@ -1043,7 +1104,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   }
   HIPCHK(hipStreamSynchronize(st));
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
-                         m->entries.bytes();
+                         m->records.bytes();
   return PPF_OK;
 }
 
@@ -1138,21 +1199,36 @@ ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows) {
 ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32_t* bucket_off, int32_t* entry_cell,
                                float* entry_alpha) {
   if (!m) return fail(PPF_ERR_INVALID, "ppf_model_get_table: NULL");
-  const size_t nb = m->info.n_buckets, ne = m->info.n_entries;
+  const size_t nb = m->info.n_buckets, nr = m->n_records;
+  const int T = m->info.n_tiles, A = m->info.num_angles;
   if (bucket_slot) HIPCHK(hipMemcpy(bucket_slot, m->bucket_slot.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (bucket_off)
-    HIPCHK(hipMemcpy(bucket_off, m->bucket_off.p, (size_t)m->info.n_tiles * (nb + 1) * sizeof(uint32_t),
-                     hipMemcpyDeviceToHost));
-  if (entry_cell || entry_alpha) {
-    std::vector<uint2> e(ne);
-    HIPCHK(hipMemcpy(e.data(), m->entries.p, ne * sizeof(uint2), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < ne; k++) {
-      if (entry_cell) { /* byte offset of the row -> reference layout local_ref*numAngles (mirrored spill entries: -numAngles) */
-        const int32_t w = (int32_t)(e[k].x / 4) - vote_guard(m->info.num_angles);
-        entry_cell[k] = w < 0 ? -m->info.num_angles : (w / vote_pitch(m->info.num_angles)) * m->info.num_angles;
+  if (!bucket_off && !entry_cell && !entry_alpha) return PPF_OK;
+  /* decode the pair records: per (tile, bucket) the real entries in storage order; dummies (row in the first
+   * guard words) are skipped; the CSR handed out counts ENTRIES */
+  std::vector<uint32_t> roff((size_t)T * (nb + 1));
+  std::vector<uint4> rec(nr);
+  HIPCHK(hipMemcpy(roff.data(), m->bucket_off.p, roff.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (nr) HIPCHK(hipMemcpy(rec.data(), m->records.p, nr * sizeof(uint4), hipMemcpyDeviceToHost));
+  const uint32_t first_real = (uint32_t)((vote_guard(A) - A) * 4);
+  size_t k = 0;
+  for (int t = 0; t < T; t++) {
+    for (size_t b = 0; b < nb; b++) {
+      if (bucket_off) bucket_off[(size_t)t * (nb + 1) + b] = (uint32_t)k;
+      for (uint32_t r = roff[(size_t)t * (nb + 1) + b]; r < roff[(size_t)t * (nb + 1) + b + 1]; r++) {
+        const uint32_t rows[2] = {rec[r].x, rec[r].y}, al[2] = {rec[r].z, rec[r].w};
+        for (int sl = 0; sl < 2; sl++) {
+          if (rows[sl] < first_real) continue;
+          if (k >= m->info.n_entries) return fail(PPF_ERR_INVALID, "ppf_model_get_table: more entries than counted");
+          if (entry_cell) { /* byte offset of the row -> reference layout local_ref*numAngles (mirrored spill entries: -numAngles) */
+            const int32_t w = (int32_t)(rows[sl] / 4) - vote_guard(A);
+            entry_cell[k] = w < 0 ? -A : (w / vote_pitch(A)) * A;
+          }
+          if (entry_alpha) memcpy(&entry_alpha[k], &al[sl], 4);
+          k++;
+        }
       }
-      if (entry_alpha) memcpy(&entry_alpha[k], &e[k].y, 4);
     }
+    if (bucket_off) bucket_off[(size_t)t * (nb + 1) + nb] = (uint32_t)k;
   }
   return PPF_OK;
 }
@@ -1257,7 +1333,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride;
   va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
   va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
-  va.entries = m->entries.p;
+  va.records = m->records.p;
   va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
   va.angle_step = m->info.angle_step; va.dist_step = m->info.distance_step;
   va.partial = ws->partial.p;
@@ -1544,28 +1620,29 @@ ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sst
 
 /* ---- model (de)serialisation: versioned binary CSR (the reference's XML format is defined by a
  * private OpenCV patch and unknown) ------------------------------------------------- */
-static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '1'};
+static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '2'}; /* 02: pair-record table */
 
 ppf_status ppf_model_save(const ppf_model* m, const char* path) {
   if (!m || !path) return fail(PPF_ERR_INVALID, "ppf_model_save: NULL");
-  const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->info.n_entries;
+  const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->n_records;
   std::vector<SlotWord> slotmap(words);
   std::vector<uint32_t> boff((size_t)m->info.n_tiles * (nb + 1)), bslot(nb);
-  std::vector<uint2> ent(ne);
+  std::vector<uint4> ent(ne);
   HIPCHK(hipMemcpy(slotmap.data(), m->slotmap.p, words * sizeof(SlotWord), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(boff.data(), m->bucket_off.p, boff.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (nb) HIPCHK(hipMemcpy(bslot.data(), m->bucket_slot.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (ne) HIPCHK(hipMemcpy(ent.data(), m->entries.p, ne * sizeof(uint2), hipMemcpyDeviceToHost));
+  if (ne) HIPCHK(hipMemcpy(ent.data(), m->records.p, ne * sizeof(uint4), hipMemcpyDeviceToHost));
   FILE* f = fopen(path, "wb");
   if (!f) return fail(PPF_ERR_IO, "ppf_model_save: cannot open %s", path);
   bool ok = fwrite(PPF_MAGIC, 1, 8, f) == 8;
   ok = ok && fwrite(&m->params, sizeof(m->params), 1, f) == 1;
   ok = ok && fwrite(&m->info, sizeof(m->info), 1, f) == 1;
+  ok = ok && fwrite(&m->n_records, sizeof(m->n_records), 1, f) == 1;
   ok = ok && fwrite(m->sampled.data(), sizeof(float), m->sampled.size(), f) == m->sampled.size();
   ok = ok && fwrite(slotmap.data(), sizeof(SlotWord), words, f) == words;
   ok = ok && fwrite(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
   ok = ok && fwrite(bslot.data(), sizeof(uint32_t), nb, f) == nb;
-  ok = ok && fwrite(ent.data(), sizeof(uint2), ne, f) == ne;
+  ok = ok && fwrite(ent.data(), sizeof(uint4), ne, f) == ne;
   ok = (fclose(f) == 0) && ok;
   if (!ok) return fail(PPF_ERR_IO, "ppf_model_save: short write to %s", path);
   return PPF_OK;
@@ -1582,13 +1659,14 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, PPF_MAGIC, 8) == 0;
   ok = ok && fread(&m->params, sizeof(m->params), 1, f) == 1;
   ok = ok && fread(&m->info, sizeof(m->info), 1, f) == 1;
+  ok = ok && fread(&m->n_records, sizeof(m->n_records), 1, f) == 1;
   ok = ok && m->info.n_ref >= 2 && m->info.n_ref < 65536 && m->info.slots >= 16 && (m->info.slots & (m->info.slots - 1)) == 0 &&
-       m->info.n_tiles >= 1 && m->info.n_entries < 0xFFFFFFFFull;
+       m->info.n_tiles >= 1 && m->info.n_entries < 0xFFFFFFFFull && m->n_records < 0xFFFFFFFFull;
   std::vector<SlotWord> slotmap;
   std::vector<uint32_t> boff, bslot;
-  std::vector<uint2> ent;
+  std::vector<uint4> ent;
   if (ok) {
-    const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->info.n_entries;
+    const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->n_records;
     m->sampled.resize((size_t)m->info.n_ref * 6);
     slotmap.resize(words);
     boff.resize((size_t)m->info.n_tiles * (nb + 1));
@@ -1598,7 +1676,7 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
     ok = ok && fread(slotmap.data(), sizeof(SlotWord), words, f) == words;
     ok = ok && fread(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
     ok = ok && fread(bslot.data(), sizeof(uint32_t), nb, f) == nb;
-    ok = ok && fread(ent.data(), sizeof(uint2), ne, f) == ne;
+    ok = ok && fread(ent.data(), sizeof(uint4), ne, f) == ne;
   }
   fclose(f);
   if (!ok) {
@@ -1615,7 +1693,7 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   if (s == PPF_OK) s = up(m->slotmap, slotmap);
   if (s == PPF_OK) s = up(m->bucket_off, boff);
   if (s == PPF_OK) s = up(m->bucket_slot, bslot);
-  if (s == PPF_OK) s = up(m->entries, ent);
+  if (s == PPF_OK) s = up(m->records, ent);
   if (s == PPF_OK) {
     hipError_t e = m->bucket_total.reserve(std::max<uint32_t>(m->info.n_buckets, 1));
     if (e != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: %s", hipGetErrorString(e));

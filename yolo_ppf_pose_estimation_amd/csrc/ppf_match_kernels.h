@@ -45,7 +45,7 @@ constexpr int PAIR_BLOCK = 256;
 constexpr int PAIRS_PER_THREAD = 8;   /* one k_pairs workgroup covers 2048 paired points of one reference point */
 constexpr int VOTE_BLOCK = 1024;
 constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
-constexpr int VOTE_UNROLL = 8;        /* entry loads in flight per lane */
+constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded per lane per batch */
 #ifndef PPF_VOTE_CHUNK_BATCHES
 #define PPF_VOTE_CHUNK_BATCHES 4
 #endif
@@ -55,7 +55,7 @@ constexpr int VOTE_UNROLL = 8;        /* entry loads in flight per lane */
 #ifndef PPF_VOTE_DYNAMIC
 #define PPF_VOTE_DYNAMIC 1
 #endif
-constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * PPF_VOTE_CHUNK_BATCHES; /* table entries per work item (2048) */
+constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * PPF_VOTE_CHUNK_BATCHES; /* pair records per work item (1024 = 2048 entries) */
 constexpr int VOTE_MAX_HITS = PPF_VOTE_MAX_HITS; /* hits of one bucket run voted per work item */
 constexpr int GROUP_BLOCK = 1024;
 constexpr int VOTE_SEG = VOTE_BLOCK;  /* hits staged in LDS per segment: one per thread */
@@ -142,7 +142,7 @@ struct MatchArgs {
   uint32_t slot_mask;
   const uint32_t* bucket_off;
   int n_buckets;
-  const uint2* entries;
+  const uint4* records;    /* pair records {row_a, row_b, alpha_a, alpha_b}; bucket_off counts records */
   int n_tiles, tile_refs, num_angles, n_model;
   double angle_step, dist_step;
   /* per-batch scratch */
@@ -362,62 +362,71 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
  *   (word offset GW-A) with any bin other than A, and the lanes past the end of a bucket (word = lane).
  *   With it the vote needs no range check at all.  Entry offsets are bytes from the guard's start.
  *
- * One vote = v_fma_f32 (q'), v_cvt_i32_f32 (k), v_fract_f32 + v_cmp (guard band), v_lshl_add_u32
- * (byte address), ds_add_u32.
+ * Two votes (one pair record) = v_pk_fma_f32 (both q'), 2 x v_cvt_i32_f32 (k), 2 x v_fract_f32 + a shared
+ * v_min3 reduction (guard band), 2 x v_lshl_add_u32 (byte address), 2 x ds_add_u32.
  *   q' = alpha_m*S + Ohg,  Ohg = A/2 - alpha_s*S + G  (folded once per hit), k = trunc(q')
  *   k is the reference's integer whenever fract(q') >= 2G; otherwise the lane
  *   re-evaluates the fp64 chain.  That happens for ~3e-5 of the votes, so the re-evaluation is
  *   taken once per batch of U entries and only when some lane of the wave needs it.
  */
 
+typedef float ppf_v2f __attribute__((ext_vector_type(2)));
+
 template <int U>
-__device__ __forceinline__ void load_entries(uint2* ent, const uint2* __restrict__ src, const uint32_t e0,
-                                             const int lane) {
+__device__ __forceinline__ void load_records(uint4* rec, const uint4* __restrict__ src, const uint32_t e0, const int lane) {
 #pragma unroll
   for (int u = 0; u < U; u++) {
-#if PPF_ABL == 3 || PPF_ABL == 5 /* diagnostic: no entry loads */
-    ent[u] = make_uint2(((e0 + u * 64 + lane) & 1023u) * 124u, 0x3a000000u + ((e0 + lane) & 0xffffu) * 64u);
+#if PPF_ABL == 3 || PPF_ABL == 5 /* diagnostic: no record loads */
+    const uint32_t x = e0 + u * 64 + lane;
+    rec[u] = make_uint4(((x * 2u) & 1023u) * 124u + 504u, ((x * 2u + 1u) & 1023u) * 124u + 504u,
+                        0x3a000000u + (x & 0xffffu) * 64u, 0x3a000000u + (x & 0xffffu) * 64u + 32u);
 #else
-    ent[u] = src[e0 + u * 64 + lane];
+    rec[u] = src[e0 + u * 64 + lane];
 #endif
   }
 }
 
+/* U pair records per lane -> 2U votes per lane.  n_valid = number of 64-record groups (of the U) holding data. */
 template <int U>
-__device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes, const uint2* ent, const int n_valid,
+__device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes, const uint4* rec, const int n_valid,
                                            const float S, const float Ohg, const double* __restrict__ asd_lds,
                                            const float G2, const int A) {
-  int k[U];
+  int ka[U], kb[U];
   float frmin = 1.0f;
+  const ppf_v2f S2 = {S, S}, O2 = {Ohg, Ohg};
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    const float q = __builtin_fmaf(__uint_as_float(ent[u].y), S, Ohg);
-    k[u] = (int)q;
-    frmin = fminf(frmin, __builtin_amdgcn_fractf(q)); /* folds into v_min3_f32 pairs */
+    const ppf_v2f al = {__uint_as_float(rec[u].z), __uint_as_float(rec[u].w)};
+    const ppf_v2f q = __builtin_elementwise_fma(al, S2, O2); /* v_pk_fma_f32: both entries of the record */
+    ka[u] = (int)q.x;
+    kb[u] = (int)q.y;
+    frmin = fminf(frmin, fminf(__builtin_amdgcn_fractf(q.x), __builtin_amdgcn_fractf(q.y)));
   }
   if (__builtin_expect(__any(frmin < G2), 0)) {
     const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      uint32_t am_bits = ent[u].y;
-      asm volatile("" : "+v"(am_bits)); /* keep the fp64 conversions of the rare path out of the hot loop */
-      const float am = __uint_as_float(am_bits);
-      const float q = __builtin_fmaf(am, S, Ohg);
-      if (__builtin_amdgcn_fractf(q) < G2) k[u] = ppf_alpha_bin_exact(am, asd, A);
+      uint32_t za = rec[u].z, zb = rec[u].w;
+      asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the hot loop */
+      const float aa = __uint_as_float(za), ab = __uint_as_float(zb);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = ppf_alpha_bin_exact(aa, asd, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = ppf_alpha_bin_exact(ab, asd, A);
     }
   }
 #pragma unroll
   for (int u = 0; u < U; u++) {
     if (u < n_valid) {
-      int adr = (int)ent[u].x + k[u] * 4;
+      int adr_a = (int)rec[u].x + ka[u] * 4, adr_b = (int)rec[u].y + kb[u] * 4;
 #if PPF_ABL == 1 /* diagnostic: same instruction stream, conflict-free addresses */
-      asm volatile("" ::"v"(adr));
-      adr = (int)((threadIdx.x & 63) * 4 + u * 256 + 1024);
+      asm volatile("" ::"v"(adr_a), "v"(adr_b));
+      adr_a = (int)((threadIdx.x & 63) * 4 + u * 512 + 1024);
+      adr_b = adr_a + 256;
 #endif
 #if PPF_ABL == 2 || PPF_ABL == 5 /* diagnostic: no atomics */
-      asm volatile("" ::"v"(adr));
+      asm volatile("" ::"v"(adr_a), "v"(adr_b));
 #else
-      atomicAdd(reinterpret_cast<uint32_t*>(acc_bytes + adr), 1u);
+      atomicAdd(reinterpret_cast<uint32_t*>(acc_bytes + adr_a), 1u);
+      atomicAdd(reinterpret_cast<uint32_t*>(acc_bytes + adr_b), 1u);
 #endif
     }
   }
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   for (int c = tid; c < words; c += VOTE_BLOCK) lds_acc[c] = 0u;
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
-  const uint2* __restrict__ entries = a.entries;
+  const uint4* __restrict__ records = a.records;
   const HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
   const int n_hits = (int)a.hit_count[r];
   const float S = (float)((double)A / (4 * PPF_PI));
@@ -566,24 +575,24 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       /* lane l holds the folded offset of hit h0+l: Ohg = A/2 + G - alpha_s*S */
       float ohg_v = 0.f;
       if (lane < nh) ohg_v = Og - __uint_as_float(seg_a32[h0 + lane]) * S;
-      const uint2* __restrict__ src = entries + o;
-      constexpr uint32_t B = 64 * VOTE_UNROLL;
+      const uint4* __restrict__ src = records + o;
+      constexpr uint32_t B = 64 * VOTE_UNROLL; /* records per batch */
       const uint32_t nfull = c / B;
       /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
        * flight while batch b is voted for every hit of the item.  The prefetch is unconditional
        * (the last one re-reads the final batch): a conditional one would merge two control-flow
        * paths and force the compiler into a vmcnt that also waits for the prefetch. */
-      uint2 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
-      if (nfull) load_entries<VOTE_UNROLL>(ea, src, 0, lane);
+      uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
+      if (nfull) load_records<VOTE_UNROLL>(ea, src, 0, lane);
       uint32_t b = 0;
       while (b < nfull) {
-        load_entries<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
+        load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
           cast_votes<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
         }
         if (++b >= nfull) break;
-        load_entries<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
+        load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
           cast_votes<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         for (int u = 0; u < VOTE_UNROLL; u++) {
           const uint32_t e = e0 + u * 64 + lane;
           ea[u] = src[min(e, c - 1)];
-          if (e >= c) ea[u].x = tail_bytes;
+          if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
         }
         const int n_valid = (int)((c - e0 + 63) / 64);
         for (int hh = 0; hh < nh; hh++) {
