@@ -183,26 +183,36 @@ __global__ __launch_bounds__(64) void k_frames(MatchArgs a) {
 
 /* grid: x = chunks of PAIR_BLOCK*PAIRS_PER_THREAD paired points, y = reference point of the batch */
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
+  __shared__ uint2 stash[PAIRS_PER_THREAD][PAIR_BLOCK]; /* {bucket, j} of this thread's hits, one slot per iteration */
   const int r = blockIdx.y;
-  const int lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int i_ref = ref_row(a, r);
   const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
   FastKeyConsts fk;
   fk.rstep32 = (float)(1.0 / a.angle_step);
   fk.gq = 4.0e-6f * fk.rstep32; /* 4e-6 rad: > 10x the 3.4e-7 rad estimate error; 1.9e-5 bins at 12 degrees */
   fk.rdstep = 1.0 / a.dist_step;
-  HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
   unsigned long long my_pairs = 0;
-  const int j0 = blockIdx.x * (PAIR_BLOCK * PAIRS_PER_THREAD) + threadIdx.x;
+  uint32_t hit_mask = 0;
+  const int j0 = blockIdx.x * (PAIR_BLOCK * PAIRS_PER_THREAD) + tid;
+  const int n = a.paired.n;
+  /* the point of the next iteration is fetched while the current pair is hashed */
+  float nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0, nx4 = 0, nx5 = 0;
+  {
+    const int jc = min(j0, n - 1);
+    nx0 = a.paired.x[jc]; nx1 = a.paired.y[jc]; nx2 = a.paired.z[jc];
+    nx3 = a.paired.nx[jc]; nx4 = a.paired.ny[jc]; nx5 = a.paired.nz[jc];
+  }
 #pragma unroll 1
   for (int it = 0; it < PAIRS_PER_THREAD; it++) {
     const int j = j0 + it * PAIR_BLOCK;
-    if ((j - lane) >= a.paired.n) break; /* whole wave past the end */
-    bool hit = false;
-    uint32_t bucket = 0;
-    if (j < a.paired.n && !(a.same_cloud && j == i_ref)) {
-      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
-      const ppf_vec3 n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
+    const ppf_vec3 p2 = ppf_mk3((double)nx0, (double)nx1, (double)nx2), n2 = ppf_mk3((double)nx3, (double)nx4, (double)nx5);
+    {
+      const int jn = min(j + PAIR_BLOCK, n - 1);
+      nx0 = a.paired.x[jn]; nx1 = a.paired.y[jn]; nx2 = a.paired.z[jn];
+      nx3 = a.paired.nx[jn]; nx4 = a.paired.ny[jn]; nx5 = a.paired.nz[jn];
+    }
+    if (j < n && !(a.same_cloud && j == i_ref)) {
       /* match_S2B: the reference point itself is never paired, even when the edge cloud contains it
        * (bit-identical row), so edge == scene reduces exactly to match().  Values came from floats, so
        * comparing the doubles compares the float bits (no NaN/-0 cases in finite clouds). */
@@ -214,20 +224,38 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
         /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
          * computed later (k_group), only for the ~6 % of pairs that found a bucket. */
         my_pairs += 1u;
-        if (b >= 0) { hit = true; bucket = (uint32_t)b; }
+        if (b >= 0) {
+          stash[it][tid] = make_uint2((uint32_t)b, (uint32_t)j);
+          hit_mask |= 1u << it;
+        }
       }
     }
-    const unsigned long long m = __ballot(hit);
-    if (m) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&a.hit_count[r], (uint32_t)__popcll(m));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (hit) {
-        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  /* one returned atomic per wave: wave-wide exclusive scan of the per-lane hit counts */
+  const uint32_t mine = (uint32_t)__popc(hit_mask);
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (total) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.hit_count[r], total);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t pos = base + incl - mine;
+    HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
+    uint2* __restrict__ keys = a.keys_a + (size_t)r * a.hit_cap;
+#pragma unroll 1
+    for (int it = 0; it < PAIRS_PER_THREAD; it++) {
+      if (hit_mask & (1u << it)) {
+        const uint2 h = stash[it][tid];
         HitRec rec;
-        rec.bucket = bucket; rec.alpha32 = (uint32_t)j; rec.alpha_s = 0.0;
-        hits[base + rank] = rec;
-        a.keys_a[(size_t)r * a.hit_cap + base + rank] = make_uint2(bucket, base + rank);
+        rec.bucket = h.x; rec.alpha32 = h.y; rec.alpha_s = 0.0;
+        hits[pos] = rec;
+        keys[pos] = make_uint2(h.x, pos);
+        pos++;
       }
     }
   }
