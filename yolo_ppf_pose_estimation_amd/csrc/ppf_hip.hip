@@ -1367,6 +1367,15 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   /* timing: ev[1]..ev[2] bracket the voting kernel of the first batch only when there are several;
    * with one batch (every measured configuration) they bracket exactly one k_vote launch */
   const int pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
+  /* k_group: one LDS counter per bucket when that fits (<= 30k buckets), else the radix-sort path */
+  va.group_lds_buckets = m->info.n_buckets <= 30000 ? (int)m->info.n_buckets : 0;
+  const size_t group_lds = va.group_lds_buckets ? ((size_t)va.group_lds_buckets + 1 + 16) * sizeof(uint32_t) : 0;
+  static std::once_flag once_g;
+  static hipError_t attr_g = hipSuccess;
+  std::call_once(once_g, [] {
+    attr_g = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group), hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+  });
+  HIPCHK(attr_g);
   for (int base = 0; base < n_ref; base += batch) {
     va.ref_base = base;
     va.n_ref = std::min(batch, n_ref - base);
@@ -1376,7 +1385,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[4], st));
     k_pairs<<<dim3(pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
     HIPCHK(hipGetLastError());
-    k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), 0, st>>>(va);
+    k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), group_lds, st>>>(va);
     HIPCHK(hipGetLastError());
     k_rank<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());

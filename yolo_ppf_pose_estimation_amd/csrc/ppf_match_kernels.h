@@ -153,6 +153,7 @@ struct MatchArgs {
   uint2* keys_b;           /* [n_ref][hit_cap] ping-pong */
   int hit_cap;
   int key_bits;            /* bits of a bucket id */
+  int group_lds_buckets;   /* n_buckets when one LDS counter per bucket fits (single-pass grouping), else 0 */
   const uint32_t* bucket_total; /* [n_buckets] entries of a bucket over all tiles */
   unsigned long long* work;     /* [n_ref] votes the reference point will cast (sum of its hits' bucket sizes) */
   uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
@@ -317,6 +318,42 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   if (n < 2) return;
   uint2* src = a.keys_a + (size_t)r * a.hit_cap;
   uint2* dst = a.keys_b + (size_t)r * a.hit_cap;
+  if (a.group_lds_buckets > 0) {
+    /* Grouping only needs equal buckets to be adjacent (any order inside a bucket: votes commute), so when one
+     * counter per bucket fits in LDS a single counting pass does it: histogram, scan, scatter through cursors.
+     * Retired hits (key 0xFFFFFFFF) go to the extra last counter. */
+    extern __shared__ uint32_t gcnt[];           /* group_lds_buckets + 1 counters, then 16 wave totals */
+    const int nb1 = a.group_lds_buckets + 1;
+    uint32_t* wtot = gcnt + nb1;
+    for (int k = tid; k < nb1; k += GROUP_BLOCK) gcnt[k] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) atomicAdd(&gcnt[min(src[i].x, (uint32_t)(nb1 - 1))], 1u);
+    __syncthreads();
+    /* exclusive scan of nb1 counters: each thread owns a contiguous slice */
+    const int per = (nb1 + GROUP_BLOCK - 1) / GROUP_BLOCK;
+    const int k0 = tid * per, k1 = min(k0 + per, nb1);
+    uint32_t tsum = 0;
+    for (int k = k0; k < k1; k++) tsum += gcnt[k];
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - tsum;
+    for (int w = 0; w < wave; w++) run += wtot[w];
+    for (int k = k0; k < k1; k++) { const uint32_t c = gcnt[k]; gcnt[k] = run; run += c; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) {
+      const uint2 key = src[i];
+      dst[atomicAdd(&gcnt[min(key.x, (uint32_t)(nb1 - 1))], 1u)] = key;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) src[i] = dst[i];
+    return;
+  }
   const int passes = (a.key_bits + 7) / 8;
   for (int pass = 0; pass < passes; pass++) {
     const int shift = pass * 8;
