@@ -427,15 +427,13 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
  *   (word offset GW-A) with any bin other than A, and the lanes past the end of a bucket (word = lane).
  *   With it the vote needs no range check at all.  Entry offsets are bytes from the guard's start.
  *
- * Two votes (one pair record) = v_pk_fma_f32 (both q'), 2 x v_cvt_i32_f32 (k), 2 x v_fract_f32 + a shared
- * v_min3 reduction (guard band), 2 x v_lshl_add_u32 (byte address), 2 x ds_add_u32.
+ * Two votes (one pair record) = 2 x v_fma_f32 (q'), 2 x v_cvt_i32_f32 (k), 2 x v_fract_f32 + a shared v_min3
+ * reduction (guard band), 2 x v_lshl_add_u32 (byte address), 2 x ds_add_u32.
  *   q' = alpha_m*S + Ohg,  Ohg = A/2 - alpha_s*S + G  (folded once per hit), k = trunc(q')
  *   k is the reference's integer whenever fract(q') >= 2G; otherwise the lane
  *   re-evaluates the fp64 chain.  That happens for ~3e-5 of the votes, so the re-evaluation is
  *   taken once per batch of U entries and only when some lane of the wave needs it.
  */
-
-typedef float ppf_v2f __attribute__((ext_vector_type(2)));
 
 template <int U>
 __device__ __forceinline__ void load_records(uint4* rec, const uint4* __restrict__ src, const uint32_t e0, const int lane) {
@@ -458,14 +456,14 @@ __device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes
                                            const float G2, const int A) {
   int ka[U], kb[U];
   float frmin = 1.0f;
-  const ppf_v2f S2 = {S, S}, O2 = {Ohg, Ohg};
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    const ppf_v2f al = {__uint_as_float(rec[u].z), __uint_as_float(rec[u].w)};
-    const ppf_v2f q = __builtin_elementwise_fma(al, S2, O2); /* v_pk_fma_f32: both entries of the record */
-    ka[u] = (int)q.x;
-    kb[u] = (int)q.y;
-    frmin = fminf(frmin, fminf(__builtin_amdgcn_fractf(q.x), __builtin_amdgcn_fractf(q.y)));
+    /* two scalar v_fma_f32: measured faster than one v_pk_fma_f32 on gfx950 (compute-only k_vote 10.0 vs 13.0 ms) */
+    const float qa = __builtin_fmaf(__uint_as_float(rec[u].z), S, Ohg);
+    const float qb = __builtin_fmaf(__uint_as_float(rec[u].w), S, Ohg);
+    ka[u] = (int)qa;
+    kb[u] = (int)qb;
+    frmin = fminf(frmin, fminf(__builtin_amdgcn_fractf(qa), __builtin_amdgcn_fractf(qb)));
   }
   if (__builtin_expect(__any(frmin < G2), 0)) {
     const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
