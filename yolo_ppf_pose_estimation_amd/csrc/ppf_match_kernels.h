@@ -521,7 +521,11 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const int tile_base = tile * a.tile_refs;
   const int refs_here = min(a.tile_refs, a.n_model - tile_base);
   const int words = GW + refs_here * P;
-  for (int c = tid; c < words; c += VOTE_BLOCK) lds_acc[c] = 0u;
+  { /* clear guard + cells with 16-byte LDS stores (the region starts 16-byte aligned) */
+    uint4* z = reinterpret_cast<uint4*>(lds_acc);
+    for (int c = tid; c < words / 4; c += VOTE_BLOCK) z[c] = make_uint4(0u, 0u, 0u, 0u);
+    for (int c = (words & ~3) + tid; c < words; c += VOTE_BLOCK) lds_acc[c] = 0u;
+  }
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
   const uint4* __restrict__ records = a.records;
@@ -683,17 +687,20 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   /* Scan in the reference's order (model ref ascending, alpha bin ascending, strict >) == smallest
    * upstream flat index ref*A + bin among the maxima; the spill cell of row ref-1 is folded into
    * (ref, bin 0) on the way.  Also the exact vote total of the tile. */
-  const int cells = refs_here * A;
   uint32_t* dump = a.acc_dump ? a.acc_dump + (size_t)rg * a.n_model * A + (size_t)tile_base * A : nullptr;
   uint32_t bv = 0, bi = 0xFFFFFFFFu;
   unsigned long long sum = 0;
-  for (int c = tid; c < cells; c += VOTE_BLOCK) {
-    const int ref = c / A, bin = c - ref * A;
-    uint32_t v = acc[ref * P + bin];
-    if (bin == 0 && ref > 0) v += acc[(ref - 1) * P + A];
-    if (dump) dump[c] = v;
-    sum += v;
-    if (v > bv) { bv = v; bi = (uint32_t)c; }
+  /* one thread per accumulator row: consecutive threads read consecutive rows, pitch P is odd -> no bank
+   * conflicts, no integer division; bins ascending with strict > keeps the row's first maximum */
+  for (int ref = tid; ref < refs_here; ref += VOTE_BLOCK) {
+    const uint32_t* row = acc + ref * P;
+    for (int bin = 0; bin < A; bin++) {
+      uint32_t v = row[bin];
+      if (bin == 0 && ref > 0) v += row[A - P]; /* spill cell of the previous row */
+      if (dump) dump[ref * A + bin] = v;
+      sum += v;
+      if (v > bv) { bv = v; bi = (uint32_t)(ref * A + bin); }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
