@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -1115,7 +1116,8 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   if (!(params->relative_sampling_step > 0) || !(params->num_angles >= 1))
     return fail(PPF_ERR_INVALID, "ppf_model_train: bad parameters");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_train: no HIP device (this engine has no CPU fallback)");
-  ppf_model* m = new ppf_model();
+  std::unique_ptr<ppf_model> owner(new ppf_model()); /* released on every early return */
+  ppf_model* m = owner.get();
   m->params = *params;
   HIPCHK(hipGetDevice(&m->device));
   /* ctor + setSearchParams defaults of the reference's detector */
@@ -1142,11 +1144,10 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
       s0 = e == hipSuccess ? device_sample_cloud(d_raw.p, n, stride, (float)params->relative_sampling_step, m->cloud, &m->sampled, st)
                            : fail(PPF_ERR_HIP, "ppf_model_train: upload failed: %s", hipGetErrorString(e));
     }
-    if (s0 != PPF_OK) { delete m; return s0; }
+    if (s0 != PPF_OK) return s0;
   }
   const int N = (int)(m->sampled.size() / 6);
   if (N < 2 || (uint64_t)N * N > 0x7FFFFFFFull) {
-    delete m;
     return fail(PPF_ERR_INVALID, "ppf_model_train: %d sampled model points unsupported", N);
   }
   m->info.n_ref = N;
@@ -1161,17 +1162,15 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   int max_refs = (LDS_ACC_BUDGET - 4 * vote_guard(A)) / (4 * vote_pitch(A));
   if (params->max_tile_refs > 0) max_refs = std::min(max_refs, params->max_tile_refs);
   if (max_refs < 1) {
-    delete m;
     return fail(PPF_ERR_INVALID, "ppf_model_train: num_angles %d too large for the LDS accumulator", A);
   }
   m->info.n_tiles = (N + max_refs - 1) / max_refs;
   m->info.tile_refs = (N + m->info.n_tiles - 1) / m->info.n_tiles;
   ppf_status s = build_table(m, st);
   if (s != PPF_OK) {
-    delete m;
     return s;
   }
-  *out = m;
+  *out = owner.release();
   return PPF_OK;
 }
 
@@ -1664,7 +1663,8 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(PPF_ERR_IO, "ppf_model_load: cannot open %s", path);
   char magic[8];
-  ppf_model* m = new ppf_model();
+  std::unique_ptr<ppf_model> owner(new ppf_model()); /* released on every early return */
+  ppf_model* m = owner.get();
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, PPF_MAGIC, 8) == 0;
   ok = ok && fread(&m->params, sizeof(m->params), 1, f) == 1;
   ok = ok && fread(&m->info, sizeof(m->info), 1, f) == 1;
@@ -1689,7 +1689,6 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   }
   fclose(f);
   if (!ok) {
-    delete m;
     return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file", path);
   }
   m->refcount = 1;
@@ -1712,11 +1711,10 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
     }
   }
   if (s != PPF_OK) {
-    delete m;
     return s;
   }
   HIPCHK(hipGetDevice(&m->device));
-  *out = m;
+  *out = owner.release();
   return PPF_OK;
 }
 
