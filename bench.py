@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2 (default, BASELINE configs[1]: the contract's workload); c4: 10k-pt model vs 200k-pt scene "
+                         "(HBM-resident stress, informational: no cpu_baseline)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -137,11 +140,16 @@ def main():
     from yolo_ppf_pose_estimation_amd.device import Workspace
     import ctypes as C
 
+    global MODEL_STEP, SCENE_POINTS
+    n_instances = 1
+    if args.config == "c4":
+        MODEL_STEP, SCENE_POINTS, n_instances = 0.0135, 200000, 2
+        args.no_cpu_baseline = True
     bottle = np.load(os.path.join(ROOT, "tests", "golden", "bottle_model_xyzn.npy"))
     det = PPF3DDetector(MODEL_STEP, 0.05, max_tile_refs=int(os.environ.get("PPF_TILE_REFS", "0"))).trainModel(bottle)
     info = det.info()
-    seed = 12345 if world == 1 else 1000 + rank
-    scene, _ = synth.make_scene(bottle, n_points=SCENE_POINTS, seed=seed)
+    seed = (12345 if args.config == "c2" else 4) if world == 1 else 1000 + rank
+    scene, _ = synth.make_scene(bottle, n_points=SCENE_POINTS, seed=seed, n_instances=n_instances)
     d_scene = torch.from_numpy(scene).cuda()
     stream = torch.cuda.Stream()
     ws = Workspace(timing=True)
@@ -208,9 +216,12 @@ def main():
             "dtype": "u32 votes / f64 pair features",
             "data": "synthetic",
             "config": {
-                "workload": "C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
-                            "(presampled, every point paired), reference stride 20 -> 2,500 reference points, "
-                            "30 alpha bins" + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"),
+                "workload": ("C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
+                             "(presampled, every point paired), reference stride 20 -> 2,500 reference points, "
+                             "30 alpha bins" if args.config == "c2" else
+                             "C4: bottle model sampled at 0.0135 (~10k pts) vs one 200,000-pt synthetic scene "
+                             "(presampled), reference stride 20 -> 10,000 reference points, 30 alpha bins")
+                            + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"),
                 "n_model": info["n_ref"], "n_scene": SCENE_POINTS, "n_ref": st["n_ref"],
                 "n_tiles": info["n_tiles"], "tile_refs": info["tile_refs"],
                 "table_buckets": info["n_buckets"], "table_entries": info["n_entries"],

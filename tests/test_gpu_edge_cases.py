@@ -1,0 +1,77 @@
+"""Edge cases of the path on the GPU, each against the CPU oracle: other alpha resolutions, scenes where every
+pair finds a bucket (hit lists at worst-case capacity, bucket runs longer than a staging segment), tiny clouds
+and models (16-slot table), reference stride larger than the cloud, weighted clustering."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from yolo_ppf_pose_estimation_amd import synth
+from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(det, ora, scene, step, presampled=True, dist=0.05, edge=None):
+    got = det.raw_votes(scene, step, dist, presampled=presampled, edge=edge)
+    want = ora.match(scene, edge=edge, relative_scene_sample_step=step, relative_scene_distance=dist,
+                     presampled=presampled, cluster=True)
+    assert got["n_ref"] == want["n_ref"]
+    np.testing.assert_array_equal(got["triples"], want["triples"])
+    assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+    poses = det.match(scene, step, dist, presampled=presampled, edge=edge)
+    assert len(poses) == want["n_final"]
+    for g, w in zip(poses, want["poses"]):
+        assert g.numVotes == w["num_votes"]
+        np.testing.assert_allclose(g.pose, w["pose"], rtol=0, atol=1e-12)
+    return got
+
+
+@pytest.mark.parametrize("num_angles", [12, 36, 45])
+def test_other_alpha_resolutions(bottle, num_angles):
+    det = PPF3DDetector(0.08, 0.05, num_angles).trainModel(bottle)
+    ora = O.OracleDetector(0.08, 0.05, num_angles).train_model(bottle)
+    assert det.info()["num_angles"] == ora.info()["num_angles"] == num_angles
+    scene, _ = synth.make_scene(bottle, n_points=2500, seed=41)
+    _same(det, ora, scene, 1.0 / 25.0)
+
+
+def test_scene_is_the_model_every_pair_hits(bottle):
+    """Scene == sampled model: every scene pair is a model pair, so every pair finds its bucket; hit lists are
+    at capacity (n_paired - 1 per reference point) and a bucket's run of hits spans several 1024-hit segments."""
+    det = PPF3DDetector(0.05, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.05, 0.05).train_model(bottle)
+    scene = det.sampled_model()
+    got = _same(det, ora, scene, 1.0 / 50.0)
+    assert got["stats"]["n_pairs"] == got["n_ref"] * (scene.shape[0] - 1)
+    # the identity pose wins
+    top = det.match(scene, 1.0 / 50.0, 0.05, presampled=True)[0]
+    np.testing.assert_allclose(top.pose[:3, :3], np.eye(3), atol=0.35)
+
+
+def test_tiny_inputs(bottle):
+    rng = np.random.default_rng(3)
+    for n_model in (2, 3, 5):
+        p = rng.uniform(-0.05, 0.05, size=(n_model, 3))
+        nn = rng.normal(size=(n_model, 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+        model = np.concatenate([p, nn], axis=1).astype(np.float32)
+        det = PPF3DDetector(0.05, 0.05).trainModel(model, presampled=True)
+        ora = O.OracleDetector(0.05, 0.05).train_model(model, presampled=True)
+        assert det.info()["slots"] == ora.info()["slots"] == (16 if n_model <= 4 else 32)
+        scene = np.concatenate([synth.apply_pose(model, synth.rigid_pose(9, 0.01)), model[:1]], axis=0)
+        _same(det, ora, scene, 1.0)
+    det = PPF3DDetector(0.07, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.07, 0.05).train_model(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=500, seed=8)
+    _same(det, ora, scene[:2], 1.0)          # two points: one pair per reference point
+    _same(det, ora, scene[:1], 1.0)          # one point: no pair at all
+    _same(det, ora, scene[:7], 1.0 / 20.0)   # stride larger than the cloud: one pose voted, none clustered
+
+
+def test_weighted_clustering_and_thresholds(bottle):
+    det = PPF3DDetector(0.07, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.07, 0.05).train_model(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=2500, seed=13)
+    for pos, rot, w in ((0.02, 0.3, True), (0.2, 0.05, False), (1e9, 1e9, True)):
+        det.setSearchParams(pos, rot, w)
+        ora.set_search_params(pos, rot, w)
+        _same(det, ora, scene, 1.0 / 10.0)
