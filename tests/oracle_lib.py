@@ -34,10 +34,10 @@ class OraclePose(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(ORACLE_DIR, "ppf_oracle.cpp")
-    hdr = os.path.join(ROOT, "include", "ppf_detmath.h")
+    srcs = [os.path.join(ORACLE_DIR, "ppf_oracle.cpp"), os.path.join(ORACLE_DIR, "ppf_icp_oracle.cpp"),
+            os.path.join(ROOT, "include", "ppf_detmath.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr)
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in srcs
     )
     if force or stale:
         subprocess.run(["make", "-C", ORACLE_DIR, "-B" if force else "-s"], check=True, stdout=subprocess.DEVNULL)
@@ -86,6 +86,9 @@ def lib():
         L.oracle_dcm_to_quat.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.oracle_quat_to_dcm.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_icp_refine.restype = C.c_int
+        L.oracle_icp_refine.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -297,3 +300,16 @@ def quat_to_dcm(q) -> np.ndarray:
 
 def max_threads() -> int:
     return int(lib().oracle_max_threads())
+
+
+def icp_refine(model, scene, poses, iterations=100, tolerance=0.005, rejection_scale=2.5, num_levels=8):
+    """ICP(iterations, tolerance, rejection_scale, num_levels).registerModelToScene(model, scene, poses):
+    returns (refined poses (k,4,4), residuals (k,), iterations used (k,))."""
+    m, mp = _f32(np.ascontiguousarray(np.asarray(model)[:, :6]))
+    s, sp = _f32(np.ascontiguousarray(np.asarray(scene)[:, :6]))
+    P = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(-1, 16)).copy()
+    res = np.zeros(P.shape[0], dtype=np.float64)
+    its = np.zeros(P.shape[0], dtype=np.int32)
+    lib().oracle_icp_refine(mp, m.shape[0], sp, s.shape[0], int(iterations), float(tolerance), float(rejection_scale),
+                            int(num_levels), _f64p(P), _f64p(res), P.shape[0], its.ctypes.data_as(C.POINTER(C.c_int)))
+    return P.reshape(-1, 4, 4), res, its
