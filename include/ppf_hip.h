@@ -24,6 +24,9 @@
  *                                   per detected object, :58 one detector per model): crops x models
  *   ppf_sample_cloud                samplePCByQuantization inside trainModel/match (A2)
  *   ppf_transform_pc_pose           transformPCPose, src/YOLO_cropping_ppf_test.cpp:125
+ *   ppf_icp_refine (+_device)       ICP icp(100, 0.005f, 2.5f, 8); icp.registerModelToScene(model, scene, poses)
+ *                                   CloudProcessing.h:465-470 (Matching), :518-523 (Matching_S2B)
+ *   ppf_icp_register                ICP::registerModelToScene(src, dst, residual, pose), the single-pose overload
  *
  * Conventions
  *   - Clouds are float32 rows `x y z nx ny nz` (the N x 6 CV_32FC1 Mat that
@@ -138,8 +141,18 @@ typedef struct ppf_match_stats {
   int32_t reserved;
 } ppf_match_stats;
 
+/* cv::ppf_match_3d::ICP constructor arguments (uniform sampling, one correspondence per point) */
+typedef struct ppf_icp_params {
+  int32_t iterations;    /* ICP ctor arg 1 (reference: 100, CloudProcessing.h:465) */
+  float tolerance;       /* arg 2 (0.005f) */
+  float rejection_scale; /* arg 3 (2.5f); <= 0 disables the median+MAD rejection */
+  int32_t num_levels;    /* arg 4 (8) */
+  int32_t reserved[4];
+} ppf_icp_params;
+
 void ppf_default_train_params(ppf_train_params* p);
 void ppf_default_match_params(ppf_match_params* p);
+void ppf_default_icp_params(ppf_icp_params* p); /* 100, 0.005f, 2.5f, 8: the reference's ICP object */
 int ppf_abi_version(void);
 /* copies the calling thread's last error text; returns its length */
 int ppf_last_error(char* buf, int cap);
@@ -207,6 +220,21 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
 ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
                             int* n_out);
 ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* pose16, float* out);
+
+
+/* ---- ICP refinement of matched poses (the step right after the path) ---------------------- */
+/* registerModelToScene(model, scene, poses): every pose moves the model, a multi-level point-to-plane ICP registers
+ * the moved model to the scene, and the pose becomes poseICP * pose (pose/q/t/angle/residual are rewritten, votes
+ * and model_index kept).  iterations_out (optional) receives the iterations spent per pose.  Host clouds. */
+ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, const float* scene, int n_scene, int sstride,
+                          const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out);
+/* same with DEVICE-resident clouds and an explicit hipStream_t (poses_io stays on the host) */
+ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, const float* d_scene, int n_scene, int sstride,
+                                 const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out,
+                                 void* stream);
+/* registerModelToScene(src, dst, residual, pose): one registration without an initial pose */
+ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const float* dst, int n_dst, int dstride,
+                            const ppf_icp_params* params, double* pose16_out, double* residual_out, int* iterations_out);
 
 #ifdef __cplusplus
 }

@@ -201,7 +201,9 @@ int icp_single(const Cloud& srcPC, const Cloud& dstPC, const IcpParams& prm, dou
           const double rowA[6] = {ax[0], ax[1], ax[2], nr[0], nr[1], nr[2]};
           const double bb = sub[0] * nr[0] + sub[1] * nr[1] + sub[2] * nr[2];
           for (int r = 0; r < 6; r++) { for (int cc = 0; cc < 6; cc++) P[r][cc] += rowA[r] * rowA[cc]; P[r][6] += rowA[r] * bb; }
-          for (int cc = 0; cc < 6; cc++) { const double df = (double)s[cc] - (double)d[cc]; fs += df * df; } /* norm(Src_Match - Dst_Match)^2 over all 6 columns */
+          double e = 0; /* norm(Src_Match - Dst_Match)^2 over all 6 columns: per-row subtotal, then into the chunk sum */
+          for (int cc = 0; cc < 6; cc++) { const double df = (double)s[cc] - (double)d[cc]; e += df * df; }
+          fs += e;
         }
         for (int r = 0; r < 6; r++) for (int cc = 0; cc < 7; cc++) M[r][cc] += P[r][cc];
         fsum += fs;

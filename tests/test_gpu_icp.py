@@ -1,0 +1,129 @@
+"""ICP refinement on the GPU (ppf_icp_refine / ppf_icp_register through the C-ABI) against the CPU oracle
+(oracle/ppf_icp_oracle.cpp).  The device kernels follow the oracle's arithmetic and summation orders, so poses,
+residuals and iteration counts must be IDENTICAL, not just close.  Reference call site:
+/root/reference/include/CloudProcessing.h:465-470, :518-523 (ICP icp(100, 0.005f, 2.5f, 8))."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from yolo_ppf_pose_estimation_amd import synth
+from yolo_ppf_pose_estimation_amd.detector import ICP, PPF3DDetector, Pose3D
+
+pytestmark = pytest.mark.gpu
+
+
+def _perturb(T, deg, shift, axis=2):
+    d = np.eye(4)
+    a = np.deg2rad(deg)
+    c, s = np.cos(a), np.sin(a)
+    R = {0: [[1, 0, 0], [0, c, -s], [0, s, c]], 1: [[c, 0, s], [0, 1, 0], [-s, 0, c]], 2: [[c, -s, 0], [s, c, 0], [0, 0, 1]]}[axis]
+    d[:3, :3] = R
+    d[:3, 3] = shift
+    return d @ T
+
+
+def _poses(mats):
+    out = []
+    for k, m in enumerate(mats):
+        p = Pose3D()
+        p.pose = np.array(m, dtype=np.float64)
+        p.numVotes = 100 - k
+        out.append(p)
+    return out
+
+
+def _check(model, scene, mats, **kw):
+    want_P, want_r, want_i = O.icp_refine(model, scene, mats, **kw)
+    icp = ICP(kw.get("iterations", 100), kw.get("tolerance", 0.005), kw.get("rejection_scale", 2.5), kw.get("num_levels", 8))
+    got = icp.registerModelToScene(model, scene, _poses(mats))
+    assert icp.last_iterations == list(want_i)
+    for g, P, r in zip(got, want_P, want_r):
+        np.testing.assert_array_equal(g.pose, P)
+        assert g.residual == r
+    return got
+
+
+def test_icp_matches_oracle_bitwise(bottle):
+    T = synth.rigid_pose(5, 0.1)
+    model, scene = bottle[::8].copy(), synth.apply_pose(bottle[3::5], T)
+    mats = [_perturb(T, 4.0, [0.004, -0.003, 0.002]), _perturb(T, -3.0, [0.0, 0.002, 0.001], axis=0), T]
+    got = _check(model, scene, mats)
+    for g in got:
+        assert np.abs(g.pose - T).max() < 1e-3
+        assert g.numVotes > 0  # votes survive the refinement
+        R = g.pose[:3, :3]
+        np.testing.assert_allclose(g.t, g.pose[:3, 3])
+        assert abs(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1)) - g.angle) < 1e-9
+
+
+@pytest.mark.parametrize("kw", [dict(iterations=30, tolerance=0.005, rejection_scale=0.0, num_levels=1),
+                                dict(iterations=50, tolerance=0.01, rejection_scale=1.5, num_levels=4),
+                                dict(iterations=7, tolerance=0.0, rejection_scale=2.5, num_levels=3)])
+def test_icp_other_parameters(bottle, kw):
+    T = synth.rigid_pose(9, 0.15)
+    model, scene = bottle[1::6].copy(), synth.apply_pose(bottle[::4], T)
+    _check(model, scene, [_perturb(T, 2.5, [0.002, 0.001, -0.002], axis=1)], **kw)
+
+
+def test_icp_cluttered_scene_and_ragged_sizes(bottle):
+    """scene = object + clutter (rejection and picky ownership both active), sizes that are not multiples of
+    the 64-row chunks / 256-point blocks"""
+    scene, Ts = synth.make_scene(bottle, n_points=3001, seed=77)
+    T = Ts[0]
+    model = bottle[::11][:1733].copy()
+    _check(model, scene, [_perturb(T, 3.0, [0.003, 0.0, -0.002])])
+
+
+def test_icp_single_registration(bottle):
+    T = _perturb(np.eye(4), 3.0, [0.003, -0.002, 0.001])
+    src, dst = bottle[::8].copy(), synth.apply_pose(bottle[2::5], T)
+    res, pose = ICP().registerModelToScene(src, dst)
+    assert np.abs(pose - T).max() < 1e-3 and res < 0.01
+
+
+def _surface_error(model, pose, T):
+    """mean distance from the model under `pose` to the model surface under the true pose (the bottle is a solid
+    of revolution, so matrices are only comparable up to its symmetry; surfaces are)"""
+    from scipy.spatial import cKDTree
+    from yolo_ppf_pose_estimation_amd.synth import apply_pose
+    truth = cKDTree(apply_pose(model, T)[:, :3].astype(np.float64))
+    d, _ = truth.query(apply_pose(model, pose)[:, :3].astype(np.float64))
+    return float(d.mean())
+
+
+def test_icp_after_match_improves_pose(bottle):
+    """the reference's sequence: match, take the top poses, refine them with ICP against the scene.  The second
+    pose of this scene is far off the object: its first iteration finds <= 6 correspondences and the level loop
+    breaks at once (residual stays at its 1e10 start value, pose unchanged) -- the oracle's break path."""
+    T = synth.rigid_pose(21, 0.2)
+    rng = np.random.default_rng(3)
+    obj = synth.apply_pose(bottle[1::4], T)
+    out = np.zeros((800, 6), np.float32)
+    out[:, :3] = obj[:, :3].mean(0) + rng.uniform(-0.15, 0.15, (800, 3))
+    nn = rng.normal(size=(800, 3))
+    out[:, 3:] = nn / np.linalg.norm(nn, axis=1, keepdims=True)
+    scene = np.concatenate([obj, out]).astype(np.float32)
+    det = PPF3DDetector(0.05, 0.05).trainModel(bottle)
+    poses = det.match(scene, 1.0 / 10.0, 0.05)[:2]
+    model = bottle[::4].copy()
+    before = _surface_error(model, poses[0].pose, T)
+    votes = [p.numVotes for p in poses]
+    want_P, want_r, want_i = O.icp_refine(model, scene, [p.pose for p in poses])
+    icp = ICP(100, 0.005, 2.5, 8)
+    icp.registerModelToScene(model, scene, poses)
+    after = _surface_error(model, poses[0].pose, T)
+    assert before < 0.01, "the match itself should land on the object"
+    assert after < before and after < 5e-4
+    assert [p.numVotes for p in poses] == votes
+    assert icp.last_iterations == list(want_i)
+    for p, P, r in zip(poses, want_P, want_r):
+        np.testing.assert_array_equal(p.pose, P)
+        assert p.residual == r
+
+
+def test_icp_argument_errors(bottle):
+    from yolo_ppf_pose_estimation_amd._capi import PPFError
+    with pytest.raises(PPFError):
+        ICP().registerModelToScene(bottle[:0], bottle)
+    with pytest.raises(PPFError):
+        ICP(iterations=-1).registerModelToScene(bottle[:100], bottle[:100])

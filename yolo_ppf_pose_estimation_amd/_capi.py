@@ -36,6 +36,11 @@ class MatchParams(C.Structure):
                 ("ref_stride", C.c_int32), ("skip_clustering", C.c_int32), ("reserved", C.c_int32)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("tolerance", C.c_float), ("rejection_scale", C.c_float),
+                ("num_levels", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 class Pose(C.Structure):
     _fields_ = [("pose", C.c_double * 16), ("q", C.c_double * 4), ("t", C.c_double * 3), ("angle", C.c_double),
                 ("alpha", C.c_double), ("residual", C.c_double), ("model_index", C.c_uint32),
@@ -65,6 +70,7 @@ class MatchStats(C.Structure):
 _SIGNATURES = {
     "ppf_default_train_params": (None, [C.POINTER(TrainParams)]),
     "ppf_default_match_params": (None, [C.POINTER(MatchParams)]),
+    "ppf_default_icp_params": (None, [C.POINTER(IcpParams)]),
     "ppf_abi_version": (C.c_int, []),
     "ppf_last_error": (C.c_int, [C.c_char_p, C.c_int]),
     "ppf_device_count": (C.c_int, []),
@@ -100,6 +106,12 @@ _SIGNATURES = {
     "ppf_sample_cloud": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_int)]),
     "ppf_transform_pc_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "ppf_icp_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
+                                 C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
+    "ppf_icp_refine_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
+                                        C.POINTER(Pose), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "ppf_icp_register": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None

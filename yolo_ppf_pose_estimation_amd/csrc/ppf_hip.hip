@@ -309,6 +309,7 @@ __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restric
 
 #include "ppf_sample_kernels.h"
 #include "ppf_match_kernels.h"
+#include "ppf_icp_kernels.h"
 
 /* ---- diagnostic: evaluate the deterministic math and the pair feature on the device ----------------- */
 __global__ void k_debug_math(int fn, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out,
@@ -1716,6 +1717,213 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   HIPCHK(hipGetDevice(&m->device));
   *out = owner.release();
   return PPF_OK;
+}
+
+}  // extern "C"
+
+/* ============================================================================================ */
+/* ICP refinement (row N2; kernels in ppf_icp_kernels.h)                                          */
+/* ============================================================================================ */
+namespace {
+
+struct IcpScratch {
+  DevBuf<float> src0, dst0, src_pct, moved, dst_pcs;
+  DevBuf<float4> q4;
+  DevBuf<unsigned long long> best, owner;
+  DevBuf<int2> sel;
+  DevBuf<double> parts, sum_src, sum_dst;
+  DevBuf<IcpState> state;
+};
+
+constexpr int ICP_BATCH = 4; /* iterations enqueued between two reads of the done flag */
+
+inline long icp_round(double v) { return std::lrint(v); } /* cvRound */
+
+/* ICP::registerModelToScene(srcPC, dstPC, residual, pose) on device-resident clouds.  init_pose (host, may be NULL)
+ * is applied to the source rows first (the caller's `transformPCPose(srcPC, poses[i]->pose)`). */
+ppf_status icp_register(const float* d_src, int n, int sstride, const float* d_dst, int nd_all, int dstride,
+                        const ppf_icp_params& prm, const double* init_pose, IcpScratch& sc, hipStream_t st, double* pose_out,
+                        double* residual, int* iters_total) {
+  const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
+  HIPCHK(sc.src0.reserve((size_t)n * 6));
+  HIPCHK(sc.src_pct.reserve((size_t)n * 6));
+  HIPCHK(sc.moved.reserve((size_t)n * 6));
+  HIPCHK(sc.dst0.reserve((size_t)nd_all * 6));
+  HIPCHK(sc.dst_pcs.reserve((size_t)nd_all * 6));
+  HIPCHK(sc.q4.reserve((size_t)nd_all));
+  HIPCHK(sc.best.reserve((size_t)n));
+  HIPCHK(sc.owner.reserve((size_t)nd_all));
+  HIPCHK(sc.sel.reserve((size_t)std::min(n, nd_all)));
+  HIPCHK(sc.parts.reserve(std::max(chunks_src, chunks_dst) * ICP_ENTRIES));
+  HIPCHK(sc.sum_src.reserve(chunks_src * 3));
+  HIPCHK(sc.sum_dst.reserve(chunks_dst * 3));
+  HIPCHK(sc.state.reserve(1));
+  IcpState* d_st = sc.state.p;
+  IcpState h_st;
+  auto grid = [](size_t items, int block) { return dim3((unsigned)((items + block - 1) / block)); };
+
+  /* the two clouds, packed; the source moved by the initial pose */
+  if (init_pose) {
+    HIPCHK(hipMemcpyAsync(d_st->T, init_pose, 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    k_icp_transform<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, d_st->T, sc.src0.p, nullptr, nullptr, nullptr);
+  } else {
+    k_icp_sample<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, sc.src0.p, nullptr);
+  }
+  k_icp_sample<<<grid(nd_all, 256), dim3(256), 0, st>>>(d_dst, dstride, 1, nd_all, sc.dst0.p, nullptr);
+  /* centre on the average of the two means, scale to unit average distance from the origin */
+  for (int mode = 0; mode < 2; mode++) {
+    k_icp_chunk_sums<<<grid(chunks_src, 64), dim3(64), 0, st>>>(sc.src0.p, n, mode, sc.sum_src.p);
+    k_icp_chunk_sums<<<grid(chunks_dst, 64), dim3(64), 0, st>>>(sc.dst0.p, nd_all, mode, sc.sum_dst.p);
+    k_icp_reduce<<<dim3(1), dim3(64), 0, st>>>(sc.sum_src.p, n, sc.sum_dst.p, nd_all, mode, d_st);
+    k_icp_center_scale<<<grid(n, 256), dim3(256), 0, st>>>(sc.src0.p, n, mode, d_st);
+    k_icp_center_scale<<<grid(nd_all, 256), dim3(256), 0, st>>>(sc.dst0.p, nd_all, mode, d_st);
+  }
+  HIPCHK(hipGetLastError());
+
+  double pose[16];
+  for (int k = 0; k < 16; k++) pose[k] = (k % 5 == 0) ? 1.0 : 0.0;
+  double fval_min = 9999999999.0;
+  int total = 0;
+  const int robust = prm.rejection_scale > 0 ? 1 : 0;
+  for (int level = prm.num_levels - 1; level >= 0; level--) {
+    const double div = std::pow(2.0, (double)level);
+    const int num_samples = (int)icp_round((double)n / div);
+    const double tol_p = (double)prm.tolerance * (double)(level + 1) * (level + 1);
+    const int max_iter = (int)icp_round((double)prm.iterations / (level + 1));
+    const int step = std::max(1, (int)icp_round((double)n / (double)std::max(num_samples, 1)));
+    const int ns = (n + step - 1) / step, nd = (nd_all + step - 1) / step;
+    HIPCHK(hipMemcpyAsync(d_st->T, pose, sizeof(pose), hipMemcpyHostToDevice, st));
+    k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src0.p, 6, step, ns, d_st->T, sc.src_pct.p, sc.moved.p, sc.best.p, nullptr);
+    k_icp_sample<<<grid(nd, 256), dim3(256), 0, st>>>(sc.dst0.p, 6, step, nd, sc.dst_pcs.p, sc.q4.p);
+    k_icp_level_init<<<dim3(1), dim3(1), 0, st>>>(d_st, tol_p, max_iter, robust);
+    /* NN launch shape: model points x scene slices, enough workgroups to fill 256 CUs */
+    const unsigned gx = (unsigned)((ns + 255) / 256);
+    const int max_splits = (nd + 63) / 64;
+    const int splits = std::max(1, std::min(max_splits, (int)(2048 / gx)));
+    const int slice = (nd + splits - 1) / splits;
+    const unsigned gy = (unsigned)((nd + slice - 1) / slice);
+    const unsigned n_chunks = (unsigned)((std::min(ns, nd) + ICP_CHUNK - 1) / ICP_CHUNK);
+    int launched = 0;
+    for (;;) {
+      const int batch = std::min(ICP_BATCH, max_iter - launched);
+      for (int b = 0; b < batch; b++) {
+        k_icp_nn<<<dim3(gx, gy), dim3(256), 0, st>>>(sc.moved.p, ns, sc.q4.p, nd, slice, sc.best.p, d_st);
+        k_icp_threshold<<<dim3(1), dim3(1024), 0, st>>>(sc.best.p, ns, prm.rejection_scale, sc.owner.p, nd, d_st);
+        k_icp_owner<<<grid(ns, 256), dim3(256), 0, st>>>(sc.best.p, ns, sc.owner.p, d_st);
+        k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
+        k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
+        k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
+        k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
+      }
+      launched += std::max(batch, 0);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (h_st.done || launched >= max_iter) break;
+    }
+    total += h_st.iter;
+    fval_min = h_st.fval_min;
+    double tmp[16];
+    ppf_mat44_mul(h_st.PoseX, pose, tmp);
+    memcpy(pose, tmp, sizeof(tmp));
+  }
+  if (prm.num_levels <= 0) {
+    HIPCHK(hipMemcpyAsync(&h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
+  double Rm[3];
+  for (int r = 0; r < 3; r++) Rm[r] = pose[r * 4] * h_st.mean_avg[0] + pose[r * 4 + 1] * h_st.mean_avg[1] + pose[r * 4 + 2] * h_st.mean_avg[2];
+  for (int r = 0; r < 3; r++) pose[r * 4 + 3] = pose[r * 4 + 3] / h_st.scale + h_st.mean_avg[r] - Rm[r];
+  memcpy(pose_out, pose, sizeof(pose));
+  if (residual) *residual = fval_min;
+  if (iters_total) *iters_total = total;
+  return PPF_OK;
+}
+
+ppf_status icp_check(const char* who, const void* src, int n, int sstride, const void* dst, int nd, int dstride, const ppf_icp_params* prm) {
+  if (!src || !dst || !prm || n <= 0 || nd <= 0 || sstride < 6 || dstride < 6) return fail(PPF_ERR_INVALID, "%s: bad argument", who);
+  if (prm->iterations < 0 || prm->num_levels < 0 || prm->num_levels > 30 || !(prm->tolerance >= 0))
+    return fail(PPF_ERR_INVALID, "%s: bad ICP parameters", who);
+  if (!have_device()) return fail(PPF_ERR_HIP, "%s: no HIP device (this engine has no CPU fallback)", who);
+  return PPF_OK;
+}
+
+/* Pose3D::appendPose: pose = incremental * pose, then q / t / angle from the new matrix */
+void icp_append_pose(ppf_pose* p, const double* inc, double residual) {
+  double out[16];
+  ppf_mat44_mul(inc, p->pose, out);
+  memcpy(p->pose, out, sizeof(out));
+  const double R[9] = {out[0], out[1], out[2], out[4], out[5], out[6], out[8], out[9], out[10]};
+  p->t[0] = out[3]; p->t[1] = out[7]; p->t[2] = out[11];
+  ppf_dcm_to_quat(R, p->q);
+  p->angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
+  p->residual = residual;
+}
+
+ppf_status icp_refine_device(const float* d_model, int n, int mstride, const float* d_scene, int nd, int sstride,
+                             const ppf_icp_params* prm, ppf_pose* poses, int n_poses, int* iters, hipStream_t st) {
+  IcpScratch sc;
+  for (int k = 0; k < n_poses; k++) {
+    double inc[16], res = 0;
+    int it = 0;
+    ppf_status s = icp_register(d_model, n, mstride, d_scene, nd, sstride, *prm, poses[k].pose, sc, st, inc, &res, &it);
+    if (s != PPF_OK) return s;
+    icp_append_pose(&poses[k], inc, res);
+    if (iters) iters[k] = it;
+  }
+  return PPF_OK;
+}
+
+ppf_status icp_upload(const float* h, int n, int stride, DevBuf<float>& d) {
+  HIPCHK(d.reserve((size_t)n * 6));
+  HIPCHK(hipMemcpy2D(d.p, 6 * sizeof(float), h, (size_t)stride * sizeof(float), 6 * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+  return PPF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ppf_default_icp_params(ppf_icp_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->iterations = 100; /* ICP icp(100, 0.005f, 2.5f, 8), CloudProcessing.h:465,518 */
+  p->tolerance = 0.005f;
+  p->rejection_scale = 2.5f;
+  p->num_levels = 8;
+}
+
+ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, const float* scene, int n_scene, int sstride,
+                          const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out) {
+  ppf_status s = icp_check("ppf_icp_refine", model, n_model, mstride, scene, n_scene, sstride, params);
+  if (s != PPF_OK) return s;
+  if (n_poses < 0 || (n_poses > 0 && !poses_io)) return fail(PPF_ERR_INVALID, "ppf_icp_refine: bad pose list");
+  DevBuf<float> dm, ds;
+  if ((s = icp_upload(model, n_model, mstride, dm)) != PPF_OK) return s;
+  if ((s = icp_upload(scene, n_scene, sstride, ds)) != PPF_OK) return s;
+  return icp_refine_device(dm.p, n_model, 6, ds.p, n_scene, 6, params, poses_io, n_poses, iterations_out, nullptr);
+}
+
+ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, const float* d_scene, int n_scene, int sstride,
+                                 const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out, void* stream) {
+  ppf_status s = icp_check("ppf_icp_refine_device", d_model, n_model, mstride, d_scene, n_scene, sstride, params);
+  if (s != PPF_OK) return s;
+  if (n_poses < 0 || (n_poses > 0 && !poses_io)) return fail(PPF_ERR_INVALID, "ppf_icp_refine_device: bad pose list");
+  return icp_refine_device(d_model, n_model, mstride, d_scene, n_scene, sstride, params, poses_io, n_poses, iterations_out,
+                           (hipStream_t)stream);
+}
+
+ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const float* dst, int n_dst, int dstride,
+                            const ppf_icp_params* params, double* pose16_out, double* residual_out, int* iterations_out) {
+  ppf_status s = icp_check("ppf_icp_register", src, n_src, sstride, dst, n_dst, dstride, params);
+  if (s != PPF_OK) return s;
+  if (!pose16_out) return fail(PPF_ERR_INVALID, "ppf_icp_register: pose16_out is NULL");
+  DevBuf<float> dsrc, ddst;
+  if ((s = icp_upload(src, n_src, sstride, dsrc)) != PPF_OK) return s;
+  if ((s = icp_upload(dst, n_dst, dstride, ddst)) != PPF_OK) return s;
+  IcpScratch sc;
+  return icp_register(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, sc, nullptr, pose16_out, residual_out, iterations_out);
 }
 
 }  // extern "C"

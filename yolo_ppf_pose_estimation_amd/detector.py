@@ -21,7 +21,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _capi
-from ._capi import MatchParams, MatchStats, ModelInfo, Pose, PPFError, TrainParams, Vote, check, lib
+from ._capi import IcpParams, MatchParams, MatchStats, ModelInfo, Pose, PPFError, TrainParams, Vote, check, lib
 
 
 class Pose3D:
@@ -306,3 +306,41 @@ def transformPCPose(pc: np.ndarray, pose: np.ndarray) -> np.ndarray:
     check(lib().ppf_transform_pc_pose(a.ctypes.data, a.shape[0], a.shape[1],
                                       T.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data))
     return out
+
+
+class ICP:
+    """cv::ppf_match_3d::ICP as the reference uses it right after the match
+    (``ICP icp(100, 0.005f, 2.5f, 8); icp.registerModelToScene(models[id], scene, resultsSub);``
+    /root/reference/include/CloudProcessing.h:465-470, :518-523): multi-level point-to-plane ICP with picky
+    correspondences and median+MAD rejection, on the device (ppf_icp_refine / ppf_icp_register)."""
+
+    def __init__(self, iterations: int = 100, tolerance: float = 0.005, rejectionScale: float = 2.5, numLevels: int = 8):
+        self._prm = IcpParams()
+        lib().ppf_default_icp_params(C.byref(self._prm))
+        self._prm.iterations, self._prm.tolerance = int(iterations), float(tolerance)
+        self._prm.rejection_scale, self._prm.num_levels = float(rejectionScale), int(numLevels)
+        self.last_iterations: List[int] = []
+
+    def registerModelToScene(self, srcPC: np.ndarray, dstPC: np.ndarray, poses: Optional[List[Pose3D]] = None):
+        """With ``poses``: refines every pose in place (pose <- poseICP * pose, residual set) and returns the list.
+        Without: registers src to dst from the identity and returns ``(residual, pose4x4)``."""
+        src, dst = _cloud(srcPC, "srcPC"), _cloud(dstPC, "dstPC")
+        if poses is None:
+            pose = (C.c_double * 16)()
+            res, it = C.c_double(0), C.c_int(0)
+            check(lib().ppf_icp_register(src.ctypes.data, src.shape[0], src.shape[1], dst.ctypes.data, dst.shape[0],
+                                         dst.shape[1], C.byref(self._prm), pose, C.byref(res), C.byref(it)))
+            self.last_iterations = [it.value]
+            return res.value, np.array(pose, dtype=np.float64).reshape(4, 4)
+        n = len(poses)
+        recs = (Pose * max(n, 1))()
+        for i, p in enumerate(poses):
+            recs[i] = p.to_record()
+        iters = (C.c_int * max(n, 1))()
+        check(lib().ppf_icp_refine(src.ctypes.data, src.shape[0], src.shape[1], dst.ctypes.data, dst.shape[0], dst.shape[1],
+                                   C.byref(self._prm), recs, n, iters))
+        self.last_iterations = [iters[i] for i in range(n)]
+        for i, p in enumerate(poses):
+            r = Pose3D(recs[i])
+            p.pose, p.q, p.t, p.angle, p.residual = r.pose, r.q, r.t, r.angle, r.residual
+        return poses
