@@ -5,7 +5,7 @@
  * against include/ppf_match_3d.hpp instead of <opencv2/surface_matching.hpp>.  Method bodies keep the
  * reference's structure line for line so the diff a maintainer has to make is visible:
  *   LoadSingleModel  CloudProcessing.h:209-221      TrainDetector  :222-261
- *   Matching         :428-480                       Matching_S2B   :481-533   (ICP step: see INTEGRATION.md)
+ *   Matching         :428-480                       Matching_S2B   :481-533   (with the ICP step, :518-523)
  * and main() follows src/YOLO_cropping_ppf_test.cpp:113-127.
  *
  *   usage: cloud_processor_demo model.ply scene.ply [edge.ply] [out.ply]
@@ -76,7 +76,11 @@ class CloudProcessor {
     size_t N = 5;
     if (results_size < N) N = results_size;
     vector<Pose3DPtr> resultsSub(results.begin(), results.begin() + N);
-    /* the reference refines resultsSub with ICP(100, 0.005f, 2.5f, 8) here (:518-523) */
+    ICP icp(100, 0.005f, 2.5f, 8); /* :518 */
+    auto t3 = chrono::steady_clock::now();
+    icp.registerModelToScene(models[id], scene, resultsSub);
+    auto t4 = chrono::steady_clock::now();
+    cout << endl << "ICP Elapsed Time " << chrono::duration<double>(t4 - t3).count() << " sec" << endl;
     return *resultsSub[0];
   }
 };
@@ -99,7 +103,8 @@ int main(int argc, char** argv) {
     result_pose.printPose();
     Mat pct = transformPCPose(bottle, result_pose.pose);
     if (argc > 4) writePLY(pct, argv[4]);
-    cout << "RESULT votes=" << result_pose.numVotes << " modelIndex=" << result_pose.modelIndex << endl;
+    cout.precision(17);
+    cout << "RESULT votes=" << result_pose.numVotes << " modelIndex=" << result_pose.modelIndex << " residual=" << result_pose.residual << endl;
   } catch (const Error& e) {
     cerr << "ppf error " << (int)e.status << ": " << e.what() << endl;
     return 10 + (int)e.status;

@@ -212,6 +212,58 @@ class PPF3DDetector {
   ppf_model* model_;
 };
 
+/* cv::ppf_match_3d::ICP as the reference constructs and calls it (CloudProcessing.h:465-470, :518-523):
+ *   ICP icp(100, 0.005f, 2.5f, 8);
+ *   icp.registerModelToScene(models[id], scene, resultsSub);      // refines every pose in place
+ * Uniform sampling and one correspondence per point (the library defaults, the only mode the reference uses). */
+class ICP {
+ public:
+  enum { ICP_SAMPLING_TYPE_UNIFORM = 0, ICP_SAMPLING_TYPE_GELFAND = 1 };
+  ICP() : ICP(250, 0.05f, 2.5f, 6) {} /* the library's default constructor values */
+  ICP(const int iterations, const float tolerence = 0.05f, const float rejectionScale = 2.5f, const int numLevels = 6,
+      const int sampleType = ICP_SAMPLING_TYPE_UNIFORM, const int numMaxCorr = 1) {
+    if (sampleType != ICP_SAMPLING_TYPE_UNIFORM || numMaxCorr != 1)
+      throw Error(PPF_ERR_INVALID, "ICP: only uniform sampling with one correspondence per point is implemented");
+    ppf_default_icp_params(&prm_);
+    prm_.iterations = iterations;
+    prm_.tolerance = tolerence;
+    prm_.rejection_scale = rejectionScale;
+    prm_.num_levels = numLevels;
+  }
+  virtual ~ICP() {}
+
+  /* one registration from the identity: returns 0, fills residual and the 4x4 src -> dst */
+  template <class M> int registerModelToScene(const M& srcPC, const M& dstPC, double& residual, Matx44d& pose) {
+    require_cloud(srcPC); require_cloud(dstPC);
+    check(ppf_icp_register(srcPC.template ptr<float>(0), srcPC.rows, srcPC.cols, dstPC.template ptr<float>(0), dstPC.rows, dstPC.cols,
+                           &prm_, pose.data(), &residual, nullptr));
+    return 0;
+  }
+  /* every pose: move the model by it, register to the scene, pose <- poseICP * pose, residual set */
+  template <class M> int registerModelToScene(const M& srcPC, const M& dstPC, std::vector<Pose3DPtr>& poses) {
+    require_cloud(srcPC); require_cloud(dstPC);
+    std::vector<ppf_pose> recs(poses.size());
+    for (size_t i = 0; i < poses.size(); i++) {
+      ppf_pose& r = recs[i];
+      const Pose3D& p = *poses[i];
+      std::memcpy(r.pose, p.pose.data(), sizeof(r.pose));
+      std::memcpy(r.q, p.q, sizeof(r.q));
+      std::memcpy(r.t, p.t, sizeof(r.t));
+      r.angle = p.angle; r.alpha = p.alpha; r.residual = p.residual; r.model_index = p.modelIndex; r.num_votes = p.numVotes;
+    }
+    check(ppf_icp_refine(srcPC.template ptr<float>(0), srcPC.rows, srcPC.cols, dstPC.template ptr<float>(0), dstPC.rows, dstPC.cols, &prm_,
+                         recs.data(), (int)recs.size(), nullptr));
+    for (size_t i = 0; i < poses.size(); i++) *poses[i] = Pose3D(recs[i]);
+    return 0;
+  }
+
+ private:
+  template <class M> static void require_cloud(const M& m) {
+    if (m.rows <= 0 || m.cols < 6) throw Error(PPF_ERR_INVALID, "ICP: expected an N x 6 float32 cloud (x y z nx ny nz)");
+  }
+  ppf_icp_params prm_;
+};
+
 /* ---- helpers the reference's driver takes from the same namespace ---------------------------------- */
 inline Mat loadPLYSimple(const char* fileName, int withNormals = 0) {
   std::ifstream ifs(fileName);

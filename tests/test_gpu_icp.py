@@ -121,6 +121,21 @@ def test_icp_after_match_improves_pose(bottle):
         assert p.residual == r
 
 
+def test_icp_reference_sized_case_bitwise(bottle):
+    """the sizes the reference runs: the full model (19,753 rows) against a 50,000-row crop, ICP(100, 0.005, 2.5, 8)
+    on the top poses of the match (CloudProcessing.h:456-470); first pose checked bit for bit against the oracle"""
+    scene, _ = synth.make_scene(bottle, n_points=50000, seed=12345)
+    det = PPF3DDetector(0.036, 0.05).trainModel(bottle)
+    poses = det.match(scene, 1.0 / 20.0, 0.05)[:5]
+    init = poses[0].pose.copy()
+    icp = ICP(100, 0.005, 2.5, 8)
+    icp.registerModelToScene(bottle, scene, poses)
+    want_P, want_r, want_i = O.icp_refine(bottle, scene, [init])
+    np.testing.assert_array_equal(poses[0].pose, want_P[0])
+    assert poses[0].residual == want_r[0] and icp.last_iterations[0] == want_i[0]
+    assert want_i[0] > 5 and want_r[0] < 0.01
+
+
 def test_icp_argument_errors(bottle):
     from yolo_ppf_pose_estimation_amd._capi import PPFError
     with pytest.raises(PPFError):
