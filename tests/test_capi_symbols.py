@@ -53,28 +53,21 @@ def test_defaults_mirror_the_reference_library():
     assert mp.position_threshold < 0 and mp.rotation_threshold < 0 and mp.ref_stride == 1
 
 
-def test_host_helpers_match_the_oracle(bottle):
-    from yolo_ppf_pose_estimation_amd.detector import samplePCByQuantization, transformPCPose
-    from yolo_ppf_pose_estimation_amd.ply import transform_pc_pose
-    for step in (0.05, 0.0714, 0.036):
-        np.testing.assert_array_equal(samplePCByQuantization(bottle, step), O.sample(bottle, step))
-    # pcl::PointNormal-like pitch (12 floats per row) gives the same result as the packed Mat layout
-    wide = np.zeros((bottle.shape[0], 12), np.float32)
-    wide[:, :6] = bottle
-    np.testing.assert_array_equal(samplePCByQuantization(wide, 0.05), O.sample(bottle, 0.05))
-    T = np.eye(4); T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]; T[:3, 3] = [0.1, -0.2, 0.3]
-    np.testing.assert_allclose(transformPCPose(bottle[:100], T), transform_pc_pose(bottle[:100], T), atol=1e-6)
-
-
 def test_errors_without_a_device_are_loud(bottle):
     """No CPU fallback: on a box without a GPU every compute entry point reports PPF_ERR_HIP."""
     if lib().ppf_device_count() > 0:
         pytest.skip("a GPU is present")
-    from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
-    with pytest.raises(_capi.PPFError) as e:
-        PPF3DDetector(0.05, 0.05).trainModel(bottle)
-    assert e.value.status == _capi.PPF_ERR_HIP
-    assert "no HIP device" in str(e.value)
+    from yolo_ppf_pose_estimation_amd.detector import ICP, PPF3DDetector, samplePCByQuantization, transformPCPose
+    calls = [lambda: PPF3DDetector(0.05, 0.05).trainModel(bottle),
+             lambda: samplePCByQuantization(bottle, 0.05),
+             lambda: transformPCPose(bottle[:10], np.eye(4)),
+             lambda: ICP().registerModelToScene(bottle[:100], bottle[:100]),
+             lambda: ICP().registerModelToScene(bottle[:100], bottle[:100], [])]
+    for call in calls:
+        with pytest.raises(_capi.PPFError) as e:
+            call()
+        assert e.value.status == _capi.PPF_ERR_HIP
+        assert "no HIP device" in str(e.value)
 
 
 def test_argument_validation_precedes_any_device_work(bottle):

@@ -187,3 +187,19 @@ def test_device_sampling_matches_oracle_on_large_clouds(bottle):
                      cluster=False)
     assert got["stats"]["n_scene_sampled"] == want["sampled_scene"].shape[0]
     np.testing.assert_array_equal(got["triples"], want["triples"])
+
+
+def test_edge_helpers_match_the_oracle(bottle):
+    """ppf_sample_cloud / ppf_transform_pc_pose (device kernels behind host-pointer entries) against the oracle's
+    samplePCByQuantization and the numpy transformPCPose of yolo_ppf_pose_estimation_amd/ply.py"""
+    from yolo_ppf_pose_estimation_amd.detector import transformPCPose
+    from yolo_ppf_pose_estimation_amd.ply import transform_pc_pose
+    for step in (0.05, 0.0714, 0.036):
+        np.testing.assert_array_equal(samplePCByQuantization(bottle, step), O.sample(bottle, step))
+    # pcl::PointNormal-like pitch (12 floats per row) gives the same result as the packed Mat layout
+    wide = np.zeros((bottle.shape[0], 12), np.float32)
+    wide[:, :6] = bottle
+    np.testing.assert_array_equal(samplePCByQuantization(wide, 0.05), O.sample(bottle, 0.05))
+    T = np.eye(4); T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]; T[:3, 3] = [0.1, -0.2, 0.3]
+    np.testing.assert_allclose(transformPCPose(bottle[:100], T), transform_pc_pose(bottle[:100], T), atol=1e-6)
+    np.testing.assert_allclose(transformPCPose(wide[:100], T), transform_pc_pose(bottle[:100], T), atol=1e-6)

@@ -686,46 +686,6 @@ void bbox_host(const float* pc, int n, int stride, float lo[3], float hi[3]) {
     }
 }
 
-/* Row A2 (samplePCByQuantization + computeBboxStd) on the host: cell index in float arithmetic,
- * cells emitted in ascending index order, per-cell fp64 sums taken in ascending point order.
- * Implemented as a stable sort of point indices by cell.  Host helper behind ppf_sample_cloud only; trainModel
- * and match use the device version (ppf_sample_kernels.h). */
-std::vector<float> sample_cloud_host(const float* pc, int n, int stride, float step) {
-  float lo[3], hi[3];
-  bbox_host(pc, n, stride, lo, hi);
-  const int ns = (int)(1.0 / step);
-  const float rg[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-  std::vector<std::pair<int, int>> key((size_t)n);
-  for (int i = 0; i < n; i++) {
-    const float* p = pc + (size_t)i * stride;
-    int c[3];
-    for (int k = 0; k < 3; k++) c[k] = rg[k] > 0.0f ? ppf_f2i((float)ns * (p[k] - lo[k]) / rg[k]) : 0;
-    key[i] = {c[0] * ns * ns + c[1] * ns + c[2], i};
-  }
-  std::sort(key.begin(), key.end());
-  std::vector<float> out;
-  size_t s = 0;
-  while (s < key.size()) {
-    size_t e = s;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    while (e < key.size() && key[e].first == key[s].first) {
-      const float* p = pc + (size_t)key[e].second * stride;
-      for (int k = 0; k < 6; k++) acc[k] += (double)p[k];
-      e++;
-    }
-    const double cn = (double)(e - s);
-    for (int k = 0; k < 6; k++) acc[k] /= cn;
-    float row[6] = {(float)acc[0], (float)acc[1], (float)acc[2], 0.f, 0.f, 0.f};
-    const double norm = std::sqrt(acc[3] * acc[3] + acc[4] * acc[4] + acc[5] * acc[5]);
-    if (norm > PPF_EPS) {
-      row[3] = (float)(acc[3] / norm); row[4] = (float)(acc[4] / norm); row[5] = (float)(acc[5] / norm);
-    }
-    out.insert(out.end(), row, row + 6);
-    s = e;
-  }
-  return out;
-}
-
 bool have_device() {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -981,37 +941,6 @@ int ppf_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
-
-ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
-                            int* n_out) {
-  if (!xyzn || n <= 0 || stride < 6 || !(relative_step > 0)) return fail(PPF_ERR_INVALID, "ppf_sample_cloud: bad argument");
-  std::vector<float> s = sample_cloud_host(xyzn, n, stride, (float)relative_step);
-  const int rows = (int)(s.size() / 6);
-  if (n_out) *n_out = rows;
-  if (out) {
-    if (cap_rows < rows) return fail(PPF_ERR_CAPACITY, "ppf_sample_cloud: need %d rows, have %d", rows, cap_rows);
-    memcpy(out, s.data(), s.size() * sizeof(float));
-  }
-  return PPF_OK;
-}
-
-ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* T, float* out) {
-  if (!xyzn || !T || !out || n < 0 || stride < 6) return fail(PPF_ERR_INVALID, "ppf_transform_pc_pose: bad argument");
-  for (int i = 0; i < n; i++) {
-    const float* p = xyzn + (size_t)i * stride;
-    float* o = out + (size_t)i * 6;
-    double v[4];
-    for (int r = 0; r < 4; r++) v[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
-    if (std::fabs(v[3]) > PPF_EPS) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
-    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2];
-    double nn[3];
-    for (int r = 0; r < 3; r++) nn[r] = T[r * 4] * p[3] + T[r * 4 + 1] * p[4] + T[r * 4 + 2] * p[5];
-    const double nrm = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-    if (nrm > PPF_EPS) { nn[0] /= nrm; nn[1] /= nrm; nn[2] /= nrm; }
-    o[3] = (float)nn[0]; o[4] = (float)nn[1]; o[5] = (float)nn[2];
-  }
-  return PPF_OK;
 }
 
 /* ---- model ------------------------------------------------------------------------------------ */
@@ -1924,6 +1853,44 @@ ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const floa
   if ((s = icp_upload(dst, n_dst, dstride, ddst)) != PPF_OK) return s;
   IcpScratch sc;
   return icp_register(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, sc, nullptr, pose16_out, residual_out, iterations_out);
+}
+
+/* ---- helpers on the path's edges, on the device like everything else ---------------------------------------- */
+ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
+                            int* n_out) {
+  if (!xyzn || n <= 0 || stride < 6 || !(relative_step > 0)) return fail(PPF_ERR_INVALID, "ppf_sample_cloud: bad argument");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_sample_cloud: no HIP device (this engine has no CPU fallback)");
+  DevBuf<float> d_raw;
+  HIPCHK(d_raw.reserve((size_t)n * stride));
+  HIPCHK(hipMemcpy(d_raw.p, xyzn, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
+  CloudDev sampled;
+  std::vector<float> rows_host;
+  ppf_status s = device_sample_cloud(d_raw.p, n, stride, (float)relative_step, sampled, &rows_host, nullptr);
+  if (s != PPF_OK) return s;
+  const int rows = (int)(rows_host.size() / 6);
+  if (n_out) *n_out = rows;
+  if (out) {
+    if (cap_rows < rows) return fail(PPF_ERR_CAPACITY, "ppf_sample_cloud: need %d rows, have %d", rows, cap_rows);
+    memcpy(out, rows_host.data(), rows_host.size() * sizeof(float));
+  }
+  return PPF_OK;
+}
+
+ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* T, float* out) {
+  if (!xyzn || !T || !out || n < 0 || stride < 6) return fail(PPF_ERR_INVALID, "ppf_transform_pc_pose: bad argument");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_transform_pc_pose: no HIP device (this engine has no CPU fallback)");
+  if (n == 0) return PPF_OK;
+  DevBuf<float> d_in, d_out;
+  DevBuf<double> d_T;
+  ppf_status s = icp_upload(xyzn, n, stride, d_in);
+  if (s != PPF_OK) return s;
+  HIPCHK(d_out.reserve((size_t)n * 6));
+  HIPCHK(d_T.reserve(16));
+  HIPCHK(hipMemcpy(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice));
+  k_icp_transform<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_in.p, 6, 1, n, d_T.p, d_out.p, nullptr, nullptr, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  return PPF_OK;
 }
 
 }  // extern "C"
