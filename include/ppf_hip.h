@@ -27,6 +27,9 @@
  *   ppf_icp_refine (+_device)       ICP icp(100, 0.005f, 2.5f, 8); icp.registerModelToScene(model, scene, poses)
  *                                   CloudProcessing.h:465-470 (Matching), :518-523 (Matching_S2B)
  *   ppf_icp_register                ICP::registerModelToScene(src, dst, residual, pose), the single-pose overload
+ *   ppf_prep_crop / _voxel_grid /   CloudProcessor::SceneCropping :263, Subsampling :361, OutlierProcessing :341,
+ *   _outlier_removal / _normals /   NormalEstimation :381, EdgeExtraction :406, PointCloudXYZNormalToMat :163
+ *   _edges / _to_mat (+ppf_cloud_*) (the PCL stages that produce the matcher's input)
  *
  * Conventions
  *   - Clouds are float32 rows `x y z nx ny nz` (the N x 6 CV_32FC1 Mat that
@@ -67,6 +70,7 @@ typedef enum ppf_status {
 
 typedef struct ppf_model ppf_model;         /* opaque, ref-counted, device-resident model table */
 typedef struct ppf_workspace ppf_workspace; /* opaque per-caller scratch + result buffers */
+typedef struct ppf_cloud ppf_cloud;         /* opaque device-resident cloud: rows x y z nx ny nz + curvature */
 
 typedef struct ppf_train_params {
   double relative_sampling_step;  /* PPF3DDetector ctor arg 1 (reference: 0.025, CloudProcessing.h:64) */
@@ -235,6 +239,33 @@ ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride,
 /* registerModelToScene(src, dst, residual, pose): one registration without an initial pose */
 ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const float* dst, int n_dst, int dstride,
                             const ppf_icp_params* params, double* pose16_out, double* residual_out, int* iterations_out);
+
+/* ---- the producers of the N x 6 input (CloudProcessing.h:263-427), device-resident between stages ---------- */
+/* cols = 3 (xyz; normals zero) or 6 (xyz + normal) floats per row, `stride` floats between rows */
+ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int cols, ppf_cloud** out);
+ppf_status ppf_cloud_release(ppf_cloud* c);
+ppf_status ppf_cloud_size(const ppf_cloud* c, int* n);
+/* rows6: n x 6 floats, curvature: n floats; either may be NULL */
+ppf_status ppf_cloud_download(const ppf_cloud* c, float* rows6, float* curvature, int cap_rows);
+/* device pointer to the packed n x 6 rows (valid while the cloud lives): feeds ppf_match_device / ppf_icp_refine_device */
+ppf_status ppf_cloud_device_rows(const ppf_cloud* c, const float** d_rows6, int* n);
+/* SceneCropping (:263-339) for one box {x, y, width, height}: +-30 px, mean corner depth, corners pushed 0.15 m back,
+ * points inside the pyramid {camera centre, 4 corners} are kept.  depth: HOST image (rows x cols float, metres),
+ * intr = {fx, fy, ppx, ppy}. */
+ppf_status ppf_prep_crop(const ppf_cloud* in, const int* box_xywh, const float* depth, int depth_rows, int depth_cols,
+                         const double* intr, ppf_cloud** out);
+/* Subsampling (:361-380): pcl::VoxelGrid, cubic leaf */
+ppf_status ppf_prep_voxel_grid(const ppf_cloud* in, double leaf, ppf_cloud** out);
+/* OutlierProcessing (:341-360): pcl::StatisticalOutlierRemoval(meanK, stddevMul) */
+ppf_status ppf_prep_outlier_removal(const ppf_cloud* in, int mean_k, double stddev_mul, ppf_cloud** out);
+/* NormalEstimation (:381-405): k-neighbour plane fit, normals towards the camera centre, curvature */
+ppf_status ppf_prep_normals(const ppf_cloud* in, int k, ppf_cloud** out);
+/* EdgeExtraction (:406-427): curvature > threshold */
+ppf_status ppf_prep_edges(const ppf_cloud* in, float curvature_threshold, ppf_cloud** out);
+/* PointCloudXYZNormalToMat (:163-190): rows with re-normalised normals */
+ppf_status ppf_prep_to_mat(const ppf_cloud* in, ppf_cloud** out);
+/* exact neighbour lists (parity surface): idx, d2 are [n][k], ascending (distance, index) */
+ppf_status ppf_prep_knn(const ppf_cloud* in, int k, int* idx, float* d2);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,7 @@ class OraclePose(C.Structure):
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(ORACLE_DIR, "ppf_oracle.cpp"), os.path.join(ORACLE_DIR, "ppf_icp_oracle.cpp"),
+            os.path.join(ORACLE_DIR, "ppf_prep_oracle.cpp"),
             os.path.join(ROOT, "include", "ppf_detmath.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in srcs
@@ -89,6 +90,15 @@ def lib():
         L.oracle_icp_refine.restype = C.c_int
         L.oracle_icp_refine.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+        ip = C.POINTER(C.c_int)
+        L.oracle_prep_crop.argtypes = [fp, C.c_int, C.c_int, ip, fp, C.c_int, C.c_int, C.POINTER(C.c_double), ip, ip,
+                                       C.POINTER(C.c_double)]
+        L.oracle_prep_voxel.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, ip]
+        L.oracle_prep_knn.argtypes = [fp, C.c_int, C.c_int, C.c_int, ip, fp]
+        L.oracle_prep_sor.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_ubyte), fp,
+                                      C.POINTER(C.c_double)]
+        L.oracle_prep_normals.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, fp]
+        L.oracle_prep_to_mat.argtypes = [fp, fp, C.c_int, fp]
         _lib = L
     return _lib
 
@@ -313,3 +323,70 @@ def icp_refine(model, scene, poses, iterations=100, tolerance=0.005, rejection_s
     lib().oracle_icp_refine(mp, m.shape[0], sp, s.shape[0], int(iterations), float(tolerance), float(rejection_scale),
                             int(num_levels), _f64p(P), _f64p(res), P.shape[0], its.ctypes.data_as(C.POINTER(C.c_int)))
     return P.reshape(-1, 4, 4), res, its
+
+
+# ---- pre-processing stages (oracle/ppf_prep_oracle.cpp) ------------------------------------------------------------
+def _xyz(cloud):
+    a = np.ascontiguousarray(np.asarray(cloud, dtype=np.float32))
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def prep_crop(cloud, box, depth, intr):
+    """SceneCropping for one box = (x, y, w, h); intr = (fx, fy, ppx, ppy).  Returns (kept indices, planes(13,))."""
+    a, ap = _xyz(cloud)
+    d = np.ascontiguousarray(depth, dtype=np.float32)
+    bx = (C.c_int * 4)(*[int(v) for v in box])
+    it = (C.c_double * 4)(*[float(v) for v in intr])
+    keep = np.zeros(a.shape[0], dtype=np.int32)
+    n = C.c_int(0)
+    planes = (C.c_double * 13)()
+    lib().oracle_prep_crop(ap, a.shape[0], a.shape[1], bx, d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], d.shape[1], it,
+                           keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n), planes)
+    return keep[: n.value].copy(), np.array(planes)
+
+
+def prep_voxel(cloud, leaf):
+    a, ap = _xyz(cloud)
+    out = np.zeros((a.shape[0], 3), dtype=np.float32)
+    n = C.c_int(0)
+    rc = lib().oracle_prep_voxel(ap, a.shape[0], a.shape[1], float(leaf), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n))
+    if rc:
+        raise ValueError("leaf size too small")
+    return out[: n.value].copy()
+
+
+def prep_knn(cloud, k):
+    a, ap = _xyz(cloud)
+    idx = np.zeros((a.shape[0], k), dtype=np.int32)
+    d2 = np.zeros((a.shape[0], k), dtype=np.float32)
+    lib().oracle_prep_knn(ap, a.shape[0], a.shape[1], int(k), idx.ctypes.data_as(C.POINTER(C.c_int)),
+                          d2.ctypes.data_as(C.POINTER(C.c_float)))
+    return idx, d2
+
+
+def prep_sor(cloud, mean_k=50, std_mul=1.5):
+    """StatisticalOutlierRemoval: returns (keep mask, mean neighbour distances, threshold)."""
+    a, ap = _xyz(cloud)
+    keep = np.zeros(a.shape[0], dtype=np.uint8)
+    dist = np.zeros(a.shape[0], dtype=np.float32)
+    thr = C.c_double(0)
+    lib().oracle_prep_sor(ap, a.shape[0], a.shape[1], int(mean_k), float(std_mul), keep.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                          dist.ctypes.data_as(C.POINTER(C.c_float)), C.byref(thr))
+    return keep.astype(bool), dist, thr.value
+
+
+def prep_normals(cloud, k=30):
+    a, ap = _xyz(cloud)
+    nrm = np.zeros((a.shape[0], 3), dtype=np.float32)
+    curv = np.zeros(a.shape[0], dtype=np.float32)
+    lib().oracle_prep_normals(ap, a.shape[0], a.shape[1], int(k), nrm.ctypes.data_as(C.POINTER(C.c_float)),
+                              curv.ctypes.data_as(C.POINTER(C.c_float)))
+    return nrm, curv
+
+
+def prep_to_mat(xyz, normals):
+    a, ap = _xyz(np.asarray(xyz)[:, :3])
+    b, bp = _xyz(normals)
+    out = np.zeros((a.shape[0], 6), dtype=np.float32)
+    lib().oracle_prep_to_mat(ap, bp, a.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out

@@ -110,6 +110,19 @@ _SIGNATURES = {
                                  C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_icp_refine_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
                                         C.POINTER(Pose), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "ppf_cloud_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ppf_cloud_release": (C.c_int, [C.c_void_p]),
+    "ppf_cloud_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "ppf_cloud_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ppf_cloud_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "ppf_prep_crop": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                C.POINTER(C.c_void_p)]),
+    "ppf_prep_voxel_grid": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "ppf_prep_outlier_removal": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),
+    "ppf_prep_normals": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ppf_prep_edges": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "ppf_prep_to_mat": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ppf_prep_knn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ppf_icp_register": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
