@@ -89,3 +89,46 @@ def test_pcl_shaped_facade_runs(tmp_path, bottle):
     det.setSearchParams(float(np.float32(0.05)), float(np.float32(30.0 / 180.0 * 3.14159265)))
     poses = det.match(scene, 1.0 / 20.0, 0.05, presampled=True)
     assert votes == poses[0].numVotes
+
+
+def test_stage_wrapper_compiles_and_fails_loudly_without_gpu(tmp_path, bottle):
+    exe = _build(tmp_path, "cloud_stages_demo")
+    if _capi.lib().ppf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = str(tmp_path / "model.ply")
+    ply.write_ply(bottle[::40], m)
+    s = str(tmp_path / "scene.ply")
+    ply.write_ply(bottle[::40, :3], s)
+    d = str(tmp_path / "depth.f32")
+    np.zeros((8, 8), np.float32).tofile(d)
+    r = subprocess.run([exe, m, s, d, "8", "8", "1", "1", "2", "2", "10", "10", "4", "4", "0.01", "1.0"],
+                       capture_output=True, text=True)
+    assert r.returncode == 10 + _capi.PPF_ERR_HIP
+    assert "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_stage_wrapper_runs_the_drivers_sequence_on_the_real_frame(tmp_path, bottle):
+    """examples/cloud_stages_demo.cpp (C++ wrapper of the stages + detector + ICP) on the reference's depth frame
+    gives the counts and the refined residual of the Python mirror of the same sequence"""
+    import prep_data as D
+    from yolo_ppf_pose_estimation_amd.cloud_processor import DeviceCloud
+    from yolo_ppf_pose_estimation_amd.detector import ICP, PPF3DDetector
+    exe = _build(tmp_path, "cloud_stages_demo")
+    xyz, depth, box, intr = D.c1_frame()
+    xyz = xyz[::3].copy()                      # keep the ASCII PLY small
+    m, s, d = str(tmp_path / "model.ply"), str(tmp_path / "scene.ply"), str(tmp_path / "depth.f32")
+    ply.write_ply(bottle, m)
+    ply.write_ply(xyz, s)
+    depth.tofile(d)
+    args = [exe, m, s, d, str(depth.shape[0]), str(depth.shape[1])] + [str(v) for v in box] + [repr(v) for v in intr] + ["0.004", "1.0"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    res = dict(kv.split("=") for kv in r.stdout.split("RESULT ")[1].split())
+    obj = DeviceCloud.upload(xyz).crop(box, depth, intr).voxel_grid(0.004).outlier_removal(50, 1.0).normals(30)
+    obj_mat, edge_mat = obj.to_mat().rows(), obj.edges(0.03).to_mat().rows()
+    assert (int(res["object"]), int(res["edges"])) == (obj_mat.shape[0], edge_mat.shape[0])
+    poses = PPF3DDetector(0.05, 0.05).trainModel(ply.load_ply_simple(m)).match_S2B(obj_mat, edge_mat, 0.05, 0.05)[:5]
+    ICP(100, 0.005, 2.5, 8).registerModelToScene(ply.load_ply_simple(m), obj_mat, poses)
+    assert int(res["votes"]) == poses[0].numVotes
+    assert float(res["residual"]) == poses[0].residual
