@@ -1963,7 +1963,7 @@ ppf_status prep_check(const char* who, const ppf_cloud* in, ppf_cloud** out) {
   return PPF_OK;
 }
 
-/* exact kNN lists of every point of the cloud: idx/d2 are [n][k], k <= min(n, KNN_MAX_K) */
+/* exact kNN lists of every point of the cloud: idx/d2 are [n][k], k <= min(n, KNN_MAX_K); q4 = xyz by original row */
 ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>& idx, DevBuf<float>& d2) {
   const int n = in->n;
   HIPCHK(q4.reserve((size_t)n));
@@ -1972,8 +1972,49 @@ ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>
   DevBuf<float> scratch;
   HIPCHK(scratch.reserve((size_t)n * 6));
   k_icp_sample<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, 6, 1, n, scratch.p, q4.p);
-  const size_t lds = (size_t)KNN_BLOCK * k * 8;
-  k_prep_knn<<<grid_for(n, KNN_BLOCK), dim3(KNN_BLOCK), lds>>>(q4.p, n, k, idx.p, d2.p);
+  /* grid over the bounding box: about sqrt(n)/6 cells along the longest side (a 3x3x3 cube of a surface-like cloud
+   * then holds a few hundred points), at most 128 */
+  DevBuf<uint32_t> mm;
+  HIPCHK(mm.reserve(6));
+  const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  HIPCHK(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
+  k_prep_minmax<<<dim3(std::min<unsigned>((unsigned)((n + 255) / 256), 2048u)), dim3(256)>>>(in->rows.p, n, mm.p);
+  HIPCHK(hipGetLastError());
+  uint32_t h_mm[6];
+  HIPCHK(hipMemcpy(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost));
+  KnnGrid g;
+  float ext_max = 0.f;
+  for (int a = 0; a < 3; a++) {
+    const float lo = ordered_to_float(h_mm[a]), hi = ordered_to_float(h_mm[3 + a]);
+    if (!std::isfinite(lo) || !std::isfinite(hi))
+      return fail(PPF_ERR_INVALID, "neighbour search: the cloud holds non-finite points (crop or voxel-grid it first)");
+    g.lo[a] = lo;
+    ext_max = std::max(ext_max, hi - lo);
+  }
+  const int G = std::max(1, std::min(128, (int)(std::sqrt((double)n) / 6.0)));
+  g.h = ext_max > 0.f ? ext_max / (float)G : 1.0f;
+  g.inv_h = 1.0f / g.h;
+  size_t cells = 1;
+  for (int a = 0; a < 3; a++) {
+    const float hi = ordered_to_float(h_mm[3 + a]);
+    g.dim[a] = std::max(1, std::min(G + 1, (int)std::floor((hi - g.lo[a]) * g.inv_h) + 1));
+    cells *= (size_t)g.dim[a];
+  }
+  DevBuf<uint32_t> keys, vals, keys2, vals2, starts, cell_count, cell_begin;
+  HIPCHK(keys.reserve(n)); HIPCHK(vals.reserve(n)); HIPCHK(keys2.reserve(n)); HIPCHK(vals2.reserve(n));
+  HIPCHK(cell_count.reserve(cells + 1)); HIPCHK(cell_begin.reserve(cells + 1));
+  HIPCHK(hipMemset(cell_count.p, 0, (cells + 1) * sizeof(uint32_t)));
+  k_prep_knn_keys<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, n, g, keys.p, vals.p, cell_count.p);
+  HIPCHK(hipGetLastError());
+  ppf_status s = device_exclusive_scan(cell_count.p, cell_begin.p, cells + 1, nullptr);
+  if (s != PPF_OK) return s;
+  uint32_t n_runs = 0;
+  uint32_t* order = nullptr;
+  if ((s = sort_segments(keys, vals, keys2, vals2, n, (unsigned long long)cells, starts, &order, &n_runs, nullptr)) != PPF_OK) return s;
+  DevBuf<float4> pts;
+  HIPCHK(pts.reserve((size_t)n));
+  k_prep_knn_pack<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, order, n, pts.p);
+  k_prep_knn<<<grid_for(n, KNN_WAVES), dim3(KNN_WAVES * 64)>>>(pts.p, cell_begin.p, g, n, k, idx.p, d2.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   return PPF_OK;

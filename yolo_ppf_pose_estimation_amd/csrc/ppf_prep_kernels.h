@@ -8,18 +8,18 @@
  *   crop / outlier / edge : per-point predicate -> flags -> exclusive scan -> ordered gather (HBM streaming, 28 B/pt)
  *   voxel grid            : finite min/max -> PCL's cell index -> stable LSD radix sort (shared with the sampler) ->
  *                           one thread per cell, float sums in point order
- *   k nearest neighbours  : exhaustive; one thread per query keeps its k best (distance, index) sorted in LDS
- *                           (column layout: element m of lane t at [m][t], so equal-m accesses are conflict-free),
- *                           candidates arrive in index order through wave-uniform scalar loads.  VALU-bound:
- *                           n^2 distance evaluations, insertion only when a candidate beats the current k-th.
+ *   k nearest neighbours  : uniform grid (cells sorted by the same radix sort), ONE WAVE per query, cube of cells
+ *                           grown until the k-th distance is provably final; the k <= 64 best (distance bits, index)
+ *                           keys live one per lane and 64 candidates at a time are merged in by a register bitonic
+ *                           network.  Exact: equals the oracle's exhaustive search bit for bit.
  *   normals               : one thread per point, fp64 two-pass covariance over its neighbour list, cyclic Jacobi in
  *                           registers (12 sweeps, + - * / sqrt only), smallest eigenvector, flip towards the origin.
  */
 #ifndef PPF_PREP_KERNELS_H
 #define PPF_PREP_KERNELS_H
 
-constexpr int KNN_BLOCK = 64;
-constexpr int KNN_MAX_K = 64; /* LDS: KNN_BLOCK * k * 8 bytes */
+constexpr int KNN_WAVES = 4;  /* queries (waves) per workgroup */
+constexpr int KNN_MAX_K = 64; /* the k best keys live one per lane */
 
 struct CropPlanes {
   double n[4][3]; /* inward normals of the four side planes through the origin */
@@ -128,42 +128,106 @@ __global__ __launch_bounds__(64) void k_prep_voxel_sum(const float* __restrict__
 }
 
 /* ---- exact k nearest neighbours ----------------------------------------------------------------------------- */
-/* idx/d2: [n][k], ascending (d2, index).  q4 = packed xyz of the same cloud.  Dynamic LDS: KNN_BLOCK*k*8 bytes. */
-__global__ __launch_bounds__(KNN_BLOCK) void k_prep_knn(const float4* __restrict__ q4, int n, int k, int* __restrict__ idx_out,
-                                                        float* __restrict__ d2_out) {
-  extern __shared__ float knn_lds[];
-  float* ds = knn_lds;                               /* [k][KNN_BLOCK] */
-  int* is = (int*)(knn_lds + (size_t)k * KNN_BLOCK); /* [k][KNN_BLOCK] */
-  const int t = threadIdx.x;
-  const int i = blockIdx.x * KNN_BLOCK + t;
-  for (int m = 0; m < k; m++) { ds[m * KNN_BLOCK + t] = __builtin_inff(); is[m * KNN_BLOCK + t] = -1; }
-  float px = 0.f, py = 0.f, pz = 0.f;
-  if (i < n) { const float4 p = q4[i]; px = p.x; py = p.y; pz = p.z; }
-  float worst = __builtin_inff();
-  for (int j = 0; j < n; j++) {
-    const float4 q = q4[j]; /* wave-uniform: scalar load */
-    const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-    const float d = (dx * dx + dy * dy) + dz * dz;
-    if (d < worst) {
-      int m = k - 1;
-      while (m > 0) {
-        const float prev = ds[(m - 1) * KNN_BLOCK + t];
-        if (!(prev > d)) break;
-        ds[m * KNN_BLOCK + t] = prev;
-        is[m * KNN_BLOCK + t] = is[(m - 1) * KNN_BLOCK + t];
-        m--;
+/* Uniform grid over the cloud's bounding box; points sorted by cell (x fastest).  A query scans the cube of cells of
+ * radius r around its own cell and keeps its k best keys (float d2 bits << 32 | original index: d2 >= +0, so the
+ * u64 order IS (distance, index) order, independent of the scan order).  Every point
+ * outside that cube is farther than r*h, so the list is final once its k-th distance is within (0.9999 r h)^2 (the
+ * margin covers the float rounding of the cell assignment); otherwise the cube grows.  When the cube covers the whole
+ * grid the search has been exhaustive.  Results equal the oracle's brute force bit for bit. */
+struct KnnGrid {
+  float lo[3];
+  float inv_h, h;
+  int dim[3];
+};
+__device__ __forceinline__ void knn_cell(const KnnGrid& g, float x, float y, float z, int* c) {
+  c[0] = min(max(ppf_f2i(floorf((x - g.lo[0]) * g.inv_h)), 0), g.dim[0] - 1);
+  c[1] = min(max(ppf_f2i(floorf((y - g.lo[1]) * g.inv_h)), 0), g.dim[1] - 1);
+  c[2] = min(max(ppf_f2i(floorf((z - g.lo[2]) * g.inv_h)), 0), g.dim[2] - 1);
+}
+__global__ __launch_bounds__(256) void k_prep_knn_keys(const float* __restrict__ rows, int n, KnnGrid g, uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c[3];
+  knn_cell(g, rows[(size_t)i * 6], rows[(size_t)i * 6 + 1], rows[(size_t)i * 6 + 2], c);
+  const uint32_t key = (uint32_t)((c[2] * g.dim[1] + c[1]) * g.dim[0] + c[0]);
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+  atomicAdd(&cell_count[key], 1u);
+}
+/* pts[s] = xyz of the s-th point in cell order, w = its original index */
+__global__ __launch_bounds__(256) void k_prep_knn_pack(const float* __restrict__ rows, const uint32_t* __restrict__ order, int n,
+                                                       float4* __restrict__ pts) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t i = order[s];
+  pts[s] = make_float4(rows[(size_t)i * 6], rows[(size_t)i * 6 + 1], rows[(size_t)i * 6 + 2], __uint_as_float(i));
+}
+/* bitonic compare-exchange across lanes */
+__device__ __forceinline__ unsigned long long knn_cex(unsigned long long key, int stride, bool take_min) {
+  const unsigned long long other = __shfl_xor(key, stride);
+  return take_min ? (key < other ? key : other) : (key < other ? other : key);
+}
+/* ONE WAVE PER QUERY.  idx/d2: [n][k] at the ORIGINAL row of each point, ascending (d2, index); k <= 64.
+ * The wave reads 64 candidates per step (coalesced within a row of cells); its current k best keys live one per
+ * lane, ascending by lane (lanes >= k hold the sentinel).  A step whose candidates all fail the k-th key costs one
+ * ballot; otherwise the 64 new keys are bitonic-sorted across the lanes (21 exchanges) and merged with the list
+ * (reverse + min = the 64 smallest of both as a bitonic sequence, 6 more exchanges).  No LDS. */
+__global__ __launch_bounds__(256) void k_prep_knn(const float4* __restrict__ pts, const uint32_t* __restrict__ cell_begin, KnnGrid g,
+                                                  int n, int k, int* __restrict__ idx_out, float* __restrict__ d2_out) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); /* wave-uniform */
+  if (s >= n) return;
+  const float4 p = pts[s];
+  int c[3];
+  knn_cell(g, p.x, p.y, p.z, c);
+  const unsigned long long none = ~0ull;
+  unsigned long long best;
+  for (int r = 1;; r++) {
+    best = none;
+    unsigned long long worst = none; /* the k-th key, wave-uniform */
+    const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+    const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+    const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+    for (int cz = z0; cz <= z1; cz++)
+      for (int cy = y0; cy <= y1; cy++) {
+        const int base = (cz * g.dim[1] + cy) * g.dim[0];
+        const uint32_t jb = cell_begin[base + x0], je = cell_begin[base + x1 + 1];
+        for (uint32_t j0 = jb; j0 < je; j0 += 64) {
+          const uint32_t j = j0 + (uint32_t)lane;
+          unsigned long long key = none;
+          if (j < je) {
+            const float4 q = pts[j];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d >= 0.f) key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(q.w); /* drops NaN */
+          }
+          if (!__any(key < worst)) continue;
+          /* sort the 64 new keys ascending by lane */
+#pragma unroll
+          for (int size = 2; size <= 64; size <<= 1) {
+            const bool up = (lane & size) == 0 || size == 64;
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) key = knn_cex(key, stride, ((lane & stride) == 0) == up);
+          }
+          /* the 64 smallest of (best, key): best ascending, key reversed -> elementwise min is bitonic */
+          const unsigned long long rev = __shfl(key, 63 - lane);
+          best = best < rev ? best : rev;
+#pragma unroll
+          for (int stride = 32; stride > 0; stride >>= 1) best = knn_cex(best, stride, (lane & stride) == 0);
+          if (lane >= k) best = none;
+          worst = __shfl(best, k - 1);
+        }
       }
-      ds[m * KNN_BLOCK + t] = d;
-      is[m * KNN_BLOCK + t] = j;
-      worst = ds[(k - 1) * KNN_BLOCK + t];
-    }
+    const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1;
+    const float lim = (float)r * g.h * 0.9999f;
+    if (whole || (worst != none && __uint_as_float((uint32_t)(worst >> 32)) <= lim * lim)) break;
   }
-  if (i < n)
-    for (int m = 0; m < k; m++) {
-      const bool ok = is[m * KNN_BLOCK + t] >= 0;
-      idx_out[(size_t)i * k + m] = is[m * KNN_BLOCK + t];
-      d2_out[(size_t)i * k + m] = ok ? ds[m * KNN_BLOCK + t] : 0.f;
-    }
+  if (lane < k) {
+    const size_t row = (size_t)__float_as_uint(p.w) * k;
+    idx_out[row + lane] = best == none ? -1 : (int)(uint32_t)best;
+    d2_out[row + lane] = best == none ? 0.f : __uint_as_float((uint32_t)(best >> 32));
+  }
 }
 
 /* ---- statistical outlier removal ---------------------------------------------------------------------------- */
