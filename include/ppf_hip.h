@@ -264,6 +264,12 @@ ppf_status ppf_prep_normals(const ppf_cloud* in, int k, ppf_cloud** out);
 ppf_status ppf_prep_edges(const ppf_cloud* in, float curvature_threshold, ppf_cloud** out);
 /* PointCloudXYZNormalToMat (:163-190): rows with re-normalised normals */
 ppf_status ppf_prep_to_mat(const ppf_cloud* in, ppf_cloud** out);
+/* match / match_S2B (:442, :495) and the ICP step (:465-470, :518-523) on clouds that are already resident (the
+ * outputs of ppf_prep_to_mat): crop -> ... -> edges -> match -> ICP without a host copy of any cloud */
+ppf_status ppf_match_clouds(const ppf_model* m, const ppf_cloud* scene, const ppf_cloud* edge, const ppf_match_params* params,
+                            ppf_pose* out, int cap, int* n_out);
+ppf_status ppf_icp_refine_clouds(const ppf_cloud* model, const ppf_cloud* scene, const ppf_icp_params* params, ppf_pose* poses_io,
+                                 int n_poses, int* iterations_out);
 /* exact neighbour lists (parity surface): idx, d2 are [n][k], ascending (distance, index) */
 ppf_status ppf_prep_knn(const ppf_cloud* in, int k, int* idx, float* d2);
 

@@ -176,5 +176,11 @@ def test_reference_sequence_on_a_synthetic_frame(bottle):
                                                                   relative_scene_distance=0.05, cluster=True)
     P, r, _ = O.icp_refine(bottle, obj_mat, [w["pose"] for w in want["poses"][:5]])
     np.testing.assert_allclose(pose.pose, P[0], rtol=0, atol=1e-9)
+    # the same with every cloud resident on the device (ppf_match_clouds + ppf_icp_refine_clouds): identical pose
+    obj_dev = cp.PointCloudXYZNormalToMat(cp.objects_with_normals[0], resident=True)
+    edge_dev = cp.PointCloudXYZNormalToMat(cp.objects_edges[0], resident=True)
+    pose_dev = cp.Matching_S2B("bottle", obj_dev, edge_dev)
+    np.testing.assert_array_equal(pose_dev.pose, pose.pose)
+    assert (pose_dev.numVotes, pose_dev.residual) == (pose.numVotes, pose.residual)
     # plain surface matching votes for the wall that fills the crop (planes beat the bottle); it still returns a pose
     assert cp.Matching("bottle", obj_mat, 0.05, 0.05) is not None

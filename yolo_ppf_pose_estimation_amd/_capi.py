@@ -122,6 +122,10 @@ _SIGNATURES = {
     "ppf_prep_normals": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ppf_prep_edges": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
     "ppf_prep_to_mat": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ppf_match_clouds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MatchParams), C.POINTER(Pose), C.c_int,
+                                   C.POINTER(C.c_int)]),
+    "ppf_icp_refine_clouds": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(IcpParams), C.POINTER(Pose), C.c_int,
+                                        C.POINTER(C.c_int)]),
     "ppf_prep_knn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ppf_icp_register": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _capi
-from ._capi import PPFError, check, lib
+from ._capi import IcpParams, Pose, PPFError, check, lib
 from .detector import ICP, PPF3DDetector, Pose3D
 
 
@@ -122,6 +122,7 @@ class CloudProcessor:
         self.if_trained: List[bool] = []
         self.label_to_id: Dict[str, int] = {}
         self.id_to_label: Dict[int, str] = {}
+        self._model_clouds: Dict[int, DeviceCloud] = {}
 
     # ---- the PCL half -------------------------------------------------------------------------------------
     def SceneCropping(self, CameraIntr) -> List[DeviceCloud]:
@@ -149,8 +150,11 @@ class CloudProcessor:
         return self.objects_edges
 
     @staticmethod
-    def PointCloudXYZNormalToMat(pcl_cloud: DeviceCloud) -> np.ndarray:
-        return pcl_cloud.to_mat().rows()
+    def PointCloudXYZNormalToMat(pcl_cloud: DeviceCloud, resident: bool = False):
+        """the N x 6 Mat of the reference (numpy array); ``resident=True`` keeps it on the device (a DeviceCloud that
+        Matching / Matching_S2B accept directly, so no cloud crosses PCIe between the crop and the pose)"""
+        mat = pcl_cloud.to_mat()
+        return mat if resident else mat.rows()
 
     # ---- the PPF half -------------------------------------------------------------------------------------
     def LoadSingleModel(self, model_input: np.ndarray, label: str):
@@ -170,12 +174,31 @@ class CloudProcessor:
         if not self.if_trained[idx]:
             raise PPFError(_capi.PPF_ERR_NOT_TRAINED, f"Model [{name}] not trained yet.")
         det = self.detectors[idx]
+        if isinstance(scene, DeviceCloud):
+            return self._match_resident(idx, det, scene, edge, step, dist)
         results = det.match(scene, step, dist) if edge is None else det.match_S2B(scene, edge, step, dist)
         if not results:
             return None  # the reference prints "No matching Poses found" and exits (:450-454)
         sub = results[:5]
         ICP(100, 0.005, 2.5, 8).registerModelToScene(self.models[idx], scene, sub)
         return sub[0]
+
+    def _match_resident(self, idx, det, scene: DeviceCloud, edge: Optional[DeviceCloud], step, dist) -> Optional[Pose3D]:
+        mp = det._params(step, dist, False)
+        cap = len(scene) + 8
+        out = (Pose * cap)()
+        n = C.c_int(0)
+        check(lib().ppf_match_clouds(det._model.ptr, scene._ptr, edge._ptr if edge is not None else None, C.byref(mp), out, cap,
+                                     C.byref(n)))
+        if n.value == 0:
+            return None
+        top = min(5, n.value)
+        if idx not in self._model_clouds:
+            self._model_clouds[idx] = DeviceCloud.upload(self.models[idx])
+        prm = IcpParams()
+        lib().ppf_default_icp_params(C.byref(prm))
+        check(lib().ppf_icp_refine_clouds(self._model_clouds[idx]._ptr, scene._ptr, C.byref(prm), out, top, None))
+        return Pose3D(out[0])
 
     def Matching(self, name: str, scene: np.ndarray, relativeSceneSampleStep: float = 0.0714,
                  relativeSceneDistance: float = 0.05) -> Optional[Pose3D]:

@@ -2258,4 +2258,27 @@ ppf_status ppf_prep_to_mat(const ppf_cloud* in, ppf_cloud** out) {
   return PPF_OK;
 }
 
+/* ---- the PPF calls on device-resident clouds: the whole chain after the detector's boxes without host copies --- */
+ppf_status ppf_match_clouds(const ppf_model* m, const ppf_cloud* scene, const ppf_cloud* edge, const ppf_match_params* params,
+                            ppf_pose* out, int cap, int* n_out) {
+  if (!n_out) return fail(PPF_ERR_INVALID, "ppf_match_clouds: n_out is NULL");
+  *n_out = 0;
+  if (!scene) return fail(PPF_ERR_INVALID, "ppf_match_clouds: scene is NULL");
+  ppf_status s = check_match_args(m, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params);
+  if (s != PPF_OK) return s;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_clouds: no HIP device (this engine has no CPU fallback)");
+  ppf_workspace ws;
+  s = ppf_match_device(m, &ws, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params, nullptr);
+  if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
+  for (auto& e : ws.ev)
+    if (e) (void)hipEventDestroy(e);
+  return s;
+}
+
+ppf_status ppf_icp_refine_clouds(const ppf_cloud* model, const ppf_cloud* scene, const ppf_icp_params* params, ppf_pose* poses_io,
+                                 int n_poses, int* iterations_out) {
+  if (!model || !scene) return fail(PPF_ERR_INVALID, "ppf_icp_refine_clouds: cloud is NULL");
+  return ppf_icp_refine_device(model->rows.p, model->n, 6, scene->rows.p, scene->n, 6, params, poses_io, n_poses, iterations_out, nullptr);
+}
+
 }  // extern "C"
