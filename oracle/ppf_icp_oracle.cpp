@@ -16,7 +16,7 @@
  *   - least squares: upstream cv::solve(A, b, DECOMP_SVD) on the n x 6 system (minimum-norm solution when the
  *     correspondences leave directions unconstrained).  Here: normal equations (A^T A) x = A^T b in fp64, rows
  *     accumulated in chunks of 64 (sequential inside a chunk, chunk sums added sequentially) -- the order the device
- *     kernels reproduce -- solved through a Jacobi eigen-decomposition with a truncated pseudo-inverse (solve6).
+ *     kernels reproduce -- with Tikhonov damping 1e-10 * trace, solved by Gaussian elimination (solve6).
  *   - median: element of rank (m-1)/2 of the sorted values (lower median).
  *   - every other sum over points (means, distance sums) is taken in the same chunk-of-64 order; sin/cos/sqrt come
  *     from include/ppf_detmath.h (<= 1 ulp from libm), so the device kernels can match this file bit for bit.
@@ -83,52 +83,32 @@ void transform_from_euler(const double* e, const double* t, double* P) {
   for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) P[i * 4 + j] = R[i * 3 + j]; P[i * 4 + 3] = t[i]; }
   P[12] = P[13] = P[14] = 0; P[15] = 1;
 }
-/* Minimum-norm least-squares solution of the 6x6 normal equations M[:, :6] x = M[:, 6] (what cv::solve(DECOMP_SVD)
- * returns for the n x 6 system): cyclic Jacobi eigen-decomposition (16 sweeps, + - * / sqrt only), eigenvalues not
- * above 1e-10 * lambda_max are dropped (singular values below 1e-5 * sigma_max: directions the correspondences do
- * not constrain, e.g. sliding on a plane), x = sum_i v_i (v_i . b) / lambda_i in index order.  Result in M[i][6];
- * false when the matrix has no positive eigenvalue. */
+/* Least-squares solution of the 6x6 normal equations M[:, :6] x = M[:, 6], robust to directions the correspondences
+ * do not constrain (sliding on a plane, spinning about an axis of symmetry), where upstream's cv::solve(DECOMP_SVD)
+ * returns the minimum-norm solution: Tikhonov damping (M + lambda I) x = b with lambda = 1e-10 * trace(M) -- identical
+ * to the plain solution for constrained directions (relative change 1e-10 * condition number), ~0 along unconstrained
+ * ones -- then Gaussian elimination with partial pivoting.  Result in M[i][6]; false when trace(M) is not positive. */
 bool solve6(double M[6][7]) {
-  double A[6][6], V[6][6], rhs[6];
-  for (int i = 0; i < 6; i++) { rhs[i] = M[i][6]; for (int j = 0; j < 6; j++) { A[i][j] = M[i][j]; V[i][j] = i == j ? 1.0 : 0.0; } }
-  for (int sweep = 0; sweep < 16; sweep++)
-    for (int p = 0; p < 5; p++)
-      for (int q = p + 1; q < 6; q++) {
-        const double apq = A[p][q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-        const double at = theta < 0 ? -theta : theta;
-        double t = 1.0 / (at + ppf_sqrt(theta * theta + 1.0));
-        if (theta < 0) t = -t;
-        const double c = 1.0 / ppf_sqrt(t * t + 1.0), sn = t * c;
-        for (int k = 0; k < 6; k++) {
-          if (k == p || k == q) continue;
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - sn * akq; A[p][k] = A[k][p];
-          A[k][q] = sn * akp + c * akq; A[q][k] = A[k][q];
-        }
-        A[p][p] = A[p][p] - t * apq;
-        A[q][q] = A[q][q] + t * apq;
-        A[p][q] = 0.0; A[q][p] = 0.0;
-        for (int k = 0; k < 6; k++) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - sn * vkq;
-          V[k][q] = sn * vkp + c * vkq;
-        }
-      }
-  double lmax = A[0][0];
-  for (int i = 1; i < 6; i++) if (A[i][i] > lmax) lmax = A[i][i];
-  if (!(lmax > 0.0)) return false;
-  const double cut = 1e-10 * lmax;
-  double x[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 6; i++) {
-    if (!(A[i][i] > cut)) continue;
-    double proj = 0;
-    for (int k = 0; k < 6; k++) proj += V[k][i] * rhs[k];
-    const double w = proj / A[i][i];
-    for (int k = 0; k < 6; k++) x[k] += V[k][i] * w;
+  double trace = 0;
+  for (int i = 0; i < 6; i++) trace += M[i][i];
+  if (!(trace > 0.0)) return false;
+  const double lambda = 1e-10 * trace;
+  for (int i = 0; i < 6; i++) M[i][i] += lambda;
+  for (int c = 0; c < 6; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 6; r++) if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+    if (std::fabs(M[piv][c]) < 1e-300) return false;
+    if (piv != c) for (int k = 0; k < 7; k++) std::swap(M[c][k], M[piv][k]);
+    for (int r = c + 1; r < 6; r++) {
+      const double f = M[r][c] / M[c][c];
+      for (int k = c; k < 7; k++) M[r][k] -= f * M[c][k];
+    }
   }
-  for (int i = 0; i < 6; i++) M[i][6] = x[i];
+  for (int c = 5; c >= 0; c--) {
+    double s = M[c][6];
+    for (int k = c + 1; k < 6; k++) s -= M[c][k] * M[k][6];
+    M[c][6] = s / M[c][c];
+  }
   return true;
 }
 

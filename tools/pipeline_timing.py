@@ -46,9 +46,10 @@ def main():
         cp.label_to_id, cp.id_to_label, cp._model_clouds = trainer.label_to_id, trainer.id_to_label, trainer._model_clouds
         pose, n_obj, n_edge = run(cp)
         times.append(time.perf_counter() - t0)
+        parts = {k: round(v * 1e3, 3) for k, v in cp.timings.items()}
     print(json.dumps({"frame_points": int(xyz.shape[0]), "object_points": n_obj, "edge_points": n_edge,
                       "model_sampled_points": trainer.detectors[0].info()["n_ref"], "train_seconds": train_s,
-                      "frame_to_pose_ms": [round(t * 1e3, 3) for t in times], "votes": pose.numVotes, "residual": pose.residual,
+                      "frame_to_pose_ms": [round(t * 1e3, 3) for t in times], "of_which_ms": parts, "votes": pose.numVotes, "residual": pose.residual,
                       "pose": pose.pose.round(6).tolist()}))
 
 

@@ -7,6 +7,7 @@ reference's; the YOLO detector that supplies ``boxes`` is out of scope (SURVEY.m
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -123,6 +124,7 @@ class CloudProcessor:
         self.label_to_id: Dict[str, int] = {}
         self.id_to_label: Dict[int, str] = {}
         self._model_clouds: Dict[int, DeviceCloud] = {}
+        self.timings: Dict[str, float] = {}  # seconds spent in the last resident match / ICP call
 
     # ---- the PCL half -------------------------------------------------------------------------------------
     def SceneCropping(self, CameraIntr) -> List[DeviceCloud]:
@@ -188,8 +190,10 @@ class CloudProcessor:
         cap = len(scene) + 8
         out = (Pose * cap)()
         n = C.c_int(0)
+        t0 = time.perf_counter()
         check(lib().ppf_match_clouds(det._model.ptr, scene._ptr, edge._ptr if edge is not None else None, C.byref(mp), out, cap,
                                      C.byref(n)))
+        self.timings["match"] = time.perf_counter() - t0
         if n.value == 0:
             return None
         top = min(5, n.value)
@@ -197,7 +201,9 @@ class CloudProcessor:
             self._model_clouds[idx] = DeviceCloud.upload(self.models[idx])
         prm = IcpParams()
         lib().ppf_default_icp_params(C.byref(prm))
+        t0 = time.perf_counter()
         check(lib().ppf_icp_refine_clouds(self._model_clouds[idx]._ptr, scene._ptr, C.byref(prm), out, top, None))
+        self.timings["icp"] = time.perf_counter() - t0
         return Pose3D(out[0])
 
     def Matching(self, name: str, scene: np.ndarray, relativeSceneSampleStep: float = 0.0714,

@@ -15,8 +15,8 @@
  *     scene index (one workgroup, thread-contiguous ranges + block scan).
  *   - normal equations: one wave per chunk of 64 correspondences; every lane builds its row, 28 lanes each add one
  *     entry of the symmetric 6x7 system (+ the residual) over the chunk IN ROW ORDER; the single-wave solve kernel
- *     adds the chunk sums IN CHUNK ORDER, solves the 6x6 (Jacobi eigen-decomposition + truncated pseudo-inverse:
- *     the minimum-norm solution, as upstream's SVD solve gives when correspondences leave directions free), builds
+ *     adds the chunk sums IN CHUNK ORDER, solves the 6x6 (Tikhonov damping 1e-10*trace + Gaussian elimination:
+ *     ~0 along directions the correspondences leave free, as upstream's SVD solve gives), builds
  *     PoseX = T(t) * Rz*Ry*Rx and updates the loop state.  fp64 throughout, no FMA contraction.
  *   - the loop state (PoseX, fval_old/perc/min, iteration counter, done flag) lives in HBM; every kernel starts with
  *     `if (st->done) return`, so the host enqueues iterations in batches and reads the flag once per batch.
@@ -361,7 +361,6 @@ __global__ __launch_bounds__(64) void k_icp_solve(const double* __restrict__ par
   if (st->done) return;
   __shared__ double tot[ICP_ENTRIES];
   __shared__ double M[6][7];
-  __shared__ double V[6][6];
   const int tid = threadIdx.x;
   const int n_chunks = (st->n_sel + ICP_CHUNK - 1) / ICP_CHUNK;
   if (tid < ICP_ENTRIES) tot[tid] = icp_sum_parts(parts + tid, n_chunks, ICP_ENTRIES);
@@ -372,47 +371,29 @@ __global__ __launch_bounds__(64) void k_icp_solve(const double* __restrict__ par
     for (int j = i; j < 6; j++) { M[i][j] = tot[e]; M[j][i] = tot[e]; e++; }
   for (int i = 0; i < 6; i++) M[i][6] = tot[21 + i];
   const double fsum = tot[27];
-  /* minimum-norm solution: Jacobi eigen-decomposition of the 6x6, truncated pseudo-inverse (oracle: solve6) */
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) V[i][j] = i == j ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 16; sweep++)
-    for (int p = 0; p < 5; p++)
-      for (int q = p + 1; q < 6; q++) {
-        const double apq = M[p][q];
-        if (apq == 0.0) continue;
-        const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
-        const double at = theta < 0 ? -theta : theta;
-        double tt = 1.0 / (at + ppf_sqrt(theta * theta + 1.0));
-        if (theta < 0) tt = -tt;
-        const double c = 1.0 / ppf_sqrt(tt * tt + 1.0), sn = tt * c;
-        for (int k = 0; k < 6; k++) {
-          if (k == p || k == q) continue;
-          const double akp = M[k][p], akq = M[k][q];
-          M[k][p] = c * akp - sn * akq; M[p][k] = M[k][p];
-          M[k][q] = sn * akp + c * akq; M[q][k] = M[k][q];
-        }
-        M[p][p] = M[p][p] - tt * apq;
-        M[q][q] = M[q][q] + tt * apq;
-        M[p][q] = 0.0; M[q][p] = 0.0;
-        for (int k = 0; k < 6; k++) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - sn * vkq;
-          V[k][q] = sn * vkp + c * vkq;
-        }
-      }
-  double lmax = M[0][0];
-  for (int i = 1; i < 6; i++) if (M[i][i] > lmax) lmax = M[i][i];
-  if (!(lmax > 0.0)) { st->done = 1; return; }
-  const double cut = 1e-10 * lmax;
-  double x[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 6; i++) {
-    if (!(M[i][i] > cut)) continue;
-    double proj = 0;
-    for (int k = 0; k < 6; k++) proj += V[k][i] * M[k][6];
-    const double w = proj / M[i][i];
-    for (int k = 0; k < 6; k++) x[k] += V[k][i] * w;
+  /* damped normal equations (M + 1e-10 trace I) x = b, Gaussian elimination with partial pivoting (oracle: solve6) */
+  double trace = 0;
+  for (int i = 0; i < 6; i++) trace += M[i][i];
+  if (!(trace > 0.0)) { st->done = 1; return; }
+  const double lambda = 1e-10 * trace;
+  for (int i = 0; i < 6; i++) M[i][i] += lambda;
+  bool ok = true;
+  for (int c = 0; c < 6 && ok; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 6; r++) if (ppf_fabs(M[r][c]) > ppf_fabs(M[piv][c])) piv = r;
+    if (ppf_fabs(M[piv][c]) < 1e-300) { ok = false; break; }
+    if (piv != c) for (int k = 0; k < 7; k++) { const double tmp = M[c][k]; M[c][k] = M[piv][k]; M[piv][k] = tmp; }
+    for (int r = c + 1; r < 6; r++) {
+      const double f = M[r][c] / M[c][c];
+      for (int k = c; k < 7; k++) M[r][k] -= f * M[c][k];
+    }
   }
-  for (int i = 0; i < 6; i++) M[i][6] = x[i];
+  if (!ok) { st->done = 1; return; }
+  for (int c = 5; c >= 0; c--) {
+    double sacc = M[c][6];
+    for (int k = c + 1; k < 6; k++) sacc -= M[c][k] * M[k][6];
+    M[c][6] = sacc / M[c][c];
+  }
   const double rpy[3] = {M[0][6], M[1][6], M[2][6]}, t[3] = {M[3][6], M[4][6], M[5][6]};
   if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) { st->done = 1; return; }
   double P[16];
