@@ -1683,56 +1683,78 @@ struct IcpScratch {
   DevBuf<IcpState> state;
 };
 
-constexpr int ICP_BATCH = 4; /* iterations enqueued between two reads of the done flag */
+constexpr int ICP_BATCH = 2;     /* iterations enqueued between two reads of the done flag (measured best of 1..6) */
+constexpr int ICP_MAX_JOBS = 8;  /* poses refined concurrently, one HIP stream each */
 
 inline long icp_round(double v) { return std::lrint(v); } /* cvRound */
 
-/* ICP::registerModelToScene(srcPC, dstPC, residual, pose) on device-resident clouds.  init_pose (host, may be NULL)
- * is applied to the source rows first (the caller's `transformPCPose(srcPC, poses[i]->pose)`). */
-ppf_status icp_register(const float* d_src, int n, int sstride, const float* d_dst, int nd_all, int dstride,
-                        const ppf_icp_params& prm, const double* init_pose, IcpScratch& sc, hipStream_t st, double* pose_out,
-                        double* residual, int* iters_total) {
-  const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
-  HIPCHK(sc.src0.reserve((size_t)n * 6));
-  HIPCHK(sc.src_pct.reserve((size_t)n * 6));
-  HIPCHK(sc.moved.reserve((size_t)n * 6));
-  HIPCHK(sc.dst0.reserve((size_t)nd_all * 6));
-  HIPCHK(sc.dst_pcs.reserve((size_t)nd_all * 6));
-  HIPCHK(sc.q4.reserve((size_t)nd_all));
-  HIPCHK(sc.best.reserve((size_t)n));
-  HIPCHK(sc.owner.reserve((size_t)nd_all));
-  HIPCHK(sc.sel.reserve((size_t)std::min(n, nd_all)));
-  HIPCHK(sc.parts.reserve(std::max(chunks_src, chunks_dst) * ICP_ENTRIES));
-  HIPCHK(sc.sum_src.reserve(chunks_src * 3));
-  HIPCHK(sc.sum_dst.reserve(chunks_dst * 3));
-  HIPCHK(sc.state.reserve(1));
-  IcpState* d_st = sc.state.p;
-  IcpState h_st;
-  auto grid = [](size_t items, int block) { return dim3((unsigned)((items + block - 1) / block)); };
-
-  /* the two clouds, packed; the source moved by the initial pose */
-  if (init_pose) {
-    HIPCHK(hipMemcpyAsync(d_st->T, init_pose, 16 * sizeof(double), hipMemcpyHostToDevice, st));
-    k_icp_transform<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, d_st->T, sc.src0.p, nullptr, nullptr, nullptr);
-  } else {
-    k_icp_sample<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, sc.src0.p, nullptr);
-  }
-  k_icp_sample<<<grid(nd_all, 256), dim3(256), 0, st>>>(d_dst, dstride, 1, nd_all, sc.dst0.p, nullptr);
-  /* centre on the average of the two means, scale to unit average distance from the origin */
-  for (int mode = 0; mode < 2; mode++) {
-    k_icp_chunk_sums<<<grid(chunks_src, 64), dim3(64), 0, st>>>(sc.src0.p, n, mode, sc.sum_src.p);
-    k_icp_chunk_sums<<<grid(chunks_dst, 64), dim3(64), 0, st>>>(sc.dst0.p, nd_all, mode, sc.sum_dst.p);
-    k_icp_reduce<<<dim3(1), dim3(64), 0, st>>>(sc.sum_src.p, n, sc.sum_dst.p, nd_all, mode, d_st);
-    k_icp_center_scale<<<grid(n, 256), dim3(256), 0, st>>>(sc.src0.p, n, mode, d_st);
-    k_icp_center_scale<<<grid(nd_all, 256), dim3(256), 0, st>>>(sc.dst0.p, nd_all, mode, d_st);
-  }
-  HIPCHK(hipGetLastError());
-
+/* one registration in flight: its scratch, its stream, a pinned mirror of the device loop state */
+struct IcpJob {
+  IcpScratch sc;
+  hipStream_t st = nullptr; /* borrowed: the caller's stream or one of the pool's */
+  IcpState* h_st = nullptr;
   double pose[16];
-  for (int k = 0; k < 16; k++) pose[k] = (k % 5 == 0) ? 1.0 : 0.0;
   double fval_min = 9999999999.0;
-  int total = 0;
+  int total = 0, launched = 0;
+  bool active = false;
+  ~IcpJob() {
+    if (h_st) (void)hipHostFree(h_st);
+  }
+};
+
+/* ICP::registerModelToScene(srcPC, dstPC, residual, pose) on device-resident clouds for jobs.size() initial poses at
+ * once (init_poses[j] may be NULL: register from the identity).  The registrations are independent chains of small
+ * kernels, so each runs on its own stream and the host walks them in lock-step: same level, one batch of iterations
+ * enqueued on every stream, then one read of every done flag. */
+ppf_status icp_register_many(const float* d_src, int n, int sstride, const float* d_dst, int nd_all, int dstride,
+                             const ppf_icp_params& prm, const double* const* init_poses, std::vector<std::unique_ptr<IcpJob>>& jobs,
+                             double* poses_out /* jobs x 16 */, double* residuals, int* iters_total) {
+  const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
+  auto grid = [](size_t items, int block) { return dim3((unsigned)((items + block - 1) / block)); };
   const int robust = prm.rejection_scale > 0 ? 1 : 0;
+  const int icp_batch = getenv("PPF_ICP_BATCH") ? std::max(1, atoi(getenv("PPF_ICP_BATCH"))) : ICP_BATCH;
+  for (size_t j = 0; j < jobs.size(); j++) {
+    IcpJob& J = *jobs[j];
+    IcpScratch& sc = J.sc;
+    HIPCHK(sc.src0.reserve((size_t)n * 6));
+    HIPCHK(sc.src_pct.reserve((size_t)n * 6));
+    HIPCHK(sc.moved.reserve((size_t)n * 6));
+    HIPCHK(sc.dst0.reserve((size_t)nd_all * 6));
+    HIPCHK(sc.dst_pcs.reserve((size_t)nd_all * 6));
+    HIPCHK(sc.q4.reserve((size_t)nd_all));
+    HIPCHK(sc.best.reserve((size_t)n));
+    HIPCHK(sc.owner.reserve((size_t)nd_all));
+    HIPCHK(sc.sel.reserve((size_t)std::min(n, nd_all)));
+    HIPCHK(sc.parts.reserve(std::max(chunks_src, chunks_dst) * ICP_ENTRIES));
+    HIPCHK(sc.sum_src.reserve(chunks_src * 3));
+    HIPCHK(sc.sum_dst.reserve(chunks_dst * 3));
+    HIPCHK(sc.state.reserve(1));
+    if (!J.h_st) HIPCHK(hipHostMalloc((void**)&J.h_st, sizeof(IcpState), hipHostMallocDefault));
+    IcpState* d_st = sc.state.p;
+    hipStream_t st = J.st;
+    /* the two clouds, packed; the source moved by the initial pose */
+    if (init_poses && init_poses[j]) {
+      IcpMat44 T0;
+      memcpy(T0.m, init_poses[j], sizeof(T0.m));
+      k_icp_set_pose<<<dim3(1), dim3(1), 0, st>>>(d_st, T0);
+      k_icp_transform<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, d_st->T, sc.src0.p, nullptr, nullptr, nullptr);
+    } else {
+      k_icp_sample<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, sc.src0.p, nullptr);
+    }
+    k_icp_sample<<<grid(nd_all, 256), dim3(256), 0, st>>>(d_dst, dstride, 1, nd_all, sc.dst0.p, nullptr);
+    /* centre on the average of the two means, scale to unit average distance from the origin */
+    for (int mode = 0; mode < 2; mode++) {
+      k_icp_chunk_sums<<<grid(chunks_src, 64), dim3(64), 0, st>>>(sc.src0.p, n, mode, sc.sum_src.p);
+      k_icp_chunk_sums<<<grid(chunks_dst, 64), dim3(64), 0, st>>>(sc.dst0.p, nd_all, mode, sc.sum_dst.p);
+      k_icp_reduce<<<dim3(1), dim3(64), 0, st>>>(sc.sum_src.p, n, sc.sum_dst.p, nd_all, mode, d_st);
+      k_icp_center_scale<<<grid(n, 256), dim3(256), 0, st>>>(sc.src0.p, n, mode, d_st);
+      k_icp_center_scale<<<grid(nd_all, 256), dim3(256), 0, st>>>(sc.dst0.p, nd_all, mode, d_st);
+    }
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k < 16; k++) J.pose[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    J.fval_min = 9999999999.0;
+    J.total = 0;
+  }
   for (int level = prm.num_levels - 1; level >= 0; level--) {
     const double div = std::pow(2.0, (double)level);
     const int num_samples = (int)icp_round((double)n / div);
@@ -1740,10 +1762,6 @@ ppf_status icp_register(const float* d_src, int n, int sstride, const float* d_d
     const int max_iter = (int)icp_round((double)prm.iterations / (level + 1));
     const int step = std::max(1, (int)icp_round((double)n / (double)std::max(num_samples, 1)));
     const int ns = (n + step - 1) / step, nd = (nd_all + step - 1) / step;
-    HIPCHK(hipMemcpyAsync(d_st->T, pose, sizeof(pose), hipMemcpyHostToDevice, st));
-    k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src0.p, 6, step, ns, d_st->T, sc.src_pct.p, sc.moved.p, sc.best.p, nullptr);
-    k_icp_sample<<<grid(nd, 256), dim3(256), 0, st>>>(sc.dst0.p, 6, step, nd, sc.dst_pcs.p, sc.q4.p);
-    k_icp_level_init<<<dim3(1), dim3(1), 0, st>>>(d_st, tol_p, max_iter, robust);
     /* NN launch shape: model points x scene slices, enough workgroups to fill 256 CUs */
     const unsigned gx = (unsigned)((ns + 255) / 256);
     const int max_splits = (nd + 63) / 64;
@@ -1751,41 +1769,122 @@ ppf_status icp_register(const float* d_src, int n, int sstride, const float* d_d
     const int slice = (nd + splits - 1) / splits;
     const unsigned gy = (unsigned)((nd + slice - 1) / slice);
     const unsigned n_chunks = (unsigned)((std::min(ns, nd) + ICP_CHUNK - 1) / ICP_CHUNK);
-    int launched = 0;
-    for (;;) {
-      const int batch = std::min(ICP_BATCH, max_iter - launched);
-      for (int b = 0; b < batch; b++) {
-        k_icp_nn<<<dim3(gx, gy), dim3(256), 0, st>>>(sc.moved.p, ns, sc.q4.p, nd, slice, sc.best.p, d_st);
-        k_icp_threshold<<<dim3(1), dim3(1024), 0, st>>>(sc.best.p, ns, prm.rejection_scale, sc.owner.p, nd, d_st);
-        k_icp_owner<<<grid(ns, 256), dim3(256), 0, st>>>(sc.best.p, ns, sc.owner.p, d_st);
-        k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
-        k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
-        k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
-        k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
-      }
-      launched += std::max(batch, 0);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(&h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      if (h_st.done || launched >= max_iter) break;
+    for (auto& jp : jobs) {
+      IcpJob& J = *jp;
+      IcpScratch& sc = J.sc;
+      IcpState* d_st = sc.state.p;
+      IcpMat44 T;
+      memcpy(T.m, J.pose, sizeof(T.m));
+      k_icp_set_pose<<<dim3(1), dim3(1), 0, J.st>>>(d_st, T);
+      k_icp_transform<<<grid(ns, 256), dim3(256), 0, J.st>>>(sc.src0.p, 6, step, ns, d_st->T, sc.src_pct.p, sc.moved.p, sc.best.p, nullptr);
+      k_icp_sample<<<grid(nd, 256), dim3(256), 0, J.st>>>(sc.dst0.p, 6, step, nd, sc.dst_pcs.p, sc.q4.p);
+      k_icp_level_init<<<dim3(1), dim3(1), 0, J.st>>>(d_st, tol_p, max_iter, robust);
+      J.launched = 0;
+      J.active = true;
     }
-    total += h_st.iter;
-    fval_min = h_st.fval_min;
-    double tmp[16];
-    ppf_mat44_mul(h_st.PoseX, pose, tmp);
-    memcpy(pose, tmp, sizeof(tmp));
+    for (bool any = true; any;) {
+      for (auto& jp : jobs) {
+        IcpJob& J = *jp;
+        if (!J.active) continue;
+        IcpScratch& sc = J.sc;
+        IcpState* d_st = sc.state.p;
+        hipStream_t st = J.st;
+        const int batch = std::min(icp_batch, max_iter - J.launched);
+        for (int b = 0; b < batch; b++) {
+          k_icp_nn<<<dim3(gx, gy), dim3(256), 0, st>>>(sc.moved.p, ns, sc.q4.p, nd, slice, sc.best.p, d_st);
+          k_icp_threshold<<<dim3(1), dim3(1024), 0, st>>>(sc.best.p, ns, prm.rejection_scale, sc.owner.p, nd, d_st);
+          k_icp_owner<<<grid(ns, 256), dim3(256), 0, st>>>(sc.best.p, ns, sc.owner.p, d_st);
+          k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
+          k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
+          k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
+          k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
+        }
+        J.launched += std::max(batch, 0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(J.h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+      }
+      any = false;
+      for (auto& jp : jobs) {
+        IcpJob& J = *jp;
+        if (!J.active) continue;
+        HIPCHK(hipStreamSynchronize(J.st));
+        if (J.h_st->done || J.launched >= max_iter) J.active = false;
+        else any = true;
+      }
+    }
+    for (auto& jp : jobs) {
+      IcpJob& J = *jp;
+      J.total += J.h_st->iter;
+      J.fval_min = J.h_st->fval_min;
+      double tmp[16];
+      ppf_mat44_mul(J.h_st->PoseX, J.pose, tmp);
+      memcpy(J.pose, tmp, sizeof(tmp));
+    }
   }
-  if (prm.num_levels <= 0) {
-    HIPCHK(hipMemcpyAsync(&h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+  for (size_t j = 0; j < jobs.size(); j++) {
+    IcpJob& J = *jobs[j];
+    if (prm.num_levels <= 0) {
+      HIPCHK(hipMemcpyAsync(J.h_st, J.sc.state.p, sizeof(IcpState), hipMemcpyDeviceToHost, J.st));
+      HIPCHK(hipStreamSynchronize(J.st));
+    }
+    /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
+    const IcpState& h = *J.h_st;
+    double* pose = J.pose;
+    double Rm[3];
+    for (int r = 0; r < 3; r++) Rm[r] = pose[r * 4] * h.mean_avg[0] + pose[r * 4 + 1] * h.mean_avg[1] + pose[r * 4 + 2] * h.mean_avg[2];
+    for (int r = 0; r < 3; r++) pose[r * 4 + 3] = pose[r * 4 + 3] / h.scale + h.mean_avg[r] - Rm[r];
+    memcpy(poses_out + j * 16, pose, 16 * sizeof(double));
+    if (residuals) residuals[j] = J.fval_min;
+    if (iters_total) iters_total[j] = J.total;
   }
-  /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
-  double Rm[3];
-  for (int r = 0; r < 3; r++) Rm[r] = pose[r * 4] * h_st.mean_avg[0] + pose[r * 4 + 1] * h_st.mean_avg[1] + pose[r * 4 + 2] * h_st.mean_avg[2];
-  for (int r = 0; r < 3; r++) pose[r * 4 + 3] = pose[r * 4 + 3] / h_st.scale + h_st.mean_avg[r] - Rm[r];
-  memcpy(pose_out, pose, sizeof(pose));
-  if (residual) *residual = fval_min;
-  if (iters_total) *iters_total = total;
+  return PPF_OK;
+}
+
+/* Streams (and pinned state mirrors) for concurrent jobs come from a process-wide pool: creating a HIP stream costs
+ * milliseconds, far more than a registration.  One caller at a time owns the pool (others fall back to one stream). */
+struct IcpStreamPool {
+  std::mutex mu;
+  hipStream_t st[ICP_MAX_JOBS] = {};
+  int device = -1;
+  bool ok = false;
+};
+IcpStreamPool g_icp_pool;
+
+ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<std::unique_ptr<IcpJob>>& jobs, std::unique_lock<std::mutex>& pool_lock) {
+  jobs.clear();
+  bool pooled = false;
+  if (count > 1 && !getenv("PPF_ICP_ONE_STREAM")) {
+    pool_lock = std::unique_lock<std::mutex>(g_icp_pool.mu, std::try_to_lock);
+    if (pool_lock.owns_lock()) {
+      int dev = 0;
+      HIPCHK(hipGetDevice(&dev));
+      if (!g_icp_pool.ok || g_icp_pool.device != dev) {
+        for (int j = 0; j < ICP_MAX_JOBS; j++) {
+          if (g_icp_pool.st[j]) (void)hipStreamDestroy(g_icp_pool.st[j]);
+          g_icp_pool.st[j] = nullptr;
+          HIPCHK(hipStreamCreateWithFlags(&g_icp_pool.st[j], hipStreamNonBlocking));
+        }
+        g_icp_pool.device = dev;
+        g_icp_pool.ok = true;
+      }
+      pooled = true;
+    }
+  }
+  hipEvent_t ready = nullptr;
+  if (pooled) {
+    HIPCHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ready, user));
+  }
+  for (int j = 0; j < count; j++) {
+    jobs.emplace_back(new IcpJob());
+    IcpJob& J = *jobs.back();
+    J.st = pooled ? g_icp_pool.st[j] : user;
+    if (pooled) {
+      const hipError_t e = hipStreamWaitEvent(J.st, ready, 0);
+      if (e != hipSuccess) { (void)hipEventDestroy(ready); return fail(PPF_ERR_HIP, "ICP: hipStreamWaitEvent failed: %s", hipGetErrorString(e)); }
+    }
+  }
+  if (ready) (void)hipEventDestroy(ready);
   return PPF_OK;
 }
 
@@ -1811,14 +1910,22 @@ void icp_append_pose(ppf_pose* p, const double* inc, double residual) {
 
 ppf_status icp_refine_device(const float* d_model, int n, int mstride, const float* d_scene, int nd, int sstride,
                              const ppf_icp_params* prm, ppf_pose* poses, int n_poses, int* iters, hipStream_t st) {
-  IcpScratch sc;
-  for (int k = 0; k < n_poses; k++) {
-    double inc[16], res = 0;
-    int it = 0;
-    ppf_status s = icp_register(d_model, n, mstride, d_scene, nd, sstride, *prm, poses[k].pose, sc, st, inc, &res, &it);
+  for (int k0 = 0; k0 < n_poses; k0 += ICP_MAX_JOBS) {
+    const int cnt = std::min(ICP_MAX_JOBS, n_poses - k0);
+    std::vector<std::unique_ptr<IcpJob>> jobs;
+    std::unique_lock<std::mutex> pool_lock;
+    ppf_status s = icp_make_jobs(cnt, st, jobs, pool_lock);
     if (s != PPF_OK) return s;
-    icp_append_pose(&poses[k], inc, res);
-    if (iters) iters[k] = it;
+    const double* init[ICP_MAX_JOBS];
+    double inc[ICP_MAX_JOBS * 16], res[ICP_MAX_JOBS];
+    int it[ICP_MAX_JOBS];
+    for (int j = 0; j < cnt; j++) init[j] = poses[k0 + j].pose;
+    s = icp_register_many(d_model, n, mstride, d_scene, nd, sstride, *prm, init, jobs, inc, res, it);
+    if (s != PPF_OK) return s;
+    for (int j = 0; j < cnt; j++) {
+      icp_append_pose(&poses[k0 + j], inc + j * 16, res[j]);
+      if (iters) iters[k0 + j] = it[j];
+    }
   }
   return PPF_OK;
 }
@@ -1870,8 +1977,10 @@ ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const floa
   DevBuf<float> dsrc, ddst;
   if ((s = icp_upload(src, n_src, sstride, dsrc)) != PPF_OK) return s;
   if ((s = icp_upload(dst, n_dst, dstride, ddst)) != PPF_OK) return s;
-  IcpScratch sc;
-  return icp_register(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, sc, nullptr, pose16_out, residual_out, iterations_out);
+  std::vector<std::unique_ptr<IcpJob>> jobs;
+  std::unique_lock<std::mutex> pool_lock;
+  if ((s = icp_make_jobs(1, nullptr, jobs, pool_lock)) != PPF_OK) return s;
+  return icp_register_many(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, jobs, pose16_out, residual_out, iterations_out);
 }
 
 /* ---- helpers on the path's edges, on the device like everything else ---------------------------------------- */

@@ -154,6 +154,16 @@ __global__ __launch_bounds__(256) void k_icp_center_scale(float* __restrict__ c,
   for (int k = 0; k < 3; k++) p[k] = mode == 0 ? (float)((double)p[k] - st->mean_avg[k]) : (float)((double)p[k] * st->scale);
 }
 
+struct IcpMat44 {
+  double m[16];
+};
+/* state->T = T (the pose applied when a level starts / the initial pose): by kernel argument, so that several
+ * registrations can be enqueued on different streams without pageable host copies serialising them */
+__global__ void k_icp_set_pose(IcpState* __restrict__ st, IcpMat44 T) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int k = 0; k < 16; k++) st->T[k] = T.m[k];
+}
+
 __global__ void k_icp_level_init(IcpState* __restrict__ st, double tol_p, int max_iter, int robust) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int k = 0; k < 16; k++) st->PoseX[k] = (k % 5 == 0) ? 1.0 : 0.0;
