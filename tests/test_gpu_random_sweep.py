@@ -1,0 +1,70 @@
+"""Seeded random sweep of the hot path against the oracle: 24 configurations drawn over model shape and sampling
+step, alpha resolution, distance-step rule, scene size / sampling / reference stride, presampled or not, surface or
+surface-to-boundary matching, clustering thresholds, forced accumulator tiling.  Every one must give bit-exact vote
+triples, vote and pair totals, bit-identical raw poses and the oracle's clustered poses (the bar of
+tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from yolo_ppf_pose_estimation_amd import synth
+from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["bottle", "box", "cylinder", "torus"]
+
+
+def _draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    cfg = dict(kind=KINDS[int(rng.integers(0, 4))],
+               train_step=float(rng.choice([0.04, 0.05, 0.0625, 0.08, 0.1])),
+               dist_step=float(rng.choice([0.03, 0.05, 0.08])),
+               num_angles=int(rng.choice([15, 24, 30, 40])),
+               n_scene=int(rng.integers(600, 4000)),
+               scene_seed=int(rng.integers(0, 10 ** 6)),
+               presampled=bool(rng.integers(0, 2)),
+               ref_step=float(rng.choice([1.0 / 3.0, 1.0 / 7.0, 1.0 / 10.0, 1.0 / 25.0])),
+               scene_dist=float(rng.choice([0.03, 0.05, 0.07])),
+               s2b=bool(rng.integers(0, 3) == 0),
+               weighted=bool(rng.integers(0, 4) == 0),
+               pos_thr=float(rng.choice([-1.0, 0.02, 0.08])),
+               rot_thr=float(rng.choice([-1.0, 0.2, 0.6])),
+               max_tile_refs=int(rng.choice([0, 0, 37, 150])))
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(bottle, seed):
+    cfg = _draw(seed)
+    model = bottle if cfg["kind"] == "bottle" else synth.make_solid(cfg["kind"], 6000, seed=seed + 1)
+    det = PPF3DDetector(cfg["train_step"], cfg["dist_step"], cfg["num_angles"], max_tile_refs=cfg["max_tile_refs"])
+    det.trainModel(model)
+    ora = O.OracleDetector(cfg["train_step"], cfg["dist_step"], cfg["num_angles"]).train_model(model)
+    det.setSearchParams(cfg["pos_thr"], cfg["rot_thr"], cfg["weighted"])
+    ora.set_search_params(cfg["pos_thr"], cfg["rot_thr"], cfg["weighted"])
+    info, oinfo = det.info(), ora.info()
+    assert (info["n_ref"], info["num_angles"], info["slots"]) == (oinfo["n_ref"], oinfo["num_angles"], oinfo["slots"])
+    if cfg["max_tile_refs"]:
+        assert info["tile_refs"] <= cfg["max_tile_refs"]
+    scene, _ = synth.make_scene(model, n_points=cfg["n_scene"], seed=cfg["scene_seed"])
+    edge = None
+    if cfg["s2b"]:
+        rng = np.random.default_rng(seed)
+        edge = scene[rng.random(scene.shape[0]) < 0.3]
+        if not cfg["presampled"]:
+            edge = edge + 0.0  # same rows as the surface cloud: exercises the "never pair a point with itself" rule
+    got = det.raw_votes(scene, cfg["ref_step"], cfg["scene_dist"], presampled=cfg["presampled"], edge=edge)
+    want = ora.match(scene, edge=edge, relative_scene_sample_step=cfg["ref_step"], relative_scene_distance=cfg["scene_dist"],
+                     presampled=cfg["presampled"], cluster=True)
+    assert got["n_ref"] == want["n_ref"], cfg
+    np.testing.assert_array_equal(got["triples"], want["triples"], err_msg=str(cfg))
+    assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum()), cfg
+    assert got["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum()), cfg
+    for g, w in zip(got["raw_poses"], want["raw_poses"]):
+        assert np.array_equal(g.pose, w["pose"]), cfg
+    poses = det.match(scene, cfg["ref_step"], cfg["scene_dist"], presampled=cfg["presampled"], edge=edge)
+    assert len(poses) == want["n_final"], cfg
+    for g, w in zip(poses, want["poses"]):
+        assert g.numVotes == w["num_votes"], cfg
+        np.testing.assert_allclose(g.pose, w["pose"], rtol=0, atol=1e-9, err_msg=str(cfg))
