@@ -1782,6 +1782,14 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
       J.launched = 0;
       J.active = true;
     }
+    static std::once_flag once_thr;
+    static hipError_t attr_thr = hipSuccess;
+    std::call_once(once_thr, [] {
+      attr_thr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_icp_threshold), hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
+    });
+    HIPCHK(attr_thr);
+    const int staged = ns <= 32768 ? 1 : 0; /* the level's distances fit LDS (4 bytes each): the selection passes read them there */
+    const bool small = ns <= ICP_SMALL_NS && !getenv("PPF_ICP_NO_SMALL"); /* the whole level in one workgroup, one launch */
     for (bool any = true; any;) {
       for (auto& jp : jobs) {
         IcpJob& J = *jp;
@@ -1789,17 +1797,23 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
         IcpScratch& sc = J.sc;
         IcpState* d_st = sc.state.p;
         hipStream_t st = J.st;
-        const int batch = std::min(icp_batch, max_iter - J.launched);
-        for (int b = 0; b < batch; b++) {
-          k_icp_nn<<<dim3(gx, gy), dim3(256), 0, st>>>(sc.moved.p, ns, sc.q4.p, nd, slice, sc.best.p, d_st);
-          k_icp_threshold<<<dim3(1), dim3(1024), 0, st>>>(sc.best.p, ns, prm.rejection_scale, sc.owner.p, nd, d_st);
-          k_icp_owner<<<grid(ns, 256), dim3(256), 0, st>>>(sc.best.p, ns, sc.owner.p, d_st);
-          k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
-          k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
-          k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
-          k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
+        if (small) {
+          k_icp_level_small<<<dim3(1), dim3(1024), 0, st>>>(sc.src_pct.p, ns, sc.q4.p, sc.dst_pcs.p, nd, sc.owner.p, prm.rejection_scale, d_st);
+          J.launched = max_iter;
+        } else {
+          const int batch = std::min(icp_batch, max_iter - J.launched);
+          for (int b = 0; b < batch; b++) {
+            k_icp_nn<<<dim3(gx, gy), dim3(256), 0, st>>>(sc.moved.p, ns, sc.q4.p, nd, slice, sc.best.p, d_st);
+            k_icp_threshold<<<dim3(1), dim3(1024), staged ? (size_t)ns * 4 : 0, st>>>(sc.best.p, ns, prm.rejection_scale, sc.owner.p, nd,
+                                                                                     staged, d_st);
+            k_icp_owner<<<grid(ns, 256), dim3(256), 0, st>>>(sc.best.p, ns, sc.owner.p, d_st);
+            k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
+            k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
+            k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
+            k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
+          }
+          J.launched += std::max(batch, 0);
         }
-        J.launched += std::max(batch, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(J.h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
       }

@@ -240,24 +240,28 @@ __device__ uint32_t icp_block_select(F val, int n, uint32_t rank, uint32_t* hist
   return prefix;
 }
 
-/* getRejectionThreshold: median + scale * 1.48257968 * MAD; also clears the ownership keys of the scene points */
+/* getRejectionThreshold: median + scale * 1.48257968 * MAD; also clears the ownership keys of the scene points.
+ * The eight selection passes read the distances from LDS (dynamic, ns*4 bytes, staged once) when `staged`. */
 __global__ __launch_bounds__(1024) void k_icp_threshold(const unsigned long long* __restrict__ best, int ns, float rej_scale,
-                                                        unsigned long long* __restrict__ owner, int nd, IcpState* __restrict__ st) {
+                                                        unsigned long long* __restrict__ owner, int nd, int staged,
+                                                        IcpState* __restrict__ st) {
   if (st->done) return;
+  extern __shared__ uint32_t s_bits[];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sh[2];
   const int tid = threadIdx.x;
   for (int b = tid; b < nd; b += blockDim.x) owner[b] = ICP_NONE;
   if (!st->robust) return;
+  if (staged) {
+    for (int i = tid; i < ns; i += blockDim.x) s_bits[i] = (uint32_t)(best[i] >> 32);
+    __syncthreads();
+  }
   const uint32_t rank = (uint32_t)((ns - 1) / 2);
-  const uint32_t med_bits = icp_block_select([&](int i) { return (uint32_t)(best[i] >> 32); }, ns, rank, hist, sh);
+  auto dist_bits = [&](int i) { return staged ? s_bits[i] : (uint32_t)(best[i] >> 32); };
+  const uint32_t med_bits = icp_block_select(dist_bits, ns, rank, hist, sh);
   const float med = __uint_as_float(med_bits);
   const uint32_t mad_bits = icp_block_select(
-      [&](int i) {
-        const float r = __uint_as_float((uint32_t)(best[i] >> 32));
-        return __float_as_uint((float)ppf_fabs((double)r - (double)med));
-      },
-      ns, rank, hist, sh);
+      [&](int i) { return __float_as_uint((float)ppf_fabs((double)__uint_as_float(dist_bits(i)) - (double)med)); }, ns, rank, hist, sh);
   if (tid == 0) {
     const float s = 1.48257968f * __uint_as_float(mad_bits);
     st->thr = rej_scale * s + med;
@@ -418,6 +422,234 @@ __global__ __launch_bounds__(64) void k_icp_solve(const double* __restrict__ par
   st->iter = it;
   const double tp = st->tol_p;
   st->done = (!(perc < (1 + tp) && perc > (1 - tp)) && it < st->max_iter) ? 0 : 1;
+}
+
+/* ---- coarse levels: the whole level in ONE workgroup ---------------------------------------------------------
+ * The pyramid's coarse levels hold a few hundred to ~2000 model rows; seven launches and a host round trip per
+ * iteration cost far more than their arithmetic.  For ns <= ICP_SMALL_NS one 1024-thread workgroup runs the level's
+ * complete loop: the same steps with the same arithmetic and orders as the kernels above (NN search in registers,
+ * radix-select threshold over LDS, ownership by global atomicMin, ordered compaction, chunk sums by waves, solve by
+ * thread 0), separated by workgroup barriers instead of kernel boundaries, until the loop condition fails.  One
+ * launch per level, no intermediate read-back; results are bit-identical to the multi-kernel path. */
+constexpr int ICP_SMALL_NS = 2048;
+constexpr int ICP_SMALL_VAL = 4; /* chunk row buffers (waves working on chunk sums at a time) */
+
+/* ownership keys are produced by global atomics of this workgroup's other waves: read them at the coherence point */
+__device__ __forceinline__ unsigned long long icp_ld(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void k_icp_level_small(const float* __restrict__ src_pct, int ns, const float4* __restrict__ q4,
+                                                          const float* __restrict__ dst_pcs, int nd, unsigned long long* __restrict__ owner,
+                                                          float rej_scale, IcpState* __restrict__ st) {
+  __shared__ float s_dist[ICP_SMALL_NS];
+  __shared__ int s_nn[ICP_SMALL_NS];
+  __shared__ int2 s_sel[ICP_SMALL_NS];
+  __shared__ double s_val[ICP_SMALL_VAL][ICP_CHUNK][9];
+  __shared__ double s_parts[ICP_SMALL_NS / ICP_CHUNK][ICP_ENTRIES];
+  __shared__ double s_pose[16], s_tot[ICP_ENTRIES], s_M[6][7];
+  __shared__ double s_fval_old, s_fval_perc, s_fval_min;
+  __shared__ uint32_t hist[256], sh[2], wsum[16];
+  __shared__ float s_thr;
+  __shared__ int s_done, s_iter, s_nsel;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int robust = st->robust, max_iter = st->max_iter;
+  const double tol_p = st->tol_p;
+  if (tid == 0) {
+    s_done = st->done; s_iter = st->iter; s_nsel = 0;
+    s_fval_old = st->fval_old; s_fval_perc = st->fval_perc; s_fval_min = st->fval_min;
+    for (int k = 0; k < 16; k++) s_pose[k] = st->PoseX[k];
+  }
+  __syncthreads();
+  while (!s_done) {
+    /* 1. nearest neighbours: up to two model points per thread, one pass over the scene (uniform index: scalar loads) */
+    float px[2] = {0.f, 0.f}, py[2] = {0.f, 0.f}, pz[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int a = tid + u * 1024;
+      if (a < ns) {
+        const float* p = src_pct + (size_t)a * 6;
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          v[r] = s_pose[r * 4] * (double)p[0] + s_pose[r * 4 + 1] * (double)p[1] + s_pose[r * 4 + 2] * (double)p[2] + s_pose[r * 4 + 3];
+        if (ppf_fabs(v[3]) > PPF_EPS) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
+        px[u] = (float)v[0]; py[u] = (float)v[1]; pz[u] = (float)v[2];
+      }
+    }
+    float bd[2] = {3.402823466e+38f, 3.402823466e+38f};
+    int bi[2] = {0, 0};
+    for (int b = 0; b < nd; b++) {
+      const float4 q = q4[b];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const float dx = px[u] - q.x, dy = py[u] - q.y, dz = pz[u] - q.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < bd[u]) { bd[u] = d2; bi[u] = b; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int a = tid + u * 1024;
+      if (a < ns) { s_dist[a] = bd[u]; s_nn[a] = bi[u]; }
+    }
+    for (int b = tid; b < nd; b += 1024) __hip_atomic_store(&owner[b], ICP_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    /* 2. rejection threshold */
+    if (robust) {
+      const uint32_t rank = (uint32_t)((ns - 1) / 2);
+      const uint32_t med_bits = icp_block_select([&](int i) { return __float_as_uint(s_dist[i]); }, ns, rank, hist, sh);
+      const float med = __uint_as_float(med_bits);
+      const uint32_t mad_bits = icp_block_select(
+          [&](int i) { return __float_as_uint((float)ppf_fabs((double)s_dist[i] - (double)med)); }, ns, rank, hist, sh);
+      if (tid == 0) {
+        const float sc = 1.48257968f * __uint_as_float(mad_bits);
+        s_thr = rej_scale * sc + med;
+      }
+      __syncthreads();
+    }
+    /* 3. picky ownership */
+    for (int a = tid; a < ns; a += 1024) {
+      const float d = s_dist[a];
+      if (!robust || d < s_thr) atomicMin(&owner[s_nn[a]], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)a);
+    }
+    __syncthreads();
+    /* 4. ordered compaction */
+    {
+      const int per = (nd + 1023) / 1024;
+      const int b0 = min(nd, tid * per), b1 = min(nd, b0 + per);
+      uint32_t cnt = 0;
+      for (int b = b0; b < b1; b++) cnt += icp_ld(&owner[b]) != ICP_NONE;
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t base = 0, total = 0;
+      for (int w = 0; w < 16; w++) {
+        if (w < wave) base += wsum[w];
+        total += wsum[w];
+      }
+      uint32_t pos = base + incl - cnt;
+      for (int b = b0; b < b1; b++) {
+        const unsigned long long o = icp_ld(&owner[b]);
+        if (o != ICP_NONE) s_sel[pos++] = make_int2((int)(uint32_t)o, b);
+      }
+      if (tid == 0) {
+        s_nsel = (int)total;
+        if (total <= 6) s_done = 1; /* `if (selInd <= 6) break;` */
+      }
+      __syncthreads();
+    }
+    if (s_done) break;
+    /* 5. chunk sums: waves 0..ICP_SMALL_VAL-1 take the chunks round-robin */
+    const int n_sel = s_nsel;
+    const int n_chunks = (n_sel + ICP_CHUNK - 1) / ICP_CHUNK;
+    if (wave < ICP_SMALL_VAL) {
+      double (*val)[9] = s_val[wave];
+      for (int c = wave; c < n_chunks; c += ICP_SMALL_VAL) {
+        const int c0 = c * ICP_CHUNK, rows = min(ICP_CHUNK, n_sel - c0);
+        if (lane < rows) {
+          const int2 ab = s_sel[c0 + lane];
+          const float* sp_ = src_pct + (size_t)ab.x * 6;
+          const float* d = dst_pcs + (size_t)ab.y * 6;
+          const double sp[3] = {(double)sp_[0], (double)sp_[1], (double)sp_[2]}, dp[3] = {(double)d[0], (double)d[1], (double)d[2]},
+                       nr[3] = {(double)d[3], (double)d[4], (double)d[5]};
+          const double sub[3] = {dp[0] - sp[0], dp[1] - sp[1], dp[2] - sp[2]};
+          val[lane][0] = sp[1] * nr[2] - sp[2] * nr[1];
+          val[lane][1] = sp[2] * nr[0] - sp[0] * nr[2];
+          val[lane][2] = sp[0] * nr[1] - sp[1] * nr[0];
+          val[lane][3] = nr[0]; val[lane][4] = nr[1]; val[lane][5] = nr[2];
+          val[lane][6] = sub[0] * nr[0] + sub[1] * nr[1] + sub[2] * nr[2];
+          double e = 0;
+#pragma unroll
+          for (int cc = 0; cc < 6; cc++) { const double df = (double)sp_[cc] - (double)d[cc]; e += df * df; }
+          val[lane][7] = e;
+          val[lane][8] = 1.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ICP_ENTRIES) {
+          int i = 0, j = 0;
+          if (lane < 21) {
+            int t = lane;
+            while (t >= 6 - i) { t -= 6 - i; i++; }
+            j = i + t;
+          } else if (lane < 27) { i = lane - 21; j = 6; }
+          else { i = 7; j = 8; }
+          double acc = 0;
+          for (int k = 0; k < rows; k++) acc += val[k][i] * val[k][j];
+          s_parts[c][lane] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    /* 6. chunk sums in chunk order, solve, loop state */
+    if (tid < ICP_ENTRIES) {
+      double acc = 0;
+      for (int c = 0; c < n_chunks; c++) acc += s_parts[c][tid];
+      s_tot[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int e = 0;
+      for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) { s_M[i][j] = s_tot[e]; s_M[j][i] = s_tot[e]; e++; }
+      for (int i = 0; i < 6; i++) s_M[i][6] = s_tot[21 + i];
+      const double fsum = s_tot[27];
+      double trace = 0;
+      for (int i = 0; i < 6; i++) trace += s_M[i][i];
+      bool ok = trace > 0.0;
+      if (ok) {
+        const double lambda = 1e-10 * trace;
+        for (int i = 0; i < 6; i++) s_M[i][i] += lambda;
+        for (int c = 0; c < 6 && ok; c++) {
+          int piv = c;
+          for (int r = c + 1; r < 6; r++) if (ppf_fabs(s_M[r][c]) > ppf_fabs(s_M[piv][c])) piv = r;
+          if (ppf_fabs(s_M[piv][c]) < 1e-300) { ok = false; break; }
+          if (piv != c) for (int k = 0; k < 7; k++) { const double tmp = s_M[c][k]; s_M[c][k] = s_M[piv][k]; s_M[piv][k] = tmp; }
+          for (int r = c + 1; r < 6; r++) {
+            const double f = s_M[r][c] / s_M[c][c];
+            for (int k = c; k < 7; k++) s_M[r][k] -= f * s_M[c][k];
+          }
+        }
+      }
+      if (ok) {
+        for (int c = 5; c >= 0; c--) {
+          double sacc = s_M[c][6];
+          for (int k = c + 1; k < 6; k++) sacc -= s_M[c][k] * s_M[k][6];
+          s_M[c][6] = sacc / s_M[c][c];
+        }
+        const double rpy[3] = {s_M[0][6], s_M[1][6], s_M[2][6]}, t[3] = {s_M[3][6], s_M[4][6], s_M[5][6]};
+        if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) ok = false;
+        if (ok) {
+          double P[16];
+          icp_transform_from_euler(rpy, t, P);
+          for (int k = 0; k < 16; k++) s_pose[k] = P[k];
+          const double fval = ppf_sqrt(fsum) / (double)ns;
+          const double perc = fval / s_fval_old;
+          s_fval_perc = perc;
+          s_fval_old = fval;
+          if (fval < s_fval_min) s_fval_min = fval;
+          const int it = s_iter + 1;
+          s_iter = it;
+          s_done = (!(perc < (1 + tol_p) && perc > (1 - tol_p)) && it < max_iter) ? 0 : 1;
+        }
+      }
+      if (!ok) s_done = 1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int k = 0; k < 16; k++) st->PoseX[k] = s_pose[k];
+    st->fval_old = s_fval_old; st->fval_perc = s_fval_perc; st->fval_min = s_fval_min;
+    st->iter = s_iter; st->n_sel = s_nsel; st->done = 1;
+  }
 }
 
 #endif /* PPF_ICP_KERNELS_H */
