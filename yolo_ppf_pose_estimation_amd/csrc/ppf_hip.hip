@@ -401,27 +401,31 @@ __global__ void k_finalize(FinalArgs a) {
  * 4. clusters ranked by (votes desc, creation order asc) and written out.
  */
 /* Generic ranking: perm[rank] = i and rank_of[i] = rank for keys sorted (key desc, index asc).  n may live on the
- * device (n_dev != nullptr).  O(n^2) over many workgroups; the inner index is wave-uniform (scalar loads). */
+ * device (n_dev != nullptr).  O(n^2) spread wide: a workgroup ranks 16 keys, 16 threads per key each counting every
+ * 16th key of a 1024-key LDS tile, partial counts added by shuffles. */
+constexpr int RANK_KEYS = 16; /* keys per workgroup of 256 threads */
 __global__ __launch_bounds__(256) void k_rank(const unsigned long long* __restrict__ keys, int n_host,
                                               const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ perm,
                                               uint32_t* __restrict__ rank_of) {
+  __shared__ unsigned long long tile[1024];
   const int n = n_dev ? (int)*n_dev : n_host;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long ki = keys[i];
+  if ((int)(blockIdx.x * RANK_KEYS) >= n) return; /* whole workgroup out of range */
+  const int i = blockIdx.x * RANK_KEYS + (threadIdx.x >> 4), part = threadIdx.x & 15;
+  const unsigned long long ki = i < n ? keys[i] : 0ull;
   uint32_t rank = 0;
-  int j = 0;
-  for (; j + 4 <= n; j += 4) {
-    const unsigned long long k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
-    rank += (k0 > ki || (k0 == ki && j < i)) ? 1u : 0u;
-    rank += (k1 > ki || (k1 == ki && j + 1 < i)) ? 1u : 0u;
-    rank += (k2 > ki || (k2 == ki && j + 2 < i)) ? 1u : 0u;
-    rank += (k3 > ki || (k3 == ki && j + 3 < i)) ? 1u : 0u;
+  for (int j0 = 0; j0 < n; j0 += 1024) {
+    const int cnt = min(1024, n - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) tile[t] = keys[j0 + t];
+    __syncthreads();
+    for (int t = part; t < cnt; t += 16) {
+      const unsigned long long kj = tile[t];
+      rank += (kj > ki || (kj == ki && j0 + t < i)) ? 1u : 0u; /* keys before position i win ties */
+    }
   }
-  for (; j < n; j++) {
-    const unsigned long long kj = keys[j];
-    rank += (kj > ki || (kj == ki && j < i)) ? 1u : 0u;
-  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) rank += (uint32_t)__shfl_xor((int)rank, o);
+  if (i >= n || part != 0) return;
   if (perm) perm[rank] = (uint32_t)i;
   if (rank_of) rank_of[i] = rank;
 }
@@ -472,7 +476,11 @@ __device__ __forceinline__ bool pose_matches(double hx, double hy, double hz, do
   return ppf_sqrt(d2) < pos_thr;
 }
 
-constexpr int CL_BLOCK = 256;            /* poses resolved per round */
+#ifndef PPF_CL_BLOCK
+#define PPF_CL_BLOCK 64
+#endif
+constexpr int CL_BLOCK = PPF_CL_BLOCK;   /* poses resolved per round (64/128/256) */
+constexpr int CL_PARTS = 1024 / CL_BLOCK; /* threads per pose in step A */
 constexpr int CL_SLOTS = CL_BLOCK / 64;  /* clusters opened in a round, held in registers: slot i of lane l = i*64 + l */
 
 template <bool IN_LDS>
@@ -493,9 +501,9 @@ __global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
   __syncthreads();
   for (int s0 = 0; s0 < np; s0 += CL_BLOCK) {
     const uint32_t nc0 = s_nclusters;
-    /* A. clusters that existed before this round: 4 threads per pose, each scanning every 4th cluster in
-     *    ascending order; the first match overall is the minimum over the 4 (atomicMin). */
-    const int pl = tid & (CL_BLOCK - 1), part = tid >> 8;
+    /* A. clusters that existed before this round: CL_PARTS threads per pose, each scanning every CL_PARTS-th
+     *    cluster in ascending order; the first match overall is the minimum over them (atomicMin). */
+    const int pl = tid & (CL_BLOCK - 1), part = tid / CL_BLOCK;
     const int s = s0 + pl;
     if (part == 0) {
       if (s < np) {
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
     __syncthreads();
     if (s < np) {
       const double tx = s_pose[0][pl], ty = s_pose[1][pl], tz = s_pose[2][pl], ang = s_pose[3][pl];
-      for (uint32_t c = (uint32_t)part; c < nc0; c += 4) {
+      for (uint32_t c = (uint32_t)part; c < nc0; c += CL_PARTS) {
         if (pose_matches(hx[c], hy[c], hz[c], ha[c], tx, ty, tz, ang, a.pos_thr, pos_thr2, a.rot_thr)) {
           atomicMin(&s_match[pl], c);
           break;
@@ -529,18 +537,13 @@ __global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
       for (int c0 = 0; c0 < cnt; c0 += 64) {
         const int kk = min(c0 + lane, CL_BLOCK - 1);
         const bool un = (c0 + lane) < cnt && s_match[kk] == 0xFFFFFFFFu;
-        const double ltx = s_pose[0][kk], lty = s_pose[1][kk], ltz = s_pose[2][kk], lang = s_pose[3][kk];
-        const uint32_t lpi = s_order[kk];
         unsigned long long mask = __ballot(un);
         while (mask) {
           const int l = __ffsll((long long)mask) - 1;
           mask &= mask - 1;
-          auto bc = [&](double v) { /* broadcast lane l's double */
-            const uint64_t b = ppf_d2bits(v);
-            return ppf_bits2d((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l) |
-                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l) << 32));
-          };
-          const double tx = bc(ltx), ty = bc(lty), tz = bc(ltz), ang = bc(lang);
+          /* pose l of the chunk, read by every lane from the same LDS address (broadcast) */
+          const int kl = c0 + l;
+          const double tx = s_pose[0][kl], ty = s_pose[1][kl], tz = s_pose[2][kl], ang = s_pose[3][kl];
           uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
           for (int i = 0; i < CL_SLOTS; i++) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
               if ((uint32_t)(i * 64 + lane) == nnew) { rx[i] = tx; ry[i] = ty; rz[i] = tz; ra[i] = ang; }
             }
             if (lane == 0) {
-              a.head[m] = (uint32_t)__builtin_amdgcn_readlane((int)lpi, l);
+              a.head[m] = s_order[kl];
               hx[m] = tx; hy[m] = ty; hz[m] = tz; ha[m] = ang;
             }
             nnew++;
@@ -616,12 +619,22 @@ __global__ __launch_bounds__(1024) void k_cluster_offsets(ClusterArgs a) {
 /* gather the members' q, t, votes into member-slot order = joining order: the joining index of a pose is
  * the number of earlier (rank order) poses of the same cluster */
 __global__ __launch_bounds__(256) void k_cluster_members(ClusterArgs a) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t tile[1024];
   const int np = min(a.num_poses, a.n);
+  if ((int)(blockIdx.x * blockDim.x) >= np) return; /* whole workgroup out of range */
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = s < np ? a.assign[s] : 0xFFFFFFFFu;
+  uint32_t rin = 0; /* earlier poses of the same cluster = this pose's position among the members */
+  const int last = min(np, (int)((blockIdx.x + 1) * blockDim.x)); /* no thread of the workgroup looks past its own s */
+  for (int j0 = 0; j0 < last; j0 += 1024) {
+    const int cnt = min(1024, last - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) tile[t] = a.assign[j0 + t];
+    __syncthreads();
+    const int upto = min(max(s - j0, 0), cnt);
+    for (int t = 0; t < upto; t++) rin += tile[t] == c ? 1u : 0u;
+  }
   if (s >= np) return;
-  const uint32_t c = a.assign[s];
-  uint32_t rin = 0;
-  for (int e = 0; e < np; e++) rin += (e < s && a.assign[e] == c) ? 1u : 0u; /* e is wave-uniform: scalar loads */
   const uint32_t slot = a.coff[c] + rin;
   const ppf_pose& p = a.in[a.order[s]];
   double* g = a.gq + (size_t)slot * 7;
@@ -912,13 +925,13 @@ ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int n
     HIPCHK(attr_c);
     const unsigned nb = (unsigned)((n + 255) / 256);
     k_vote_keys<<<dim3(nb), dim3(256), 0, st>>>(d_in, n, vkeys);
-    k_rank<<<dim3(nb), dim3(256), 0, st>>>(vkeys, n, nullptr, order, nullptr);            /* (votes desc, index asc) */
+    k_rank<<<dim3((unsigned)((n + RANK_KEYS - 1) / RANK_KEYS)), dim3(256), 0, st>>>(vkeys, n, nullptr, order, nullptr);            /* (votes desc, index asc) */
     if (n <= CLUSTER_LDS_MAX) k_cluster_assign<true><<<dim3(1), dim3(1024), (size_t)n * 32 + 64, st>>>(ca);
     else k_cluster_assign<false><<<dim3(1), dim3(1024), 0, st>>>(ca);
     k_cluster_sizes<<<dim3(nb), dim3(256), 0, st>>>(ca);
     k_cluster_offsets<<<dim3(1), dim3(1024), 0, st>>>(ca);
     k_cluster_members<<<dim3(nb), dim3(256), 0, st>>>(ca);
-    k_rank<<<dim3(nb), dim3(256), 0, st>>>(ca.cvotes, 0, ca.n_out, nullptr, ca.crank);    /* (cluster votes desc, creation asc) */
+    k_rank<<<dim3((unsigned)((n + RANK_KEYS - 1) / RANK_KEYS)), dim3(256), 0, st>>>(ca.cvotes, 0, ca.n_out, nullptr, ca.crank);    /* (cluster votes desc, creation asc) */
     k_cluster_finish<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(ca);
     HIPCHK(hipGetLastError());
   }
@@ -1335,7 +1348,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     HIPCHK(hipGetLastError());
     k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), group_lds, st>>>(va);
     HIPCHK(hipGetLastError());
-    k_rank<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
+    k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
     if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[1], st));
     k_vote<<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
