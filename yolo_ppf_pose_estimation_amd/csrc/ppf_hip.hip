@@ -1330,7 +1330,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   const int pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
   /* k_group: one LDS counter per bucket when that fits (<= 30k buckets), else the radix-sort path */
   va.group_lds_buckets = m->info.n_buckets <= 30000 ? (int)m->info.n_buckets : 0;
-  const size_t group_lds = va.group_lds_buckets ? ((size_t)va.group_lds_buckets + 1 + 16) * sizeof(uint32_t) : 0;
+  const size_t group_lds = va.group_lds_buckets ? ((size_t)va.group_lds_buckets + 1 + 16) * sizeof(uint32_t)
+                                                : (size_t)(GROUP_BLOCK / 64) * 256 * sizeof(uint32_t);
   static std::once_flag once_g;
   static hipError_t attr_g = hipSuccess;
   std::call_once(once_g, [] {

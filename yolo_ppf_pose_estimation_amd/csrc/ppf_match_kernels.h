@@ -274,7 +274,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
  */
 __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   __shared__ uint32_t base[256];
-  __shared__ uint32_t wcnt[GROUP_BLOCK / 64][256];
+  extern __shared__ uint32_t gcnt[]; /* LDS path: one counter per bucket (+ wave totals); radix path: wcnt[16][256] */
   const int r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t n = a.hit_count[r];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     /* Grouping only needs equal buckets to be adjacent (any order inside a bucket: votes commute), so when one
      * counter per bucket fits in LDS a single counting pass does it: histogram, scan, scatter through cursors.
      * Retired hits (key 0xFFFFFFFF) go to the extra last counter. */
-    extern __shared__ uint32_t gcnt[];           /* group_lds_buckets + 1 counters, then 16 wave totals */
+    /* gcnt: group_lds_buckets + 1 counters, then 16 wave totals */
     const int nb1 = a.group_lds_buckets + 1;
     uint32_t* wtot = gcnt + nb1;
     for (int k = tid; k < nb1; k += GROUP_BLOCK) gcnt[k] = 0;
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     for (uint32_t i = tid; i < n; i += GROUP_BLOCK) src[i] = dst[i];
     return;
   }
+  uint32_t (*wcnt)[256] = reinterpret_cast<uint32_t (*)[256]>(gcnt);
   const int passes = (a.key_bits + 7) / 8;
   for (int pass = 0; pass < passes; pass++) {
     const int shift = pass * 8;
