@@ -456,7 +456,7 @@ __device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes
                                            const float S, const float Ohg, const double* __restrict__ asd_lds,
                                            const float G2, const int A) {
   int ka[U], kb[U];
-  float frmin = 1.0f;
+  float fa[U], fb[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
     /* two scalar v_fma_f32: measured faster than one v_pk_fma_f32 on gfx950 (compute-only k_vote 10.0 vs 13.0 ms) */
@@ -464,7 +464,20 @@ __device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes
     const float qb = __builtin_fmaf(__uint_as_float(rec[u].w), S, Ohg);
     ka[u] = (int)qa;
     kb[u] = (int)qb;
-    frmin = fminf(frmin, fminf(__builtin_amdgcn_fractf(qa), __builtin_amdgcn_fractf(qb)));
+    fa[u] = __builtin_amdgcn_fractf(qa);
+    fb[u] = __builtin_amdgcn_fractf(qb);
+  }
+  /* smallest fractional part of the 2U votes with as few v_min3_f32 as possible (3 inputs each) */
+  float frmin = fa[0];
+  {
+    float pend[2 * U];
+    int np = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) { if (u) pend[np++] = fa[u]; pend[np++] = fb[u]; }
+    int i = 0;
+#pragma unroll
+    for (; i + 2 <= np; i += 2) frmin = __builtin_fminf(__builtin_fminf(frmin, pend[i]), pend[i + 1]);
+    if (i < np) frmin = __builtin_fminf(frmin, pend[i]);
   }
   if (__builtin_expect(__any(frmin < G2), 0)) {
     const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
