@@ -1721,7 +1721,7 @@ struct IcpJob {
  * kernels, so each runs on its own stream and the host walks them in lock-step: same level, one batch of iterations
  * enqueued on every stream, then one read of every done flag. */
 ppf_status icp_register_many(const float* d_src, int n, int sstride, const float* d_dst, int nd_all, int dstride,
-                             const ppf_icp_params& prm, const double* const* init_poses, std::vector<std::unique_ptr<IcpJob>>& jobs,
+                             const ppf_icp_params& prm, const double* const* init_poses, std::vector<IcpJob*>& jobs,
                              double* poses_out /* jobs x 16 */, double* residuals, int* iters_total) {
   const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
   auto grid = [](size_t items, int block) { return dim3((unsigned)((items + block - 1) / block)); };
@@ -1870,47 +1870,61 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
 
 /* Streams (and pinned state mirrors) for concurrent jobs come from a process-wide pool: creating a HIP stream costs
  * milliseconds, far more than a registration.  One caller at a time owns the pool (others fall back to one stream). */
-struct IcpStreamPool {
+struct IcpPool {
   std::mutex mu;
+  IcpJob jobs[ICP_MAX_JOBS]; /* scratch buffers and pinned state mirrors persist across calls; they only grow */
   hipStream_t st[ICP_MAX_JOBS] = {};
   int device = -1;
   bool ok = false;
 };
-IcpStreamPool g_icp_pool;
+/* never destroyed: its buffers must not be freed after the HIP runtime has shut down at process exit */
+IcpPool& g_icp_pool = *new IcpPool();
 
-ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<std::unique_ptr<IcpJob>>& jobs, std::unique_lock<std::mutex>& pool_lock) {
+/* Jobs for `count` concurrent registrations.  With the pool (one caller at a time; others get private jobs on the
+ * caller's stream) nothing is allocated after the first call: streams, scratch and pinned mirrors are reused.  Pool
+ * streams are ordered after whatever the caller's stream has enqueued so far. */
+ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<IcpJob*>& jobs, std::vector<std::unique_ptr<IcpJob>>& owned,
+                         std::unique_lock<std::mutex>& pool_lock) {
   jobs.clear();
+  owned.clear();
   bool pooled = false;
-  if (count > 1 && !getenv("PPF_ICP_ONE_STREAM")) {
-    pool_lock = std::unique_lock<std::mutex>(g_icp_pool.mu, std::try_to_lock);
-    if (pool_lock.owns_lock()) {
-      int dev = 0;
-      HIPCHK(hipGetDevice(&dev));
-      if (!g_icp_pool.ok || g_icp_pool.device != dev) {
-        for (int j = 0; j < ICP_MAX_JOBS; j++) {
-          if (g_icp_pool.st[j]) (void)hipStreamDestroy(g_icp_pool.st[j]);
-          g_icp_pool.st[j] = nullptr;
-          HIPCHK(hipStreamCreateWithFlags(&g_icp_pool.st[j], hipStreamNonBlocking));
-        }
-        g_icp_pool.device = dev;
-        g_icp_pool.ok = true;
+  pool_lock = std::unique_lock<std::mutex>(g_icp_pool.mu, std::try_to_lock);
+  if (pool_lock.owns_lock()) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (!g_icp_pool.ok || g_icp_pool.device != dev) {
+      for (int j = 0; j < ICP_MAX_JOBS; j++) {
+        if (g_icp_pool.st[j]) (void)hipStreamDestroy(g_icp_pool.st[j]);
+        g_icp_pool.st[j] = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&g_icp_pool.st[j], hipStreamNonBlocking));
+        g_icp_pool.jobs[j].~IcpJob();
+        new (&g_icp_pool.jobs[j]) IcpJob(); /* buffers of another device are dropped */
       }
-      pooled = true;
+      g_icp_pool.device = dev;
+      g_icp_pool.ok = true;
     }
+    pooled = true;
   }
+  const bool own_streams = pooled && count > 1 && !getenv("PPF_ICP_ONE_STREAM");
   hipEvent_t ready = nullptr;
-  if (pooled) {
+  if (own_streams) {
     HIPCHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ready, user));
   }
   for (int j = 0; j < count; j++) {
-    jobs.emplace_back(new IcpJob());
-    IcpJob& J = *jobs.back();
-    J.st = pooled ? g_icp_pool.st[j] : user;
+    IcpJob* J;
     if (pooled) {
-      const hipError_t e = hipStreamWaitEvent(J.st, ready, 0);
+      J = &g_icp_pool.jobs[j];
+    } else {
+      owned.emplace_back(new IcpJob());
+      J = owned.back().get();
+    }
+    J->st = own_streams ? g_icp_pool.st[j] : user;
+    if (own_streams) {
+      const hipError_t e = hipStreamWaitEvent(J->st, ready, 0);
       if (e != hipSuccess) { (void)hipEventDestroy(ready); return fail(PPF_ERR_HIP, "ICP: hipStreamWaitEvent failed: %s", hipGetErrorString(e)); }
     }
+    jobs.push_back(J);
   }
   if (ready) (void)hipEventDestroy(ready);
   return PPF_OK;
@@ -1940,9 +1954,10 @@ ppf_status icp_refine_device(const float* d_model, int n, int mstride, const flo
                              const ppf_icp_params* prm, ppf_pose* poses, int n_poses, int* iters, hipStream_t st) {
   for (int k0 = 0; k0 < n_poses; k0 += ICP_MAX_JOBS) {
     const int cnt = std::min(ICP_MAX_JOBS, n_poses - k0);
-    std::vector<std::unique_ptr<IcpJob>> jobs;
+    std::vector<IcpJob*> jobs;
+    std::vector<std::unique_ptr<IcpJob>> owned;
     std::unique_lock<std::mutex> pool_lock;
-    ppf_status s = icp_make_jobs(cnt, st, jobs, pool_lock);
+    ppf_status s = icp_make_jobs(cnt, st, jobs, owned, pool_lock);
     if (s != PPF_OK) return s;
     const double* init[ICP_MAX_JOBS];
     double inc[ICP_MAX_JOBS * 16], res[ICP_MAX_JOBS];
@@ -2005,9 +2020,10 @@ ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const floa
   DevBuf<float> dsrc, ddst;
   if ((s = icp_upload(src, n_src, sstride, dsrc)) != PPF_OK) return s;
   if ((s = icp_upload(dst, n_dst, dstride, ddst)) != PPF_OK) return s;
-  std::vector<std::unique_ptr<IcpJob>> jobs;
+  std::vector<IcpJob*> jobs;
+  std::vector<std::unique_ptr<IcpJob>> owned;
   std::unique_lock<std::mutex> pool_lock;
-  if ((s = icp_make_jobs(1, nullptr, jobs, pool_lock)) != PPF_OK) return s;
+  if ((s = icp_make_jobs(1, nullptr, jobs, owned, pool_lock)) != PPF_OK) return s;
   return icp_register_many(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, jobs, pose16_out, residual_out, iterations_out);
 }
 
