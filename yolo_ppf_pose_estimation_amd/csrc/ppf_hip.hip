@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -53,6 +54,9 @@ ppf_status fail(ppf_status st, const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   g_last_error = buf;
+  /* error paths return while kernels of the failed call may still run; their scratch goes back to the block cache
+   * (DevPool) as the locals unwind, so drain the device first.  Errors are rare: the cost does not matter. */
+  if (st == PPF_ERR_HIP || st == PPF_ERR_NOMEM || st == PPF_ERR_CAPACITY) (void)hipDeviceSynchronize();
   return st;
 }
 
@@ -63,16 +67,83 @@ ppf_status fail(ppf_status st, const char* fmt, ...) {
       return fail(PPF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
   } while (0)
 
+/* Device memory for scratch and results comes from a process-wide cache of freed blocks (power-of-two size classes
+ * per device): hipMalloc costs tens of microseconds and hipFree synchronises the whole device, which is most of the
+ * time of the small stages (cloud stages, ICP set-up).  A block is only released by a DevBuf whose last user has been
+ * synchronised with (every entry point waits for its kernels before its scratch goes out of scope), so a reused block
+ * is never still in flight.  PPF_NO_POOL=1 turns the cache off. */
+class DevPool {
+ public:
+  static DevPool& get() {
+    static DevPool* p = new DevPool(); /* never destroyed: no hipFree after the runtime is gone */
+    return *p;
+  }
+  hipError_t acquire(size_t bytes, void** out, size_t* granted) {
+    *out = nullptr;
+    const size_t want = std::max<size_t>(bytes, 256);
+    if (off_) { *granted = want; return hipMalloc(out, want); }
+    int cls = 8;
+    while (((size_t)1 << cls) < want) cls++;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto& lst = free_[key(dev, cls)];
+      if (!lst.empty()) { *out = lst.back(); lst.pop_back(); *granted = (size_t)1 << cls; return hipSuccess; }
+    }
+    *granted = (size_t)1 << cls;
+    e = hipMalloc(out, *granted);
+    if (e != hipSuccess) { /* out of memory: drop the cache and retry once */
+      trim();
+      e = hipMalloc(out, *granted);
+    }
+    return e;
+  }
+  void release(void* p, size_t granted) {
+    if (!p) return;
+    if (off_) { (void)hipFree(p); return; }
+    int cls = 8;
+    while (((size_t)1 << cls) < granted) cls++;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> g(mu_);
+    free_[key(dev, cls)].push_back(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& kv : free_) {
+      for (void* p : kv.second) (void)hipFree(p);
+      kv.second.clear();
+    }
+  }
+
+ private:
+  DevPool() : off_(getenv("PPF_NO_POOL") != nullptr) {}
+  static int key(int dev, int cls) { return dev * 64 + cls; }
+  std::mutex mu_;
+  std::map<int, std::vector<void*>> free_;
+  bool off_;
+};
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
-  size_t cap = 0; /* elements */
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  size_t cap = 0;      /* elements usable */
+  size_t granted = 0;  /* bytes of the block behind p */
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { DevPool::get().release(p, granted); }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
-    if (e == hipSuccess) cap = n;
+    if (p) { /* growing a live buffer (rare): earlier asynchronous work may still use the old block */
+      (void)hipDeviceSynchronize();
+      DevPool::get().release(p, granted); p = nullptr; cap = 0; granted = 0;
+    }
+    void* q = nullptr;
+    hipError_t e = DevPool::get().acquire(std::max<size_t>(n, 1) * sizeof(T), &q, &granted);
+    if (e == hipSuccess) { p = static_cast<T*>(q); cap = n; }
     return e;
   }
   size_t bytes() const { return cap * sizeof(T); }
@@ -1143,7 +1214,10 @@ ppf_status ppf_model_retain(ppf_model* m) {
 }
 ppf_status ppf_model_release(ppf_model* m) {
   if (!m) return PPF_OK;
-  if (m->refcount.fetch_sub(1) == 1) delete m;
+  if (m->refcount.fetch_sub(1) == 1) {
+    (void)hipDeviceSynchronize(); /* the table returns to the block cache: no match may still be reading it */
+    delete m;
+  }
   return PPF_OK;
 }
 ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info) {
@@ -1202,6 +1276,7 @@ ppf_status ppf_workspace_create(ppf_workspace** out) {
 }
 ppf_status ppf_workspace_destroy(ppf_workspace* ws) {
   if (!ws) return PPF_OK;
+  (void)hipDeviceSynchronize(); /* its buffers return to the block cache: nothing may still be using them */
   for (auto& e : ws->ev)
     if (e) (void)hipEventDestroy(e);
   delete ws;
@@ -2197,6 +2272,7 @@ ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int cols, ppf_
   return PPF_OK;
 }
 ppf_status ppf_cloud_release(ppf_cloud* c) {
+  if (c) (void)hipDeviceSynchronize(); /* its rows return to the block cache: no kernel may still be reading them */
   delete c;
   return PPF_OK;
 }
@@ -2406,6 +2482,7 @@ ppf_status ppf_prep_to_mat(const ppf_cloud* in, ppf_cloud** out) {
     k_prep_to_mat<<<grid_for(in->n, 256), dim3(256)>>>(in->rows.p, in->n, c->rows.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(c->curv.p, in->curv.p, (size_t)in->n * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHK(hipDeviceSynchronize());
   }
   *out = c.release();
   return PPF_OK;
