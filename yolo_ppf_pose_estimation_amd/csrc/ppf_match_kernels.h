@@ -55,6 +55,12 @@ constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded pe
 #ifndef PPF_VOTE_DYNAMIC
 #define PPF_VOTE_DYNAMIC 1
 #endif
+#ifndef PPF_PIPE_VALU
+#define PPF_PIPE_VALU 4 /* VALU instructions scheduled between two LDS atomics of the pipelined vote loop */
+#endif
+#ifndef PPF_VOTE_PIPE
+#define PPF_VOTE_PIPE 1 /* atomics of hit h issued under the arithmetic of hit h+1 (vote_hits) */
+#endif
 constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * PPF_VOTE_CHUNK_BATCHES; /* pair records per work item (1024 = 2048 entries) */
 constexpr int VOTE_MAX_HITS = PPF_VOTE_MAX_HITS; /* hits of one bucket run voted per work item */
 constexpr int GROUP_BLOCK = 1024;
@@ -509,6 +515,115 @@ __device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes
   }
 }
 
+/* ---- the same votes with the LDS atomics of hit h issued in the shadow of hit h+1's arithmetic ------------------
+ * cast_votes emits [39 VALU][8 ds_add] per hit; with 4 waves per SIMD the waves bunch up at their LDS phases and the
+ * two pipes alternate instead of overlapping.  Here the addresses of a hit are kept in registers and its atomics are
+ * interleaved (sched_group_barrier: 5 VALU, 1 DS, ...) with the bin arithmetic of the next hit of the item. */
+typedef __attribute__((address_space(3))) unsigned char lds_byte; /* explicit LDS pointers: 32-bit arithmetic, ds_* atomics */
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+template <int U>
+__device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const float Ohg, const double* __restrict__ asd_lds,
+                                          const float G2, const int A, int (&ka)[U], int (&kb)[U], float& frmin_out) {
+  float fa[U], fb[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const float qa = __builtin_fmaf(__uint_as_float(rec[u].z), S, Ohg);
+    const float qb = __builtin_fmaf(__uint_as_float(rec[u].w), S, Ohg);
+    ka[u] = (int)qa;
+    kb[u] = (int)qb;
+    fa[u] = __builtin_amdgcn_fractf(qa);
+    fb[u] = __builtin_amdgcn_fractf(qb);
+  }
+  float frmin = fa[0];
+  float pend[2 * U];
+  int np = 0;
+#pragma unroll
+  for (int u = 0; u < U; u++) { if (u) pend[np++] = fa[u]; pend[np++] = fb[u]; }
+  int i = 0;
+#pragma unroll
+  for (; i + 2 <= np; i += 2) frmin = __builtin_fminf(__builtin_fminf(frmin, pend[i]), pend[i + 1]);
+  if (i < np) frmin = __builtin_fminf(frmin, pend[i]);
+  frmin_out = frmin;
+  (void)asd_lds; (void)G2; (void)A;
+}
+/* rare path: votes within the guard band of a bin edge get the exact fp64 bin */
+template <int U>
+__device__ __forceinline__ void vote_fix(const uint4* rec, const float S, const float Ohg, const double* __restrict__ asd_lds,
+                                         const float G2, const int A, const float frmin, int (&ka)[U], int (&kb)[U]) {
+  if (__builtin_expect(__any(frmin < G2), 0)) {
+    const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t za = rec[u].z, zb = rec[u].w;
+      asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the hot loop */
+      const float aa = __uint_as_float(za), ab = __uint_as_float(zb);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = ppf_alpha_bin_exact(aa, asd, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = ppf_alpha_bin_exact(ab, asd, A);
+    }
+  }
+}
+/* the 2U atomics of one hit: LDS address = row's bin 0 + 4k (one v_lshl_add_u32), ds_add_u32 */
+template <int U>
+__device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32_t (&pb)[U], const int (&ka)[U], const int (&kb)[U],
+                                           const int n_valid) {
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    if (u < n_valid) {
+      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)(pa[u] + ((uint32_t)ka[u] << 2)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)(pb[u] + ((uint32_t)kb[u] << 2)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+/* one pipeline stage: the atomics of the previous hit (bins pka/pkb) under the bin arithmetic of hit hh (-> nka/nkb) */
+template <int U>
+__device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, const float S, const float ohg_v, const int hh,
+                                           const double* __restrict__ asd_lds, const float G2, const int A, const uint32_t (&pa)[U],
+                                           const uint32_t (&pb)[U], const int (&pka)[U], const int (&pkb)[U], int (&nka)[U], int (&nkb)[U]) {
+  float frmin;
+  const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
+  vote_issue<U>(pa, pb, pka, pkb, n_valid);
+  vote_bins<U>(rec, S, Ohg, asd_lds + hh, G2, A, nka, nkb, frmin);
+#pragma unroll
+  for (int i = 0; i < 2 * U; i++) {
+    __builtin_amdgcn_sched_group_barrier(0x002, PPF_PIPE_VALU, 0); /* VALU */
+    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); /* DS */
+  }
+  vote_fix<U>(rec, S, Ohg, asd_lds + hh, G2, A, frmin, nka, nkb);
+}
+/* all hits of a work item against one register batch of records; two sets of bins alternate so that a set is only
+ * overwritten a full stage after the atomics that used it were issued */
+template <int U>
+__device__ __forceinline__ void vote_hits(unsigned char* __restrict__ acc_bytes, const uint4* rec, const int n_valid, const float S,
+                                          const float ohg_v, const int nh, const double* __restrict__ asd_lds, const float G2,
+                                          const int A) {
+  uint32_t pa[U], pb[U];
+  int ka0[U], kb0[U], ka1[U], kb1[U];
+  const uint32_t base = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes; /* LDS byte address of the guard region */
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    pa[u] = base + rec[u].x;
+    pb[u] = base + rec[u].y;
+    asm volatile("" : "+v"(pa[u]), "+v"(pb[u])); /* computed once per batch, not rematerialised per vote */
+  }
+  {
+    float frmin;
+    const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), 0));
+    vote_bins<U>(rec, S, Ohg, asd_lds, G2, A, ka0, kb0, frmin);
+    vote_fix<U>(rec, S, Ohg, asd_lds, G2, A, frmin, ka0, kb0);
+  }
+  int hh = 1;
+  for (; hh + 1 < nh; hh += 2) {
+    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd_lds, G2, A, pa, pb, ka0, kb0, ka1, kb1);
+    vote_stage<U>(rec, n_valid, S, ohg_v, hh + 1, asd_lds, G2, A, pa, pb, ka1, kb1, ka0, kb0);
+  }
+  if (hh < nh) {
+    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd_lds, G2, A, pa, pb, ka0, kb0, ka1, kb1);
+    vote_issue<U>(pa, pb, ka1, kb1, n_valid);
+  } else {
+    vote_issue<U>(pa, pb, ka0, kb0, n_valid);
+  }
+}
+
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
@@ -668,16 +783,24 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       uint32_t b = 0;
       while (b < nfull) {
         load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
+#if PPF_ABL == 0 && PPF_VOTE_PIPE
+        vote_hits<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, ohg_v, nh, &seg_a64[h0], G2, A);
+#else
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
           cast_votes<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
         }
+#endif
         if (++b >= nfull) break;
         load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
+#if PPF_ABL == 0 && PPF_VOTE_PIPE
+        vote_hits<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, ohg_v, nh, &seg_a64[h0], G2, A);
+#else
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
           cast_votes<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
         }
+#endif
         ++b;
       }
       const uint32_t e0 = nfull * B;
@@ -689,10 +812,14 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
         }
         const int n_valid = (int)((c - e0 + 63) / 64);
+#if PPF_ABL == 0 && PPF_VOTE_PIPE
+        vote_hits<VOTE_UNROLL>(acc_bytes, ea, n_valid, S, ohg_v, nh, &seg_a64[h0], G2, A);
+#else
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
           cast_votes<VOTE_UNROLL>(acc_bytes, ea, n_valid, S, Ohg, &seg_a64[h0 + hh], G2, A);
         }
+#endif
       }
     }
   }
