@@ -813,7 +813,15 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         }
         const int n_valid = (int)((c - e0 + 63) / 64);
 #if PPF_ABL == 0 && PPF_VOTE_PIPE
-        vote_hits<VOTE_UNROLL>(acc_bytes, ea, n_valid, S, ohg_v, nh, &seg_a64[h0], G2, A);
+        /* most buckets are smaller than a batch (median 18 records): only the 64-record groups that hold data get
+         * their bin arithmetic, through an instantiation per group count */
+        static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
+        switch (n_valid) {
+          case 1: vote_hits<1>(acc_bytes, ea, 1, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
+          case 2: vote_hits<2>(acc_bytes, ea, 2, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
+          case 3: vote_hits<3>(acc_bytes, ea, 3, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
+          default: vote_hits<4>(acc_bytes, ea, 4, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
+        }
 #else
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
