@@ -624,6 +624,33 @@ __device__ __forceinline__ void vote_hits(unsigned char* __restrict__ acc_bytes,
   }
 }
 
+/* Buckets of at most 32 pair records (64 entries: more than half of all (tile, bucket) runs): one ENTRY per lane
+ * instead of one pair record per lane, so the 64 lanes of the single group are filled twice as well and a hit costs
+ * one fma/cvt/fract/lshl_add/ds_add instead of two of each.  Same bins, same guard band, same exact fallback. */
+__device__ __forceinline__ void vote_hits_single(unsigned char* __restrict__ acc_bytes, const uint32_t row_bytes, const uint32_t alpha_bits,
+                                                 const float S, const float ohg_v, const int nh, const double* __restrict__ asd_lds,
+                                                 const float G2, const int A) {
+  uint32_t pr = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes + row_bytes;
+  asm volatile("" : "+v"(pr));
+  const float am = __uint_as_float(alpha_bits);
+  uint32_t adr_prev = 0;
+  for (int hh = 0; hh < nh; hh++) {
+    const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
+    if (hh) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)adr_prev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const float q = __builtin_fmaf(am, S, Ohg);
+    int k = (int)q;
+    if (__builtin_expect(__any(__builtin_amdgcn_fractf(q) < G2), 0)) {
+      const double asd = asd_lds[hh];
+      uint32_t z = alpha_bits;
+      asm volatile("" : "+v"(z));
+      const float az = __uint_as_float(z);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(az, S, Ohg)) < G2) k = ppf_alpha_bin_exact(az, asd, A);
+    }
+    adr_prev = pr + ((uint32_t)k << 2);
+  }
+  if (nh > 0) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)adr_prev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
@@ -804,6 +831,15 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         ++b;
       }
       const uint32_t e0 = nfull * B;
+#if PPF_ABL == 0 && PPF_VOTE_PIPE
+      if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
+        const uint32_t e = e0 + ((uint32_t)lane >> 1);
+        const uint4 r = src[min(e, c - 1)];
+        const bool second = (lane & 1) != 0;
+        const uint32_t row_bytes = e < c ? (second ? r.y : r.x) : tail_bytes;
+        vote_hits_single(acc_bytes, row_bytes, second ? r.w : r.z, S, ohg_v, nh, &seg_a64[h0], G2, A);
+      } else
+#endif
       if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
 #pragma unroll
         for (int u = 0; u < VOTE_UNROLL; u++) {
