@@ -75,3 +75,18 @@ def test_weighted_clustering_and_thresholds(bottle):
         det.setSearchParams(pos, rot, w)
         ora.set_search_params(pos, rot, w)
         _same(det, ora, scene, 1.0 / 10.0)
+
+
+def test_pairs_beyond_the_key_table_take_the_hash_path(bottle):
+    """k_pairs looks quantised keys up in a per-model table (distance bins 0..1023); pairs farther apart than that
+    (here: three points tens of metres away, more than 3000 distance steps) must fall back to hashing and still give
+    the oracle's votes, including their chance collisions with occupied slots"""
+    det = PPF3DDetector(0.06, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.06, 0.05).train_model(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=2000, seed=91)
+    far = scene[:3].copy()
+    far[:, :3] += np.array([[30.0, 0, 0], [0, -45.0, 10.0], [12.0, 12.0, 60.0]], dtype=np.float32)
+    cloud = np.concatenate([scene, far]).astype(np.float32)
+    assert 30.0 / det.info()["distance_step"] > 1024
+    got = _same(det, ora, cloud, 1.0 / 10.0)
+    assert got["stats"]["n_pairs"] == got["n_ref"] * (cloud.shape[0] - 1)

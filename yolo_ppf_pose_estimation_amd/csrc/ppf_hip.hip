@@ -249,6 +249,20 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
   return (int)(w.rank + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)));
 }
 
+/* key_lut[((k0*na + k1)*na + k2)*nd + k3] = dense bucket of hash(k0..k3) % slots, or -1 */
+__global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int na, int nd,
+                                                       int32_t* __restrict__ lut) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)na * na * na * nd;
+  if (idx >= total) return;
+  const int k3 = (int)(idx % nd);
+  size_t t = idx / nd;
+  const int k2 = (int)(t % na); t /= na;
+  const int k1 = (int)(t % na);
+  const int k0 = (int)(t / na);
+  lut[idx] = slot_to_bucket(slotmap, ppf_murmur_key16(k0, k1, k2, k3) & slot_mask);
+}
+
 /* phase 0: count entries per (tile, bucket); phase 1: scatter through cursors */
 /* ---- table layout (see also ppf_match_kernels.h) -------------------------------------------------------------
  * The entries of a (tile, bucket) are stored as PAIR RECORDS {row_a, row_b, alpha_a, alpha_b} (16 B): a lane of
@@ -922,6 +936,8 @@ struct ppf_model {
   DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
   DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
   DevBuf<uint4> records;          /* pair records, see place_entry */
+  DevBuf<int32_t> key_lut;        /* quantised key -> bucket, see k_build_key_lut */
+  int lut_na = 0, lut_nd = 0;
   uint64_t n_records = 0;
   int levels = 1;
   int device = 0;
@@ -1047,6 +1063,23 @@ int ppf_device_count(void) {
 }
 
 /* ---- model ------------------------------------------------------------------------------------ */
+/* tabulate hash -> bucket for every key with angle bins 0..floor(pi/angle_step)+1 and distance bins 0..1023 (pairs up
+ * to ~1000 distance steps apart: tens of model diameters); everything else keeps the hash path in k_pairs */
+static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
+  m->lut_na = (int)std::floor(PPF_PI / m->info.angle_step) + 2;
+  m->lut_nd = 1024;
+  const size_t total = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
+  if (total > ((size_t)1 << 26)) { /* very fine angle steps: shrink the distance range to keep the table at 256 MiB */
+    m->lut_nd = (int)std::max<size_t>(1, ((size_t)1 << 26) / ((size_t)m->lut_na * m->lut_na * m->lut_na));
+  }
+  const size_t n = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
+  HIPCHK(m->key_lut.reserve(n));
+  k_build_key_lut<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(m->slotmap.p, m->info.slots - 1, m->lut_na, m->lut_nd, m->key_lut.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  return PPF_OK;
+}
+
 static ppf_status build_table(ppf_model* m, hipStream_t st) {
   const int N = m->info.n_ref;
   const size_t NN = (size_t)N * N;
@@ -1137,8 +1170,10 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(st));
+  ppf_status sl = build_key_lut(m, st);
+  if (sl != PPF_OK) return sl;
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
-                         m->records.bytes();
+                         m->records.bytes() + m->key_lut.bytes();
   return PPF_OK;
 }
 
@@ -1368,6 +1403,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.same_cloud = d_edge ? 0 : 1;
   va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride;
   va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
+  va.key_lut = m->key_lut.p; va.lut_na = m->lut_na; va.lut_nd = m->lut_nd;
   va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
   va.records = m->records.p;
   va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
@@ -1748,9 +1784,12 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
       if (hipDeviceSynchronize() != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: bucket totals failed");
     }
   }
+  if (s == PPF_OK) s = build_key_lut(m, nullptr); /* not stored in the file: rebuilt from the slot map */
   if (s != PPF_OK) {
     return s;
   }
+  m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
+                         m->records.bytes() + m->key_lut.bytes();
   HIPCHK(hipGetDevice(&m->device));
   *out = owner.release();
   return PPF_OK;

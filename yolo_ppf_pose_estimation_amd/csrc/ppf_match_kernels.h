@@ -103,9 +103,9 @@ struct FastKeyConsts {
   double rdstep;   /* 1 / dist_step */
 };
 
-__device__ __forceinline__ uint32_t pair_slot_hash(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2,
-                                                   const ppf_vec3& n2, const double angle_step, const double dist_step,
-                                                   const FastKeyConsts& fk) {
+/* the four quantised features of a scene pair (the 16-byte key the reference hashes) */
+__device__ __forceinline__ void pair_key(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2, const ppf_vec3& n2,
+                                         const double angle_step, const double dist_step, const FastKeyConsts& fk, int32_t (&k)[4]) {
   const double dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
   const double f3 = ppf_sqrt(dx * dx + dy * dy + dz * dz);
   double rinv = __builtin_amdgcn_rcp(f3);
@@ -114,7 +114,6 @@ __device__ __forceinline__ uint32_t pair_slot_hash(const ppf_vec3& p1, const ppf
   const double x1 = (n2.x * dx + n2.y * dy + n2.z * dz) * rinv;
   const double x2 = ppf_dot3(n1, n2); /* same expression as the exact path: bit-identical */
   bool slow = !(f3 > PPF_EPS) || !(ppf_fabs(x0) <= 1.0 - 1e-12) || !(ppf_fabs(x1) <= 1.0 - 1e-12) || !(ppf_fabs(x2) <= 1.0);
-  int32_t k[4];
   {
     const float q0 = acos32_estimate(x0) * fk.rstep32, q1 = acos32_estimate(x1) * fk.rstep32,
                 q2 = acos32_estimate(x2) * fk.rstep32;
@@ -134,6 +133,12 @@ __device__ __forceinline__ uint32_t pair_slot_hash(const ppf_vec3& p1, const ppf
     k[0] = ppf_d2i(f[0] / angle_step); k[1] = ppf_d2i(f[1] / angle_step); k[2] = ppf_d2i(f[2] / angle_step);
     k[3] = ppf_d2i(f[3] / dist_step);
   }
+}
+__device__ __forceinline__ uint32_t pair_slot_hash(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2,
+                                                   const ppf_vec3& n2, const double angle_step, const double dist_step,
+                                                   const FastKeyConsts& fk) {
+  int32_t k[4];
+  pair_key(p1, n1, p2, n2, angle_step, dist_step, fk, k);
   return ppf_murmur_key16(k[0], k[1], k[2], k[3]);
 }
 
@@ -146,6 +151,10 @@ struct MatchArgs {
   /* model table */
   const SlotWord* slotmap;
   uint32_t slot_mask;
+  /* key -> dense bucket id (-1: empty slot), indexed ((k0*lut_na + k1)*lut_na + k2)*lut_nd + k3: the hash of every
+   * quantised key a scene can produce, tabulated once per model; keys outside the table take the hash path */
+  const int32_t* key_lut;
+  int lut_na, lut_nd;
   const uint32_t* bucket_off;
   int n_buckets;
   const uint4* records;    /* pair records {row_a, row_b, alpha_a, alpha_b}; bucket_off counts records */
@@ -226,8 +235,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
       const bool self_pair = !a.same_cloud && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x &&
                              n2.y == n1.y && n2.z == n1.z;
       if (!self_pair) {
-        const uint32_t slot = pair_slot_hash(p1, n1, p2, n2, a.angle_step, a.dist_step, fk) & a.slot_mask;
-        const int b = slot_to_bucket(a.slotmap, slot);
+        int32_t key[4];
+        pair_key(p1, n1, p2, n2, a.angle_step, a.dist_step, fk, key);
+        int b;
+        if (((uint32_t)key[0] < (uint32_t)a.lut_na) & ((uint32_t)key[1] < (uint32_t)a.lut_na) & ((uint32_t)key[2] < (uint32_t)a.lut_na) &
+            ((uint32_t)key[3] < (uint32_t)a.lut_nd)) {
+          b = a.key_lut[(size_t)((key[0] * a.lut_na + key[1]) * a.lut_na + key[2]) * a.lut_nd + key[3]];
+        } else { /* NaN features (INT_MIN bins) or pairs farther apart than the table covers */
+          b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
+        }
         /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
          * computed later (k_group), only for the ~6 % of pairs that found a bucket. */
         my_pairs += 1u;
