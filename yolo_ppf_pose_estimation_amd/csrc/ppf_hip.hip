@@ -1797,757 +1797,5 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
 
 }  // extern "C"
 
-/* ============================================================================================ */
-/* ICP refinement (row N2; kernels in ppf_icp_kernels.h)                                          */
-/* ============================================================================================ */
-namespace {
-
-struct IcpScratch {
-  DevBuf<float> src0, dst0, src_pct, moved, dst_pcs;
-  DevBuf<float4> q4;
-  DevBuf<unsigned long long> best, owner;
-  DevBuf<int2> sel;
-  DevBuf<double> parts, sum_src, sum_dst;
-  DevBuf<IcpState> state;
-};
-
-constexpr int ICP_BATCH = 2;     /* iterations enqueued between two reads of the done flag (measured best of 1..6) */
-constexpr int ICP_MAX_JOBS = 8;  /* poses refined concurrently, one HIP stream each */
-
-inline long icp_round(double v) { return std::lrint(v); } /* cvRound */
-
-/* one registration in flight: its scratch, its stream, a pinned mirror of the device loop state */
-struct IcpJob {
-  IcpScratch sc;
-  hipStream_t st = nullptr; /* borrowed: the caller's stream or one of the pool's */
-  IcpState* h_st = nullptr;
-  double pose[16];
-  double fval_min = 9999999999.0;
-  int total = 0, launched = 0;
-  bool active = false;
-  ~IcpJob() {
-    if (h_st) (void)hipHostFree(h_st);
-  }
-};
-
-/* ICP::registerModelToScene(srcPC, dstPC, residual, pose) on device-resident clouds for jobs.size() initial poses at
- * once (init_poses[j] may be NULL: register from the identity).  The registrations are independent chains of small
- * kernels, so each runs on its own stream and the host walks them in lock-step: same level, one batch of iterations
- * enqueued on every stream, then one read of every done flag. */
-ppf_status icp_register_many(const float* d_src, int n, int sstride, const float* d_dst, int nd_all, int dstride,
-                             const ppf_icp_params& prm, const double* const* init_poses, std::vector<IcpJob*>& jobs,
-                             double* poses_out /* jobs x 16 */, double* residuals, int* iters_total) {
-  const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
-  auto grid = [](size_t items, int block) { return dim3((unsigned)((items + block - 1) / block)); };
-  const int robust = prm.rejection_scale > 0 ? 1 : 0;
-  const int icp_batch = getenv("PPF_ICP_BATCH") ? std::max(1, atoi(getenv("PPF_ICP_BATCH"))) : ICP_BATCH;
-  for (size_t j = 0; j < jobs.size(); j++) {
-    IcpJob& J = *jobs[j];
-    IcpScratch& sc = J.sc;
-    HIPCHK(sc.src0.reserve((size_t)n * 6));
-    HIPCHK(sc.src_pct.reserve((size_t)n * 6));
-    HIPCHK(sc.moved.reserve((size_t)n * 6));
-    HIPCHK(sc.dst0.reserve((size_t)nd_all * 6));
-    HIPCHK(sc.dst_pcs.reserve((size_t)nd_all * 6));
-    HIPCHK(sc.q4.reserve((size_t)nd_all));
-    HIPCHK(sc.best.reserve((size_t)n));
-    HIPCHK(sc.owner.reserve((size_t)nd_all));
-    HIPCHK(sc.sel.reserve((size_t)std::min(n, nd_all)));
-    HIPCHK(sc.parts.reserve(std::max(chunks_src, chunks_dst) * ICP_ENTRIES));
-    HIPCHK(sc.sum_src.reserve(chunks_src * 3));
-    HIPCHK(sc.sum_dst.reserve(chunks_dst * 3));
-    HIPCHK(sc.state.reserve(1));
-    if (!J.h_st) HIPCHK(hipHostMalloc((void**)&J.h_st, sizeof(IcpState), hipHostMallocDefault));
-    IcpState* d_st = sc.state.p;
-    hipStream_t st = J.st;
-    /* the two clouds, packed; the source moved by the initial pose */
-    if (init_poses && init_poses[j]) {
-      IcpMat44 T0;
-      memcpy(T0.m, init_poses[j], sizeof(T0.m));
-      k_icp_set_pose<<<dim3(1), dim3(1), 0, st>>>(d_st, T0);
-      k_icp_transform<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, d_st->T, sc.src0.p, nullptr, nullptr, nullptr);
-    } else {
-      k_icp_sample<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, sc.src0.p, nullptr);
-    }
-    k_icp_sample<<<grid(nd_all, 256), dim3(256), 0, st>>>(d_dst, dstride, 1, nd_all, sc.dst0.p, nullptr);
-    /* centre on the average of the two means, scale to unit average distance from the origin */
-    for (int mode = 0; mode < 2; mode++) {
-      k_icp_chunk_sums<<<grid(chunks_src, 64), dim3(64), 0, st>>>(sc.src0.p, n, mode, sc.sum_src.p);
-      k_icp_chunk_sums<<<grid(chunks_dst, 64), dim3(64), 0, st>>>(sc.dst0.p, nd_all, mode, sc.sum_dst.p);
-      k_icp_reduce<<<dim3(1), dim3(64), 0, st>>>(sc.sum_src.p, n, sc.sum_dst.p, nd_all, mode, d_st);
-      k_icp_center_scale<<<grid(n, 256), dim3(256), 0, st>>>(sc.src0.p, n, mode, d_st);
-      k_icp_center_scale<<<grid(nd_all, 256), dim3(256), 0, st>>>(sc.dst0.p, nd_all, mode, d_st);
-    }
-    HIPCHK(hipGetLastError());
-    for (int k = 0; k < 16; k++) J.pose[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    J.fval_min = 9999999999.0;
-    J.total = 0;
-  }
-  for (int level = prm.num_levels - 1; level >= 0; level--) {
-    const double div = std::pow(2.0, (double)level);
-    const int num_samples = (int)icp_round((double)n / div);
-    const double tol_p = (double)prm.tolerance * (double)(level + 1) * (level + 1);
-    const int max_iter = (int)icp_round((double)prm.iterations / (level + 1));
-    const int step = std::max(1, (int)icp_round((double)n / (double)std::max(num_samples, 1)));
-    const int ns = (n + step - 1) / step, nd = (nd_all + step - 1) / step;
-    /* NN launch shape: model points x scene slices, enough workgroups to fill 256 CUs */
-    const unsigned gx = (unsigned)((ns + 255) / 256);
-    const int max_splits = (nd + 63) / 64;
-    const int splits = std::max(1, std::min(max_splits, (int)(2048 / gx)));
-    const int slice = (nd + splits - 1) / splits;
-    const unsigned gy = (unsigned)((nd + slice - 1) / slice);
-    const unsigned n_chunks = (unsigned)((std::min(ns, nd) + ICP_CHUNK - 1) / ICP_CHUNK);
-    for (auto& jp : jobs) {
-      IcpJob& J = *jp;
-      IcpScratch& sc = J.sc;
-      IcpState* d_st = sc.state.p;
-      IcpMat44 T;
-      memcpy(T.m, J.pose, sizeof(T.m));
-      k_icp_set_pose<<<dim3(1), dim3(1), 0, J.st>>>(d_st, T);
-      k_icp_transform<<<grid(ns, 256), dim3(256), 0, J.st>>>(sc.src0.p, 6, step, ns, d_st->T, sc.src_pct.p, sc.moved.p, sc.best.p, nullptr);
-      k_icp_sample<<<grid(nd, 256), dim3(256), 0, J.st>>>(sc.dst0.p, 6, step, nd, sc.dst_pcs.p, sc.q4.p);
-      k_icp_level_init<<<dim3(1), dim3(1), 0, J.st>>>(d_st, tol_p, max_iter, robust);
-      J.launched = 0;
-      J.active = true;
-    }
-    static std::once_flag once_thr;
-    static hipError_t attr_thr = hipSuccess;
-    std::call_once(once_thr, [] {
-      attr_thr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_icp_threshold), hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
-    });
-    HIPCHK(attr_thr);
-    const int staged = ns <= 32768 ? 1 : 0; /* the level's distances fit LDS (4 bytes each): the selection passes read them there */
-    const bool small = ns <= ICP_SMALL_NS && !getenv("PPF_ICP_NO_SMALL"); /* the whole level in one workgroup, one launch */
-    for (bool any = true; any;) {
-      for (auto& jp : jobs) {
-        IcpJob& J = *jp;
-        if (!J.active) continue;
-        IcpScratch& sc = J.sc;
-        IcpState* d_st = sc.state.p;
-        hipStream_t st = J.st;
-        if (small) {
-          k_icp_level_small<<<dim3(1), dim3(1024), 0, st>>>(sc.src_pct.p, ns, sc.q4.p, sc.dst_pcs.p, nd, sc.owner.p, prm.rejection_scale, d_st);
-          J.launched = max_iter;
-        } else {
-          const int batch = std::min(icp_batch, max_iter - J.launched);
-          for (int b = 0; b < batch; b++) {
-            k_icp_nn<<<dim3(gx, gy), dim3(256), 0, st>>>(sc.moved.p, ns, sc.q4.p, nd, slice, sc.best.p, d_st);
-            k_icp_threshold<<<dim3(1), dim3(1024), staged ? (size_t)ns * 4 : 0, st>>>(sc.best.p, ns, prm.rejection_scale, sc.owner.p, nd,
-                                                                                     staged, d_st);
-            k_icp_owner<<<grid(ns, 256), dim3(256), 0, st>>>(sc.best.p, ns, sc.owner.p, d_st);
-            k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
-            k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
-            k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
-            k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
-          }
-          J.launched += std::max(batch, 0);
-        }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(J.h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
-      }
-      any = false;
-      for (auto& jp : jobs) {
-        IcpJob& J = *jp;
-        if (!J.active) continue;
-        HIPCHK(hipStreamSynchronize(J.st));
-        if (J.h_st->done || J.launched >= max_iter) J.active = false;
-        else any = true;
-      }
-    }
-    for (auto& jp : jobs) {
-      IcpJob& J = *jp;
-      J.total += J.h_st->iter;
-      J.fval_min = J.h_st->fval_min;
-      double tmp[16];
-      ppf_mat44_mul(J.h_st->PoseX, J.pose, tmp);
-      memcpy(J.pose, tmp, sizeof(tmp));
-    }
-  }
-  for (size_t j = 0; j < jobs.size(); j++) {
-    IcpJob& J = *jobs[j];
-    if (prm.num_levels <= 0) {
-      HIPCHK(hipMemcpyAsync(J.h_st, J.sc.state.p, sizeof(IcpState), hipMemcpyDeviceToHost, J.st));
-      HIPCHK(hipStreamSynchronize(J.st));
-    }
-    /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
-    const IcpState& h = *J.h_st;
-    double* pose = J.pose;
-    double Rm[3];
-    for (int r = 0; r < 3; r++) Rm[r] = pose[r * 4] * h.mean_avg[0] + pose[r * 4 + 1] * h.mean_avg[1] + pose[r * 4 + 2] * h.mean_avg[2];
-    for (int r = 0; r < 3; r++) pose[r * 4 + 3] = pose[r * 4 + 3] / h.scale + h.mean_avg[r] - Rm[r];
-    memcpy(poses_out + j * 16, pose, 16 * sizeof(double));
-    if (residuals) residuals[j] = J.fval_min;
-    if (iters_total) iters_total[j] = J.total;
-  }
-  return PPF_OK;
-}
-
-/* Streams (and pinned state mirrors) for concurrent jobs come from a process-wide pool: creating a HIP stream costs
- * milliseconds, far more than a registration.  One caller at a time owns the pool (others fall back to one stream). */
-struct IcpPool {
-  std::mutex mu;
-  IcpJob jobs[ICP_MAX_JOBS]; /* scratch buffers and pinned state mirrors persist across calls; they only grow */
-  hipStream_t st[ICP_MAX_JOBS] = {};
-  int device = -1;
-  bool ok = false;
-};
-/* never destroyed: its buffers must not be freed after the HIP runtime has shut down at process exit */
-IcpPool& g_icp_pool = *new IcpPool();
-
-/* Jobs for `count` concurrent registrations.  With the pool (one caller at a time; others get private jobs on the
- * caller's stream) nothing is allocated after the first call: streams, scratch and pinned mirrors are reused.  Pool
- * streams are ordered after whatever the caller's stream has enqueued so far. */
-ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<IcpJob*>& jobs, std::vector<std::unique_ptr<IcpJob>>& owned,
-                         std::unique_lock<std::mutex>& pool_lock) {
-  jobs.clear();
-  owned.clear();
-  bool pooled = false;
-  pool_lock = std::unique_lock<std::mutex>(g_icp_pool.mu, std::try_to_lock);
-  if (pool_lock.owns_lock()) {
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    if (!g_icp_pool.ok || g_icp_pool.device != dev) {
-      for (int j = 0; j < ICP_MAX_JOBS; j++) {
-        if (g_icp_pool.st[j]) (void)hipStreamDestroy(g_icp_pool.st[j]);
-        g_icp_pool.st[j] = nullptr;
-        HIPCHK(hipStreamCreateWithFlags(&g_icp_pool.st[j], hipStreamNonBlocking));
-        g_icp_pool.jobs[j].~IcpJob();
-        new (&g_icp_pool.jobs[j]) IcpJob(); /* buffers of another device are dropped */
-      }
-      g_icp_pool.device = dev;
-      g_icp_pool.ok = true;
-    }
-    pooled = true;
-  }
-  const bool own_streams = pooled && count > 1 && !getenv("PPF_ICP_ONE_STREAM");
-  hipEvent_t ready = nullptr;
-  if (own_streams) {
-    HIPCHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ready, user));
-  }
-  for (int j = 0; j < count; j++) {
-    IcpJob* J;
-    if (pooled) {
-      J = &g_icp_pool.jobs[j];
-    } else {
-      owned.emplace_back(new IcpJob());
-      J = owned.back().get();
-    }
-    J->st = own_streams ? g_icp_pool.st[j] : user;
-    if (own_streams) {
-      const hipError_t e = hipStreamWaitEvent(J->st, ready, 0);
-      if (e != hipSuccess) { (void)hipEventDestroy(ready); return fail(PPF_ERR_HIP, "ICP: hipStreamWaitEvent failed: %s", hipGetErrorString(e)); }
-    }
-    jobs.push_back(J);
-  }
-  if (ready) (void)hipEventDestroy(ready);
-  return PPF_OK;
-}
-
-ppf_status icp_check(const char* who, const void* src, int n, int sstride, const void* dst, int nd, int dstride, const ppf_icp_params* prm) {
-  if (!src || !dst || !prm || n <= 0 || nd <= 0 || sstride < 6 || dstride < 6) return fail(PPF_ERR_INVALID, "%s: bad argument", who);
-  if (prm->iterations < 0 || prm->num_levels < 0 || prm->num_levels > 30 || !(prm->tolerance >= 0))
-    return fail(PPF_ERR_INVALID, "%s: bad ICP parameters", who);
-  if (!have_device()) return fail(PPF_ERR_HIP, "%s: no HIP device (this engine has no CPU fallback)", who);
-  return PPF_OK;
-}
-
-/* Pose3D::appendPose: pose = incremental * pose, then q / t / angle from the new matrix */
-void icp_append_pose(ppf_pose* p, const double* inc, double residual) {
-  double out[16];
-  ppf_mat44_mul(inc, p->pose, out);
-  memcpy(p->pose, out, sizeof(out));
-  const double R[9] = {out[0], out[1], out[2], out[4], out[5], out[6], out[8], out[9], out[10]};
-  p->t[0] = out[3]; p->t[1] = out[7]; p->t[2] = out[11];
-  ppf_dcm_to_quat(R, p->q);
-  p->angle = ppf_angle_from_trace(R[0] + R[4] + R[8]);
-  p->residual = residual;
-}
-
-ppf_status icp_refine_device(const float* d_model, int n, int mstride, const float* d_scene, int nd, int sstride,
-                             const ppf_icp_params* prm, ppf_pose* poses, int n_poses, int* iters, hipStream_t st) {
-  for (int k0 = 0; k0 < n_poses; k0 += ICP_MAX_JOBS) {
-    const int cnt = std::min(ICP_MAX_JOBS, n_poses - k0);
-    std::vector<IcpJob*> jobs;
-    std::vector<std::unique_ptr<IcpJob>> owned;
-    std::unique_lock<std::mutex> pool_lock;
-    ppf_status s = icp_make_jobs(cnt, st, jobs, owned, pool_lock);
-    if (s != PPF_OK) return s;
-    const double* init[ICP_MAX_JOBS];
-    double inc[ICP_MAX_JOBS * 16], res[ICP_MAX_JOBS];
-    int it[ICP_MAX_JOBS];
-    for (int j = 0; j < cnt; j++) init[j] = poses[k0 + j].pose;
-    s = icp_register_many(d_model, n, mstride, d_scene, nd, sstride, *prm, init, jobs, inc, res, it);
-    if (s != PPF_OK) return s;
-    for (int j = 0; j < cnt; j++) {
-      icp_append_pose(&poses[k0 + j], inc + j * 16, res[j]);
-      if (iters) iters[k0 + j] = it[j];
-    }
-  }
-  return PPF_OK;
-}
-
-ppf_status icp_upload(const float* h, int n, int stride, DevBuf<float>& d) {
-  HIPCHK(d.reserve((size_t)n * 6));
-  HIPCHK(hipMemcpy2D(d.p, 6 * sizeof(float), h, (size_t)stride * sizeof(float), 6 * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
-  return PPF_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-void ppf_default_icp_params(ppf_icp_params* p) {
-  if (!p) return;
-  memset(p, 0, sizeof(*p));
-  p->iterations = 100; /* ICP icp(100, 0.005f, 2.5f, 8), CloudProcessing.h:465,518 */
-  p->tolerance = 0.005f;
-  p->rejection_scale = 2.5f;
-  p->num_levels = 8;
-}
-
-ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, const float* scene, int n_scene, int sstride,
-                          const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out) {
-  ppf_status s = icp_check("ppf_icp_refine", model, n_model, mstride, scene, n_scene, sstride, params);
-  if (s != PPF_OK) return s;
-  if (n_poses < 0 || (n_poses > 0 && !poses_io)) return fail(PPF_ERR_INVALID, "ppf_icp_refine: bad pose list");
-  DevBuf<float> dm, ds;
-  if ((s = icp_upload(model, n_model, mstride, dm)) != PPF_OK) return s;
-  if ((s = icp_upload(scene, n_scene, sstride, ds)) != PPF_OK) return s;
-  return icp_refine_device(dm.p, n_model, 6, ds.p, n_scene, 6, params, poses_io, n_poses, iterations_out, nullptr);
-}
-
-ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, const float* d_scene, int n_scene, int sstride,
-                                 const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out, void* stream) {
-  ppf_status s = icp_check("ppf_icp_refine_device", d_model, n_model, mstride, d_scene, n_scene, sstride, params);
-  if (s != PPF_OK) return s;
-  if (n_poses < 0 || (n_poses > 0 && !poses_io)) return fail(PPF_ERR_INVALID, "ppf_icp_refine_device: bad pose list");
-  return icp_refine_device(d_model, n_model, mstride, d_scene, n_scene, sstride, params, poses_io, n_poses, iterations_out,
-                           (hipStream_t)stream);
-}
-
-ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const float* dst, int n_dst, int dstride,
-                            const ppf_icp_params* params, double* pose16_out, double* residual_out, int* iterations_out) {
-  ppf_status s = icp_check("ppf_icp_register", src, n_src, sstride, dst, n_dst, dstride, params);
-  if (s != PPF_OK) return s;
-  if (!pose16_out) return fail(PPF_ERR_INVALID, "ppf_icp_register: pose16_out is NULL");
-  DevBuf<float> dsrc, ddst;
-  if ((s = icp_upload(src, n_src, sstride, dsrc)) != PPF_OK) return s;
-  if ((s = icp_upload(dst, n_dst, dstride, ddst)) != PPF_OK) return s;
-  std::vector<IcpJob*> jobs;
-  std::vector<std::unique_ptr<IcpJob>> owned;
-  std::unique_lock<std::mutex> pool_lock;
-  if ((s = icp_make_jobs(1, nullptr, jobs, owned, pool_lock)) != PPF_OK) return s;
-  return icp_register_many(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, jobs, pose16_out, residual_out, iterations_out);
-}
-
-/* ---- helpers on the path's edges, on the device like everything else ---------------------------------------- */
-ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
-                            int* n_out) {
-  if (!xyzn || n <= 0 || stride < 6 || !(relative_step > 0)) return fail(PPF_ERR_INVALID, "ppf_sample_cloud: bad argument");
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_sample_cloud: no HIP device (this engine has no CPU fallback)");
-  DevBuf<float> d_raw;
-  HIPCHK(d_raw.reserve((size_t)n * stride));
-  HIPCHK(hipMemcpy(d_raw.p, xyzn, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
-  CloudDev sampled;
-  std::vector<float> rows_host;
-  ppf_status s = device_sample_cloud(d_raw.p, n, stride, (float)relative_step, sampled, &rows_host, nullptr);
-  if (s != PPF_OK) return s;
-  const int rows = (int)(rows_host.size() / 6);
-  if (n_out) *n_out = rows;
-  if (out) {
-    if (cap_rows < rows) return fail(PPF_ERR_CAPACITY, "ppf_sample_cloud: need %d rows, have %d", rows, cap_rows);
-    memcpy(out, rows_host.data(), rows_host.size() * sizeof(float));
-  }
-  return PPF_OK;
-}
-
-ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* T, float* out) {
-  if (!xyzn || !T || !out || n < 0 || stride < 6) return fail(PPF_ERR_INVALID, "ppf_transform_pc_pose: bad argument");
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_transform_pc_pose: no HIP device (this engine has no CPU fallback)");
-  if (n == 0) return PPF_OK;
-  DevBuf<float> d_in, d_out;
-  DevBuf<double> d_T;
-  ppf_status s = icp_upload(xyzn, n, stride, d_in);
-  if (s != PPF_OK) return s;
-  HIPCHK(d_out.reserve((size_t)n * 6));
-  HIPCHK(d_T.reserve(16));
-  HIPCHK(hipMemcpy(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice));
-  k_icp_transform<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_in.p, 6, 1, n, d_T.p, d_out.p, nullptr, nullptr, nullptr);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
-  return PPF_OK;
-}
-
-}  // extern "C"
-
-/* ============================================================================================ */
-/* Pre-processing stages (row N4; kernels in ppf_prep_kernels.h)                                  */
-/* ============================================================================================ */
-struct ppf_cloud {
-  DevBuf<float> rows; /* n x 6: x y z nx ny nz */
-  DevBuf<float> curv; /* n */
-  int n = 0;
-};
-
-namespace {
-
-inline dim3 grid_for(size_t items, int block) { return dim3((unsigned)std::max<size_t>((items + block - 1) / block, 1)); }
-
-ppf_status cloud_alloc(std::unique_ptr<ppf_cloud>& c, int n) {
-  c.reset(new ppf_cloud());
-  c->n = n;
-  HIPCHK(c->rows.reserve((size_t)std::max(n, 1) * 6));
-  HIPCHK(c->curv.reserve((size_t)std::max(n, 1)));
-  return PPF_OK;
-}
-
-/* ordered compaction of the rows whose flag is set */
-ppf_status cloud_compact(const ppf_cloud* in, const DevBuf<uint32_t>& flags, ppf_cloud** out) {
-  const int n = in->n;
-  DevBuf<uint32_t> pos;
-  HIPCHK(pos.reserve((size_t)n + 1));
-  ppf_status s = device_exclusive_scan(flags.p, pos.p, (size_t)n + 1, nullptr);
-  if (s != PPF_OK) return s;
-  uint32_t kept = 0;
-  HIPCHK(hipMemcpy(&kept, pos.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost));
-  std::unique_ptr<ppf_cloud> c;
-  if ((s = cloud_alloc(c, (int)kept)) != PPF_OK) return s;
-  if (kept) {
-    k_prep_gather<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, in->curv.p, n, flags.p, pos.p, c->rows.p, c->curv.p);
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipDeviceSynchronize());
-  *out = c.release();
-  return PPF_OK;
-}
-
-ppf_status prep_check(const char* who, const ppf_cloud* in, ppf_cloud** out) {
-  if (!out) return fail(PPF_ERR_INVALID, "%s: out is NULL", who);
-  *out = nullptr;
-  if (!in) return fail(PPF_ERR_INVALID, "%s: cloud is NULL", who);
-  if (!have_device()) return fail(PPF_ERR_HIP, "%s: no HIP device (this engine has no CPU fallback)", who);
-  return PPF_OK;
-}
-
-/* exact kNN lists of every point of the cloud: idx/d2 are [n][k], k <= min(n, KNN_MAX_K); q4 = xyz by original row */
-ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>& idx, DevBuf<float>& d2) {
-  const int n = in->n;
-  HIPCHK(q4.reserve((size_t)n));
-  HIPCHK(idx.reserve((size_t)n * k));
-  HIPCHK(d2.reserve((size_t)n * k));
-  DevBuf<float> scratch;
-  HIPCHK(scratch.reserve((size_t)n * 6));
-  k_icp_sample<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, 6, 1, n, scratch.p, q4.p);
-  /* grid over the bounding box: about sqrt(n)/6 cells along the longest side (a 3x3x3 cube of a surface-like cloud
-   * then holds a few hundred points), at most 128 */
-  DevBuf<uint32_t> mm;
-  HIPCHK(mm.reserve(6));
-  const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-  HIPCHK(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
-  k_prep_minmax<<<dim3(std::min<unsigned>((unsigned)((n + 255) / 256), 2048u)), dim3(256)>>>(in->rows.p, n, mm.p);
-  HIPCHK(hipGetLastError());
-  uint32_t h_mm[6];
-  HIPCHK(hipMemcpy(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost));
-  KnnGrid g;
-  float ext_max = 0.f;
-  for (int a = 0; a < 3; a++) {
-    const float lo = ordered_to_float(h_mm[a]), hi = ordered_to_float(h_mm[3 + a]);
-    if (!std::isfinite(lo) || !std::isfinite(hi))
-      return fail(PPF_ERR_INVALID, "neighbour search: the cloud holds non-finite points (crop or voxel-grid it first)");
-    g.lo[a] = lo;
-    ext_max = std::max(ext_max, hi - lo);
-  }
-  const int G = std::max(1, std::min(128, (int)(std::sqrt((double)n) / 6.0)));
-  g.h = ext_max > 0.f ? ext_max / (float)G : 1.0f;
-  g.inv_h = 1.0f / g.h;
-  size_t cells = 1;
-  for (int a = 0; a < 3; a++) {
-    const float hi = ordered_to_float(h_mm[3 + a]);
-    g.dim[a] = std::max(1, std::min(G + 1, (int)std::floor((hi - g.lo[a]) * g.inv_h) + 1));
-    cells *= (size_t)g.dim[a];
-  }
-  DevBuf<uint32_t> keys, vals, keys2, vals2, starts, cell_count, cell_begin;
-  HIPCHK(keys.reserve(n)); HIPCHK(vals.reserve(n)); HIPCHK(keys2.reserve(n)); HIPCHK(vals2.reserve(n));
-  HIPCHK(cell_count.reserve(cells + 1)); HIPCHK(cell_begin.reserve(cells + 1));
-  HIPCHK(hipMemset(cell_count.p, 0, (cells + 1) * sizeof(uint32_t)));
-  k_prep_knn_keys<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, n, g, keys.p, vals.p, cell_count.p);
-  HIPCHK(hipGetLastError());
-  ppf_status s = device_exclusive_scan(cell_count.p, cell_begin.p, cells + 1, nullptr);
-  if (s != PPF_OK) return s;
-  uint32_t n_runs = 0;
-  uint32_t* order = nullptr;
-  if ((s = sort_segments(keys, vals, keys2, vals2, n, (unsigned long long)cells, starts, &order, &n_runs, nullptr)) != PPF_OK) return s;
-  DevBuf<float4> pts;
-  HIPCHK(pts.reserve((size_t)n));
-  k_prep_knn_pack<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, order, n, pts.p);
-  k_prep_knn<<<grid_for(n, KNN_WAVES), dim3(KNN_WAVES * 64)>>>(pts.p, cell_begin.p, g, n, k, idx.p, d2.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
-  return PPF_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int cols, ppf_cloud** out) {
-  if (!out) return fail(PPF_ERR_INVALID, "ppf_cloud_upload: out is NULL");
-  *out = nullptr;
-  if (!rows || n < 0 || (cols != 3 && cols != 6) || stride < cols) return fail(PPF_ERR_INVALID, "ppf_cloud_upload: bad argument");
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_cloud_upload: no HIP device (this engine has no CPU fallback)");
-  std::unique_ptr<ppf_cloud> c;
-  ppf_status s = cloud_alloc(c, n);
-  if (s != PPF_OK) return s;
-  if (n) {
-    DevBuf<float> raw;
-    HIPCHK(raw.reserve((size_t)n * stride));
-    HIPCHK(hipMemcpy(raw.p, rows, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
-    k_prep_pack<<<grid_for(n, 256), dim3(256)>>>(raw.p, n, stride, cols, c->rows.p, c->curv.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-  }
-  *out = c.release();
-  return PPF_OK;
-}
-ppf_status ppf_cloud_release(ppf_cloud* c) {
-  if (c) (void)hipDeviceSynchronize(); /* its rows return to the block cache: no kernel may still be reading them */
-  delete c;
-  return PPF_OK;
-}
-ppf_status ppf_cloud_size(const ppf_cloud* c, int* n) {
-  if (!c || !n) return fail(PPF_ERR_INVALID, "ppf_cloud_size: NULL");
-  *n = c->n;
-  return PPF_OK;
-}
-ppf_status ppf_cloud_download(const ppf_cloud* c, float* rows6, float* curvature, int cap_rows) {
-  if (!c) return fail(PPF_ERR_INVALID, "ppf_cloud_download: NULL");
-  if (cap_rows < c->n) return fail(PPF_ERR_CAPACITY, "ppf_cloud_download: need %d rows, have %d", c->n, cap_rows);
-  if (rows6 && c->n) HIPCHK(hipMemcpy(rows6, c->rows.p, (size_t)c->n * 6 * sizeof(float), hipMemcpyDeviceToHost));
-  if (curvature && c->n) HIPCHK(hipMemcpy(curvature, c->curv.p, (size_t)c->n * sizeof(float), hipMemcpyDeviceToHost));
-  return PPF_OK;
-}
-ppf_status ppf_cloud_device_rows(const ppf_cloud* c, const float** d_rows6, int* n) {
-  if (!c || !d_rows6 || !n) return fail(PPF_ERR_INVALID, "ppf_cloud_device_rows: NULL");
-  *d_rows6 = c->rows.p;
-  *n = c->n;
-  return PPF_OK;
-}
-
-/* SceneCropping (CloudProcessing.h:263-339) for one bounding box */
-ppf_status ppf_prep_crop(const ppf_cloud* in, const int* box_xywh, const float* depth, int depth_rows, int depth_cols,
-                         const double* intr, ppf_cloud** out) {
-  ppf_status s = prep_check("ppf_prep_crop", in, out);
-  if (s != PPF_OK) return s;
-  if (!box_xywh || !depth || !intr || depth_rows <= 0 || depth_cols <= 0) return fail(PPF_ERR_INVALID, "ppf_prep_crop: bad argument");
-  double left = box_xywh[0] - 30; if (left < 0) left = 0;
-  double top = box_xywh[1] - 30; if (top < 0) top = 0;
-  double right = box_xywh[0] + box_xywh[2] + 30; if (right >= depth_cols) right = depth_cols - 1;
-  double bottom = box_xywh[1] + box_xywh[3] + 30; if (bottom >= depth_rows) bottom = depth_rows - 1;
-  const int il = (int)left, it = (int)top, ir = (int)right, ib = (int)bottom;
-  if (il < 0 || it < 0 || ir >= depth_cols || ib >= depth_rows || il > ir || it > ib) return fail(PPF_ERR_INVALID, "ppf_prep_crop: box outside the depth image");
-  const float d1 = depth[(size_t)it * depth_cols + il], d2 = depth[(size_t)it * depth_cols + ir],
-              d3 = depth[(size_t)ib * depth_cols + il], d4 = depth[(size_t)ib * depth_cols + ir];
-  const float davg = (d1 + d2 + d3 + d4) / 4;
-  const double fx = intr[0], fy = intr[1], ppx = intr[2], ppy = intr[3];
-  auto back_project = [&](int u, int v, float* o) { /* Camera::back_projection_bbox, Camera.h:50-61 */
-    o[0] = (float)((double)((float)((double)u - ppx) * davg) / fx);
-    o[1] = (float)((double)((float)((double)v - ppy) * davg) / fy);
-    o[2] = (float)((double)davg + 0.15); /* corners pushed 0.15 m back, :292-295 */
-  };
-  float c[4][3];
-  back_project(il, it, c[0]); back_project(il, ib, c[1]); back_project(ir, it, c[2]); back_project(ir, ib, c[3]);
-  CropPlanes pl;
-  pl.z_base = c[0][2];
-  const double ctr[3] = {((double)c[0][0] + c[1][0] + c[2][0] + c[3][0]) / 4, ((double)c[0][1] + c[1][1] + c[2][1] + c[3][1]) / 4, (double)pl.z_base};
-  const int face[4][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}};
-  for (int f = 0; f < 4; f++) {
-    const float* a = c[face[f][0]]; const float* b = c[face[f][1]];
-    pl.n[f][0] = (double)a[1] * b[2] - (double)a[2] * b[1];
-    pl.n[f][1] = (double)a[2] * b[0] - (double)a[0] * b[2];
-    pl.n[f][2] = (double)a[0] * b[1] - (double)a[1] * b[0];
-    const double sgn = pl.n[f][0] * ctr[0] + pl.n[f][1] * ctr[1] + pl.n[f][2] * ctr[2];
-    if (sgn < 0) { pl.n[f][0] = -pl.n[f][0]; pl.n[f][1] = -pl.n[f][1]; pl.n[f][2] = -pl.n[f][2]; }
-  }
-  DevBuf<uint32_t> flags;
-  HIPCHK(flags.reserve((size_t)in->n + 1));
-  HIPCHK(hipMemset(flags.p + in->n, 0, sizeof(uint32_t)));
-  if (in->n) k_prep_crop_flags<<<grid_for(in->n, 256), dim3(256)>>>(in->rows.p, in->n, pl, flags.p);
-  HIPCHK(hipGetLastError());
-  return cloud_compact(in, flags, out);
-}
-
-/* Subsampling (:361-380): pcl::VoxelGrid with a cubic leaf */
-ppf_status ppf_prep_voxel_grid(const ppf_cloud* in, double leaf, ppf_cloud** out) {
-  ppf_status s = prep_check("ppf_prep_voxel_grid", in, out);
-  if (s != PPF_OK) return s;
-  if (!((float)leaf > 0.f)) return fail(PPF_ERR_INVALID, "ppf_prep_voxel_grid: leaf size must be positive");
-  /* non-finite points do not take part */
-  DevBuf<uint32_t> fin;
-  HIPCHK(fin.reserve((size_t)in->n + 1));
-  HIPCHK(hipMemset(fin.p + in->n, 0, sizeof(uint32_t)));
-  if (in->n) k_prep_finite_flags<<<grid_for(in->n, 256), dim3(256)>>>(in->rows.p, in->n, fin.p);
-  ppf_cloud* dense_raw = nullptr;
-  if ((s = cloud_compact(in, fin, &dense_raw)) != PPF_OK) return s;
-  std::unique_ptr<ppf_cloud> dense(dense_raw);
-  const int n = dense->n;
-  std::unique_ptr<ppf_cloud> c;
-  if (n == 0) {
-    if ((s = cloud_alloc(c, 0)) != PPF_OK) return s;
-    *out = c.release();
-    return PPF_OK;
-  }
-  DevBuf<uint32_t> mm, keys, vals, keys2, vals2, starts;
-  HIPCHK(mm.reserve(6));
-  const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-  HIPCHK(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
-  k_prep_minmax<<<dim3(std::min<unsigned>((unsigned)((n + 255) / 256), 2048u)), dim3(256)>>>(dense->rows.p, n, mm.p);
-  HIPCHK(hipGetLastError());
-  uint32_t h_mm[6];
-  HIPCHK(hipMemcpy(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost));
-  VoxelGridDims g;
-  g.inv_leaf = 1.0f / (float)leaf;
-  long long cells = 1;
-  for (int k = 0; k < 3; k++) {
-    const float lo = ordered_to_float(h_mm[k]), hi = ordered_to_float(h_mm[3 + k]);
-    g.min_b[k] = (int)std::floor(lo * g.inv_leaf);
-    const int max_b = (int)std::floor(hi * g.inv_leaf);
-    g.div_b[k] = max_b - g.min_b[k] + 1;
-    cells *= g.div_b[k];
-    if (cells > 0x7fffffffLL) return fail(PPF_ERR_INVALID, "ppf_prep_voxel_grid: leaf size is too small for the cloud (index overflow)");
-  }
-  HIPCHK(keys.reserve(n)); HIPCHK(vals.reserve(n)); HIPCHK(keys2.reserve(n)); HIPCHK(vals2.reserve(n));
-  k_prep_voxel_keys<<<grid_for(n, 256), dim3(256)>>>(dense->rows.p, n, g, keys.p, vals.p);
-  HIPCHK(hipGetLastError());
-  uint32_t n_cells = 0;
-  uint32_t* va = nullptr;
-  if ((s = sort_segments(keys, vals, keys2, vals2, n, (unsigned long long)cells, starts, &va, &n_cells, nullptr)) != PPF_OK) return s;
-  if ((s = cloud_alloc(c, (int)n_cells)) != PPF_OK) return s;
-  k_prep_voxel_sum<<<grid_for(n_cells, 64), dim3(64)>>>(dense->rows.p, va, starts.p, (int)n_cells, n, c->rows.p, c->curv.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
-  *out = c.release();
-  return PPF_OK;
-}
-
-/* exact k nearest neighbours of every point (debug / parity surface): idx and d2 are [n][k]; missing = -1 / 0 */
-ppf_status ppf_prep_knn(const ppf_cloud* in, int k, int* idx, float* d2) {
-  if (!in || !idx || !d2 || k < 1 || k > KNN_MAX_K) return fail(PPF_ERR_INVALID, "ppf_prep_knn: bad argument (k <= %d)", KNN_MAX_K);
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_prep_knn: no HIP device (this engine has no CPU fallback)");
-  const int n = in->n, ke = std::min(k, n);
-  if (n == 0) return PPF_OK;
-  DevBuf<float4> q4; DevBuf<int> d_idx; DevBuf<float> d_d2;
-  ppf_status s = cloud_knn(in, ke, q4, d_idx, d_d2);
-  if (s != PPF_OK) return s;
-  std::vector<int> hi((size_t)n * ke);
-  std::vector<float> hd((size_t)n * ke);
-  HIPCHK(hipMemcpy(hi.data(), d_idx.p, hi.size() * sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hd.data(), d_d2.p, hd.size() * sizeof(float), hipMemcpyDeviceToHost));
-  for (int i = 0; i < n; i++)
-    for (int m = 0; m < k; m++) {
-      idx[(size_t)i * k + m] = m < ke ? hi[(size_t)i * ke + m] : -1;
-      d2[(size_t)i * k + m] = m < ke ? hd[(size_t)i * ke + m] : 0.f;
-    }
-  return PPF_OK;
-}
-
-/* OutlierProcessing (:341-360): pcl::StatisticalOutlierRemoval(meanK, stddevMul) */
-ppf_status ppf_prep_outlier_removal(const ppf_cloud* in, int mean_k, double stddev_mul, ppf_cloud** out) {
-  ppf_status s = prep_check("ppf_prep_outlier_removal", in, out);
-  if (s != PPF_OK) return s;
-  if (mean_k < 1 || mean_k + 1 > KNN_MAX_K) return fail(PPF_ERR_INVALID, "ppf_prep_outlier_removal: meanK must be in [1, %d]", KNN_MAX_K - 1);
-  const int n = in->n;
-  DevBuf<uint32_t> flags;
-  HIPCHK(flags.reserve((size_t)n + 1));
-  HIPCHK(hipMemset(flags.p + n, 0, sizeof(uint32_t)));
-  if (n) {
-    DevBuf<float4> q4; DevBuf<int> idx; DevBuf<float> d2, dist;
-    DevBuf<double> parts, thr;
-    const int valid = n > mean_k ? 1 : 0;
-    if (valid && (s = cloud_knn(in, mean_k + 1, q4, idx, d2)) != PPF_OK) return s;
-    HIPCHK(dist.reserve(n));
-    HIPCHK(parts.reserve((size_t)((n + 63) / 64) * 2));
-    HIPCHK(thr.reserve(1));
-    k_prep_sor_dist<<<grid_for(n, 256), dim3(256)>>>(d2.p, n, mean_k, valid, dist.p);
-    k_prep_sor_chunks<<<grid_for((n + 63) / 64, 64), dim3(64)>>>(dist.p, n, parts.p);
-    k_prep_sor_threshold<<<dim3(1), dim3(64)>>>(parts.p, n, stddev_mul, thr.p);
-    k_prep_sor_flags<<<grid_for(n, 256), dim3(256)>>>(dist.p, n, thr.p, flags.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-  }
-  return cloud_compact(in, flags, out);
-}
-
-/* NormalEstimation (:381-405): k nearest neighbours, plane fit, normal towards the camera, curvature */
-ppf_status ppf_prep_normals(const ppf_cloud* in, int k, ppf_cloud** out) {
-  ppf_status s = prep_check("ppf_prep_normals", in, out);
-  if (s != PPF_OK) return s;
-  if (k < 1 || k > KNN_MAX_K) return fail(PPF_ERR_INVALID, "ppf_prep_normals: k must be in [1, %d]", KNN_MAX_K);
-  const int n = in->n;
-  std::unique_ptr<ppf_cloud> c;
-  if ((s = cloud_alloc(c, n)) != PPF_OK) return s;
-  if (n) {
-    HIPCHK(hipMemcpy(c->rows.p, in->rows.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToDevice));
-    DevBuf<float4> q4; DevBuf<int> idx; DevBuf<float> d2;
-    const int ke = std::min(k, n);
-    if ((s = cloud_knn(in, ke, q4, idx, d2)) != PPF_OK) return s;
-    k_prep_normals<<<grid_for(n, 64), dim3(64)>>>(c->rows.p, c->curv.p, n, idx.p, ke, q4.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-  }
-  *out = c.release();
-  return PPF_OK;
-}
-
-/* EdgeExtraction (:406-427): points whose curvature exceeds the threshold */
-ppf_status ppf_prep_edges(const ppf_cloud* in, float curvature_threshold, ppf_cloud** out) {
-  ppf_status s = prep_check("ppf_prep_edges", in, out);
-  if (s != PPF_OK) return s;
-  DevBuf<uint32_t> flags;
-  HIPCHK(flags.reserve((size_t)in->n + 1));
-  HIPCHK(hipMemset(flags.p + in->n, 0, sizeof(uint32_t)));
-  if (in->n) k_prep_curv_flags<<<grid_for(in->n, 256), dim3(256)>>>(in->curv.p, in->n, curvature_threshold, flags.p);
-  HIPCHK(hipGetLastError());
-  return cloud_compact(in, flags, out);
-}
-
-/* PointCloudXYZNormalToMat (:163-190): the N x 6 rows the detector consumes, normals re-normalised */
-ppf_status ppf_prep_to_mat(const ppf_cloud* in, ppf_cloud** out) {
-  ppf_status s = prep_check("ppf_prep_to_mat", in, out);
-  if (s != PPF_OK) return s;
-  std::unique_ptr<ppf_cloud> c;
-  if ((s = cloud_alloc(c, in->n)) != PPF_OK) return s;
-  if (in->n) {
-    k_prep_to_mat<<<grid_for(in->n, 256), dim3(256)>>>(in->rows.p, in->n, c->rows.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(c->curv.p, in->curv.p, (size_t)in->n * sizeof(float), hipMemcpyDeviceToDevice));
-    HIPCHK(hipDeviceSynchronize());
-  }
-  *out = c.release();
-  return PPF_OK;
-}
-
-/* ---- the PPF calls on device-resident clouds: the whole chain after the detector's boxes without host copies --- */
-ppf_status ppf_match_clouds(const ppf_model* m, const ppf_cloud* scene, const ppf_cloud* edge, const ppf_match_params* params,
-                            ppf_pose* out, int cap, int* n_out) {
-  if (!n_out) return fail(PPF_ERR_INVALID, "ppf_match_clouds: n_out is NULL");
-  *n_out = 0;
-  if (!scene) return fail(PPF_ERR_INVALID, "ppf_match_clouds: scene is NULL");
-  ppf_status s = check_match_args(m, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params);
-  if (s != PPF_OK) return s;
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_clouds: no HIP device (this engine has no CPU fallback)");
-  ppf_workspace ws;
-  s = ppf_match_device(m, &ws, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params, nullptr);
-  if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
-  for (auto& e : ws.ev)
-    if (e) (void)hipEventDestroy(e);
-  return s;
-}
-
-ppf_status ppf_icp_refine_clouds(const ppf_cloud* model, const ppf_cloud* scene, const ppf_icp_params* params, ppf_pose* poses_io,
-                                 int n_poses, int* iterations_out) {
-  if (!model || !scene) return fail(PPF_ERR_INVALID, "ppf_icp_refine_clouds: cloud is NULL");
-  return ppf_icp_refine_device(model->rows.p, model->n, 6, scene->rows.p, scene->n, 6, params, poses_io, n_poses, iterations_out, nullptr);
-}
-
-}  // extern "C"
+#include "ppf_icp_host.h"  /* row N2: ICP refinement, host side */
+#include "ppf_prep_host.h" /* row N4: cloud stages, host side */

@@ -37,6 +37,9 @@
 #ifndef PPF_MATCH_KERNELS_H
 #define PPF_MATCH_KERNELS_H
 
+#ifndef PPF_GUARD_REL
+#define PPF_GUARD_REL 5e-7f /* alpha-bin guard band relative to A; the fp32 error bound is 1.1e-7 */
+#endif
 #ifndef PPF_ABL
 #define PPF_ABL 0 /* diagnostic ablations of k_vote; 0 in every shipped build */
 #endif
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 #ifdef PPF_FORCE_EXACT
   const float G = 1.0f;
 #else
-  const float G = 5e-7f * (float)A;
+  const float G = PPF_GUARD_REL * (float)A;
 #endif
   const float G2 = 2.0f * G;
   const float Og = 0.5f * (float)A + G;
