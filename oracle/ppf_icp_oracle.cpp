@@ -173,7 +173,7 @@ int icp_single(const Cloud& srcPC, const Cloud& dstPC, const IcpParams& prm, dou
     std::vector<float> dist(ns);
     int i = 0;
     while (!(fval_perc < (1 + TolP) && fval_perc > (1 - TolP)) && i < maxIter) {
-#pragma omp parallel for schedule(static) /* rows are independent: threads change nothing in the result */
+#pragma omp parallel for schedule(static) num_threads(16) if ((long)ns * nd > 4000000L) /* rows are independent: threads change nothing in the result; small levels stay serial (a parallel region per iteration costs more than it saves, badly so on boxes whose CPU share is smaller than their core count) */
       for (int a = 0; a < ns; a++) { /* exhaustive NN, float squared distance, first minimum */
         const float* p = moved.row(a);
         float best = 3.402823466e+38f; int bi = 0;

@@ -52,7 +52,7 @@ void back_project(float z, int u, int v, double fx, double fy, double ppx, doubl
 void knn_all(const float* xyz, int n, int stride, int k, std::vector<int>& idx, std::vector<float>& d2) {
   idx.assign((size_t)n * k, -1);
   d2.assign((size_t)n * k, 0.f);
-#pragma omp parallel
+#pragma omp parallel num_threads(16) if ((long)n * n > 4000000L)
   {
     std::vector<std::pair<float, int>> cand((size_t)n);
 #pragma omp for schedule(static)
