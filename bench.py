@@ -66,12 +66,32 @@ def measured_traffic(n_votes):
     return best
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, further limited by the cgroup CPU quota (a GPU box shows
+    all 256 hardware threads but grants a share of them; more threads than that only adds context switches and would
+    misstate `cores`)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(bottle, scene, n_ref_total, target_seconds=15.0):
     """Oracle (CPU restatement) on a bounded sample of the step's reference points."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    threads = oracle_lib.max_threads()
+    threads = min(oracle_lib.max_threads(), usable_cpus())
     ora = oracle_lib.OracleDetector(MODEL_STEP, 0.05).train_model(bottle)
     step = int(1.0 / SCENE_STEP)
     # calibrate on 2 reference points per thread, then size the sample for ~target_seconds
@@ -92,6 +112,7 @@ def cpu_baseline(bottle, scene, n_ref_total, target_seconds=15.0):
         "value": votes / dt,
         "unit": "pair-matches/s",
         "cores": threads,
+        "host_cpus_visible": os.cpu_count(),
         "kind": "port",
         "sample": f"{n_sample} of {n_ref_total} reference points (evenly spaced) of the same crop, all "
                   f"{scene.shape[0]} paired points each, {votes} pair-matches in {dt:.2f} s, "
