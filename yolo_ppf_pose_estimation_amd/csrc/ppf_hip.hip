@@ -1566,6 +1566,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.bucket_total = m->bucket_total.p; va.work = ws->work.p; va.perm = ws->perm.p;
   va.frames = ws->frames.p; va.hits = ws->hits.p; va.hit_count = ws->hit_count.p; va.hit_cap = n_paired;
   va.keys_a = ws->keys_a.p; va.keys_b = ws->keys_b.p;
+  va.keys_sorted = nullptr; /* set once group_lds_buckets is known */
   va.key_bits = 1;
   while (va.key_bits < 32 && (1ull << va.key_bits) < (unsigned long long)m->info.n_buckets) va.key_bits++;
   const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)m->info.tile_refs * vote_pitch(m->info.num_angles)) * 4;
@@ -1581,6 +1582,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   const int pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
   /* k_group: one LDS counter per bucket when that fits (<= 30k buckets), else the radix-sort path */
   va.group_lds_buckets = m->info.n_buckets <= 30000 ? (int)m->info.n_buckets : 0;
+  va.keys_sorted = va.group_lds_buckets ? va.keys_b : va.keys_a;
   const size_t group_lds = va.group_lds_buckets ? ((size_t)va.group_lds_buckets + 1 + 16) * sizeof(uint32_t)
                                                 : (size_t)(GROUP_BLOCK / 64) * 256 * sizeof(uint32_t);
   static std::once_flag once_g;

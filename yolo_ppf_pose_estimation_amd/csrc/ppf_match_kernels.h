@@ -169,6 +169,7 @@ struct MatchArgs {
   uint32_t* hit_count;     /* [n_ref] */
   uint2* keys_a;           /* [n_ref][hit_cap] {bucket, hit index}: sorted by bucket after k_group */
   uint2* keys_b;           /* [n_ref][hit_cap] ping-pong */
+  const uint2* keys_sorted; /* where k_group leaves the grouped keys: keys_b on the LDS path, keys_a on the radix path */
   int hit_cap;
   int key_bits;            /* bits of a bucket id */
   int group_lds_buckets;   /* n_buckets when one LDS counter per bucket fits (single-pass grouping), else 0 */
@@ -299,19 +300,31 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
  */
 __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   __shared__ uint32_t base[256];
+  __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
   extern __shared__ uint32_t gcnt[]; /* LDS path: one counter per bucket (+ wave totals); radix path: wcnt[16][256] */
   const int r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t n = a.hit_count[r];
+  const bool lds_path = a.group_lds_buckets > 0;
+  const int nb1 = a.group_lds_buckets + 1;
+  if (lds_path) {
+    for (int k = tid; k < nb1; k += GROUP_BLOCK) gcnt[k] = 0;
+    __syncthreads();
+  }
   {
-    /* alpha_s of every hit (dense: only pairs that found a bucket): angle of (tsg + Rsg p2) about x.  A NaN
-     * alpha (non-finite cloud) makes the reference skip the pair: the hit is retired by emptying its key. */
+    /* ONE pass over the hits: alpha_s of every hit (dense: only pairs that found a bucket) = angle of
+     * (tsg + Rsg p2) about x; the exact number of votes this reference point will cast (used to launch the heaviest
+     * first); and, on the LDS path, the per-bucket histogram.  A NaN alpha (non-finite cloud) makes the reference
+     * skip the pair: the hit is retired by emptying its key. */
     const double* __restrict__ fr = a.frames + (size_t)r * 12;
     const double R10 = fr[3], R11 = fr[4], R12 = fr[5], R20 = fr[6], R21 = fr[7], R22 = fr[8], ty = fr[10], tz = fr[11];
     HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
     uint2* kk = a.keys_a + (size_t)r * a.hit_cap;
+    unsigned long long w = 0;
     for (uint32_t i = tid; i < n; i += GROUP_BLOCK) {
       const int j = (int)hits[i].alpha32;
+      uint32_t key = kk[i].x;
+      const uint32_t total = a.bucket_total[min(key, (uint32_t)(a.n_buckets - 1))]; /* independent gather, issued with the others */
       const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
       const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
       const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
@@ -319,17 +332,14 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
       if (ppf_alpha_in_frame(qy, qz, &as)) {
         hits[i].alpha32 = __float_as_uint((float)as);
         hits[i].alpha_s = as;
+        w += total;
       } else {
         hits[i].alpha32 = 0; hits[i].alpha_s = 0.0;
-        kk[i].x = 0xFFFFFFFFu; /* sorts last; k_vote gives it no entries */
+        key = 0xFFFFFFFFu;
+        kk[i].x = key; /* sorts last; k_vote gives it no entries */
       }
+      if (lds_path) atomicAdd(&gcnt[min(key, (uint32_t)(nb1 - 1))], 1u);
     }
-    __syncthreads();
-    /* exact number of votes this reference point will cast: used to launch the heaviest first */
-    __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
-    const uint2* k0 = a.keys_a + (size_t)r * a.hit_cap;
-    unsigned long long w = 0;
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) w += (k0[i].x == 0xFFFFFFFFu) ? 0u : a.bucket_total[k0[i].x];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
     if (lane == 0) wsum[wave] = w;
@@ -340,20 +350,15 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
       a.work[r] = t;
     }
   }
-  if (n < 2) return;
   uint2* src = a.keys_a + (size_t)r * a.hit_cap;
   uint2* dst = a.keys_b + (size_t)r * a.hit_cap;
-  if (a.group_lds_buckets > 0) {
+  if (n < 2 && !lds_path) return;
+  if (lds_path) {
     /* Grouping only needs equal buckets to be adjacent (any order inside a bucket: votes commute), so when one
-     * counter per bucket fits in LDS a single counting pass does it: histogram, scan, scatter through cursors.
-     * Retired hits (key 0xFFFFFFFF) go to the extra last counter. */
-    /* gcnt: group_lds_buckets + 1 counters, then 16 wave totals */
-    const int nb1 = a.group_lds_buckets + 1;
+     * counter per bucket fits in LDS the histogram of the pass above, a scan and one scatter through cursors do it.
+     * Retired hits (key 0xFFFFFFFF) go to the extra last counter.  The grouped keys stay in keys_b (k_vote reads
+     * a.keys_sorted). */
     uint32_t* wtot = gcnt + nb1;
-    for (int k = tid; k < nb1; k += GROUP_BLOCK) gcnt[k] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) atomicAdd(&gcnt[min(src[i].x, (uint32_t)(nb1 - 1))], 1u);
-    __syncthreads();
     /* exclusive scan of nb1 counters: each thread owns a contiguous slice */
     const int per = (nb1 + GROUP_BLOCK - 1) / GROUP_BLOCK;
     const int k0 = tid * per, k1 = min(k0 + per, nb1);
@@ -375,8 +380,6 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
       const uint2 key = src[i];
       dst[atomicAdd(&gcnt[min(key.x, (uint32_t)(nb1 - 1))], 1u)] = key;
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) src[i] = dst[i];
     return;
   }
   uint32_t (*wcnt)[256] = reinterpret_cast<uint32_t (*)[256]>(gcnt);
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const float Og = 0.5f * (float)A + G;
   const uint32_t tail_bytes = (uint32_t)(lane * 4); /* per-lane guard word for lanes past the end of a bucket */
 
-  const uint2* __restrict__ keys = a.keys_a + (size_t)r * a.hit_cap;
+  const uint2* __restrict__ keys = a.keys_sorted + (size_t)r * a.hit_cap;
   unsigned long long* start_mask = reinterpret_cast<unsigned long long*>(red + 16); /* VOTE_WAVES x u64 */
 
   for (int seg0 = 0; seg0 < n_hits; seg0 += VOTE_SEG) {
