@@ -249,6 +249,16 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
   return (int)(w.rank + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)));
 }
 
+/* pair records with alpha_m as signed 16.16 fixed point of alpha_m * A/(4 pi) (what k_vote adds; see vote_hits_fx) */
+__global__ __launch_bounds__(256) void k_records_to_fixed(const uint4* __restrict__ rec, size_t n, double scale, uint4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 r = rec[i];
+  const long long fa = (long long)__builtin_rint((double)__uint_as_float(r.z) * scale);
+  const long long fb = (long long)__builtin_rint((double)__uint_as_float(r.w) * scale);
+  out[i] = make_uint4(r.x, r.y, (uint32_t)(int32_t)fa, (uint32_t)(int32_t)fb);
+}
+
 /* key_lut[((k0*na + k1)*na + k2)*nd + k3] = dense bucket of hash(k0..k3) % slots, or -1 */
 __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int na, int nd,
                                                        int32_t* __restrict__ lut) {
@@ -1051,6 +1061,7 @@ struct ppf_model {
   DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
   DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
   DevBuf<uint4> records;          /* pair records, see place_entry */
+  DevBuf<uint4> records_fx;       /* the same records, alpha_m in 16.16 fixed point (k_records_to_fixed) */
   DevBuf<int32_t> key_lut;        /* quantised key -> bucket, see k_build_key_lut */
   int lut_na = 0, lut_nd = 0;
   uint64_t n_records = 0;
@@ -1213,6 +1224,12 @@ static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
     m->lut_nd = (int)std::max<size_t>(1, ((size_t)1 << 26) / ((size_t)m->lut_na * m->lut_na * m->lut_na));
   }
   const size_t n = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
+  if (PPF_VOTE_FIXED && m->n_records) { /* fixed-point twin of the records (only when k_vote is built to use it) */
+    HIPCHK(m->records_fx.reserve(m->n_records));
+    const double scale = (double)m->info.num_angles / (4 * PPF_PI) * 65536.0;
+    k_records_to_fixed<<<dim3((unsigned)((m->n_records + 255) / 256)), dim3(256), 0, st>>>(m->records.p, m->n_records, scale, m->records_fx.p);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(m->key_lut.reserve(n));
   k_build_key_lut<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(m->slotmap.p, m->info.slots - 1, m->lut_na, m->lut_nd, m->key_lut.p);
   HIPCHK(hipGetLastError());
@@ -1313,7 +1330,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   ppf_status sl = build_key_lut(m, st);
   if (sl != PPF_OK) return sl;
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
-                         m->records.bytes() + m->key_lut.bytes();
+                         m->records.bytes() + m->records_fx.bytes() + m->key_lut.bytes();
   return PPF_OK;
 }
 
@@ -1544,6 +1561,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride;
   va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
   va.key_lut = m->key_lut.p; va.lut_na = m->lut_na; va.lut_nd = m->lut_nd;
+  va.records_fx = m->records_fx.p;
   va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
   va.records = m->records.p;
   va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
@@ -1931,7 +1949,7 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
     return s;
   }
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
-                         m->records.bytes() + m->key_lut.bytes();
+                         m->records.bytes() + m->records_fx.bytes() + m->key_lut.bytes();
   HIPCHK(hipGetDevice(&m->device));
   *out = owner.release();
   return PPF_OK;

@@ -61,6 +61,11 @@ constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded pe
 #ifndef PPF_PIPE_VALU
 #define PPF_PIPE_VALU 4 /* VALU instructions scheduled between two LDS atomics of the pipelined vote loop */
 #endif
+#ifndef PPF_VOTE_FIXED
+#define PPF_VOTE_FIXED 0 /* 1: 16.16 fixed-point alpha bins, 2.5-2.75 VALU per vote instead of 4.9 (vote_hits_fx).  Bit-exact (same
+                          parity tests), but NOT faster on gfx950 today: with the VALU work halved the kernel sits on its LDS-atomic
+                          bound (13.8 ms either way; 11.7 ms with conflict-free addresses), so the plain fp32 path stays the default */
+#endif
 #ifndef PPF_VOTE_PIPE
 #define PPF_VOTE_PIPE 1 /* atomics of hit h issued under the arithmetic of hit h+1 (vote_hits) */
 #endif
@@ -161,6 +166,7 @@ struct MatchArgs {
   const uint32_t* bucket_off;
   int n_buckets;
   const uint4* records;    /* pair records {row_a, row_b, alpha_a, alpha_b}; bucket_off counts records */
+  const uint4* records_fx; /* the same records with alpha_m as signed 16.16 fixed point of alpha_m*A/(4pi): what k_vote adds */
   int n_tiles, tile_refs, num_angles, n_model;
   double angle_step, dist_step;
   /* per-batch scratch */
@@ -673,6 +679,150 @@ __device__ __forceinline__ void vote_hits_single(unsigned char* __restrict__ acc
   if (nh > 0) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)adr_prev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+/* ---- 16.16 fixed-point votes --------------------------------------------------------------------------------
+ * bin = floor(x), x = (alpha_m - alpha_s)*A/(4pi) + A/2.  Per entry fx = rint(alpha_m * A/(4pi) * 65536) (signed, built
+ * with the table), per hit C = rint((A/2 - alpha_s*A/(4pi)) * 65536) + 2 (fp64, once per staged hit): the integer sum
+ * s = fx + C equals x*65536 + 2 + e with |e| <= 1.01 (two roundings; the fp64 products are exact to 1e-9 units), so
+ * whenever the 16 fraction bits of s are >= 4, floor(x) = s >> 16 -- and it is also what the reference's fp64 chain
+ * gives, which differs from x by ~1e-14.  Otherwise (6e-5 of the votes) the lane evaluates that fp64 chain.
+ * Cost per vote: v_add_u32 (s), v_mad_u32_u16 (LDS address = hi16(s)*4 + row: the shift, the mask and the add in
+ * one instruction), half a v_min3_u16 (the guard: running minimum of the low halves), ds_add_u32. */
+#ifndef PPF_FX_ASM
+#define PPF_FX_ASM 1 /* v_mad_u32_u16 / v_min3_u16 through inline asm (the compiler does not select them from C++) */
+#endif
+__device__ __forceinline__ uint32_t fx_min3(uint32_t m, uint32_t a, uint32_t b) {
+#if PPF_FX_ASM
+  uint32_t r;
+  asm("v_min3_u16 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+#else /* 16-bit minimum of the low halves: selected as v_min3_u16 */
+  const unsigned short x = (unsigned short)m, y = (unsigned short)a, z = (unsigned short)b;
+  const unsigned short t = x < y ? x : y;
+  return (uint32_t)(t < z ? t : z);
+#endif
+}
+__device__ __forceinline__ uint32_t fx_addr(uint32_t s, uint32_t row) { /* hi16(s) * 4 + row */
+#if PPF_FX_ASM
+  uint32_t r;
+  asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(s), "v"(row));
+  return r;
+#else
+  return (uint32_t)(unsigned short)(s >> 16) * (uint32_t)(unsigned short)4 + row;
+#endif
+}
+template <int U>
+__device__ __forceinline__ void fx_sums(const uint4* rec, const uint32_t C, uint32_t (&sa)[U], uint32_t (&sb)[U], uint32_t& guard) {
+  uint32_t m = 0xFFFFu;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    sa[u] = rec[u].z + C;
+    sb[u] = rec[u].w + C;
+    m = fx_min3(m, sa[u], sb[u]);
+  }
+  guard = m;
+}
+/* rare path: votes whose fraction is inside the guard get the exact fp64 bin (alpha_m comes from the float records) */
+template <int U>
+__device__ __forceinline__ void fx_fix(const uint4* __restrict__ srcf, const uint32_t e0, const uint32_t c, const int lane,
+                                       const double* __restrict__ asd_lds, const int A, const uint32_t T, const uint32_t guard,
+                                       uint32_t (&sa)[U], uint32_t (&sb)[U]) {
+  if (__builtin_expect(__any((guard & 0xFFFFu) < T), 0)) {
+    const double asd = *asd_lds; /* exact alpha_s of this hit */
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (__any(((sa[u] & 0xFFFFu) < T) | ((sb[u] & 0xFFFFu) < T))) {
+        const uint4 rf = srcf[min(e0 + (uint32_t)(u * 64 + lane), c - 1u)];
+        if ((sa[u] & 0xFFFFu) < T) sa[u] = (uint32_t)ppf_alpha_bin_exact(__uint_as_float(rf.z), asd, A) << 16;
+        if ((sb[u] & 0xFFFFu) < T) sb[u] = (uint32_t)ppf_alpha_bin_exact(__uint_as_float(rf.w), asd, A) << 16;
+      }
+    }
+  }
+}
+template <int U>
+__device__ __forceinline__ void fx_issue(const uint32_t (&pa)[U], const uint32_t (&pb)[U], const uint32_t (&sa)[U], const uint32_t (&sb)[U],
+                                         const int n_valid) {
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    if (u < n_valid) {
+#ifdef PPF_FX_NOCONFLICT /* diagnostic: same instruction stream, conflict-free addresses */
+      uint32_t aa = fx_addr(sa[u], pa[u]), ab = fx_addr(sb[u], pb[u]);
+      asm volatile("" ::"v"(aa), "v"(ab));
+      aa = (uint32_t)((threadIdx.x & 63) * 4 + u * 512 + 29184 + 1024);
+      ab = aa + 256;
+      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)aa, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)ab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(sa[u], pa[u]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(sb[u], pb[u]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    }
+  }
+}
+template <int U>
+__device__ __forceinline__ void fx_stage(const uint4* rec, const int n_valid, const uint32_t cfix_v, const int hh,
+                                         const double* __restrict__ asd_lds, const int A, const uint32_t T, const uint4* __restrict__ srcf,
+                                         const uint32_t e0, const uint32_t c, const int lane, const uint32_t (&pa)[U], const uint32_t (&pb)[U],
+                                         const uint32_t (&psa)[U], const uint32_t (&psb)[U], uint32_t (&nsa)[U], uint32_t (&nsb)[U]) {
+  const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)cfix_v, hh);
+  uint32_t guard;
+  fx_issue<U>(pa, pb, psa, psb, n_valid);
+  fx_sums<U>(rec, C, nsa, nsb, guard);
+#pragma unroll
+  for (int i = 0; i < 2 * U; i++) {
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); /* VALU */
+    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); /* DS */
+  }
+  fx_fix<U>(srcf, e0, c, lane, asd_lds + hh, A, T, guard, nsa, nsb);
+}
+/* all hits of a work item against one register batch of records (rec: fixed-point records e0.. of the run) */
+template <int U>
+__device__ __forceinline__ void vote_hits_fx(unsigned char* __restrict__ acc_bytes, const uint4* rec, const int n_valid, const uint32_t cfix_v,
+                                             const int nh, const double* __restrict__ asd_lds, const int A, const uint32_t T,
+                                             const uint4* __restrict__ srcf, const uint32_t e0, const uint32_t c, const int lane) {
+  uint32_t pa[U], pb[U], sa0[U], sb0[U], sa1[U], sb1[U];
+  const uint32_t base = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes; /* LDS byte address of the guard region */
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    pa[u] = base + rec[u].x;
+    pb[u] = base + rec[u].y;
+    asm volatile("" : "+v"(pa[u]), "+v"(pb[u])); /* computed once per batch, not rematerialised per vote */
+  }
+  {
+    uint32_t guard;
+    fx_sums<U>(rec, (uint32_t)__builtin_amdgcn_readlane((int)cfix_v, 0), sa0, sb0, guard);
+    fx_fix<U>(srcf, e0, c, lane, asd_lds, A, T, guard, sa0, sb0);
+  }
+  int hh = 1;
+  for (; hh + 1 < nh; hh += 2) {
+    fx_stage<U>(rec, n_valid, cfix_v, hh, asd_lds, A, T, srcf, e0, c, lane, pa, pb, sa0, sb0, sa1, sb1);
+    fx_stage<U>(rec, n_valid, cfix_v, hh + 1, asd_lds, A, T, srcf, e0, c, lane, pa, pb, sa1, sb1, sa0, sb0);
+  }
+  if (hh < nh) {
+    fx_stage<U>(rec, n_valid, cfix_v, hh, asd_lds, A, T, srcf, e0, c, lane, pa, pb, sa0, sb0, sa1, sb1);
+    fx_issue<U>(pa, pb, sa1, sb1, n_valid);
+  } else {
+    fx_issue<U>(pa, pb, sa0, sb0, n_valid);
+  }
+}
+/* runs of at most 32 pair records: one entry per lane (see vote_hits_single) */
+__device__ __forceinline__ void vote_hits_single_fx(unsigned char* __restrict__ acc_bytes, const uint32_t row_bytes, const uint32_t fxv,
+                                                    const uint32_t alpha_bits, const uint32_t cfix_v, const int nh,
+                                                    const double* __restrict__ asd_lds, const int A, const uint32_t T) {
+  uint32_t pr = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes + row_bytes;
+  asm volatile("" : "+v"(pr));
+  uint32_t s_prev = 0;
+  for (int hh = 0; hh < nh; hh++) {
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)cfix_v, hh);
+    if (hh) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(s_prev, pr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t sv = fxv + C;
+    if (__builtin_expect(__any((sv & 0xFFFFu) < T), 0)) {
+      if ((sv & 0xFFFFu) < T) sv = (uint32_t)ppf_alpha_bin_exact(__uint_as_float(alpha_bits), asd_lds[hh], A) << 16;
+    }
+    s_prev = sv;
+  }
+  if (nh > 0) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(s_prev, pr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
@@ -706,7 +856,12 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   }
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
+#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
+  const uint4* __restrict__ records = a.records_fx;
+  const uint4* __restrict__ records_f = a.records; /* float alpha_m: only read on the guard path */
+#else
   const uint4* __restrict__ records = a.records;
+#endif
   const HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
   const int n_hits = (int)a.hit_count[r];
   const float S = (float)((double)A / (4 * PPF_PI));
@@ -716,6 +871,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const float G = PPF_GUARD_REL * (float)A;
 #endif
   const float G2 = 2.0f * G;
+  (void)G2;
   const float Og = 0.5f * (float)A + G;
   const uint32_t tail_bytes = (uint32_t)(lane * 4); /* per-lane guard word for lanes past the end of a bucket */
 
@@ -736,7 +892,12 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         off = boff[key.x];
         cnt = boff[key.x + 1] - off;
       }
+#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
+      /* C = rint((A/2 - alpha_s * A/(4 pi)) * 65536) + 2 (the folded guard), fp64 */
+      seg_a32[tid] = (uint32_t)(long long)__builtin_rint((0.5 * (double)A - h.alpha_s * ((double)A / (4 * PPF_PI))) * 65536.0) + 2u;
+#else
       seg_a32[tid] = h.alpha32;
+#endif
       seg_a64[tid] = h.alpha_s;
       is_start = (tid == 0) || (keys[seg0 + tid - 1].x != key.x);
     }
@@ -821,6 +982,16 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       float ohg_v = 0.f;
       if (lane < nh) ohg_v = Og - __uint_as_float(seg_a32[h0 + lane]) * S;
       const uint4* __restrict__ src = records + o;
+#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
+      const uint32_t cfix_v = lane < nh ? seg_a32[h0 + lane] : 0u; /* lane l: fixed-point offset of hit h0+l */
+      const uint4* __restrict__ srcf = records_f + o;
+#ifdef PPF_FORCE_EXACT
+      const uint32_t T = 0x10000u;
+#else
+      const uint32_t T = 4u;
+#endif
+      (void)ohg_v;
+#endif
       constexpr uint32_t B = 64 * VOTE_UNROLL; /* records per batch */
       const uint32_t nfull = c / B;
       /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
@@ -832,7 +1003,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       uint32_t b = 0;
       while (b < nfull) {
         load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
-#if PPF_ABL == 0 && PPF_VOTE_PIPE
+#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
+        vote_hits_fx<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, cfix_v, nh, &seg_a64[h0], A, T, srcf, b * B, c, lane);
+#elif PPF_ABL == 0 && PPF_VOTE_PIPE
         vote_hits<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, ohg_v, nh, &seg_a64[h0], G2, A);
 #else
         for (int hh = 0; hh < nh; hh++) {
@@ -842,7 +1015,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 #endif
         if (++b >= nfull) break;
         load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
-#if PPF_ABL == 0 && PPF_VOTE_PIPE
+#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
+        vote_hits_fx<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, cfix_v, nh, &seg_a64[h0], A, T, srcf, b * B, c, lane);
+#elif PPF_ABL == 0 && PPF_VOTE_PIPE
         vote_hits<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, ohg_v, nh, &seg_a64[h0], G2, A);
 #else
         for (int hh = 0; hh < nh; hh++) {
@@ -859,7 +1034,12 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         const uint4 r = src[min(e, c - 1)];
         const bool second = (lane & 1) != 0;
         const uint32_t row_bytes = e < c ? (second ? r.y : r.x) : tail_bytes;
+#if PPF_VOTE_FIXED
+        const uint4 rf = srcf[min(e, c - 1)];
+        vote_hits_single_fx(acc_bytes, row_bytes, second ? r.w : r.z, second ? rf.w : rf.z, cfix_v, nh, &seg_a64[h0], A, T);
+#else
         vote_hits_single(acc_bytes, row_bytes, second ? r.w : r.z, S, ohg_v, nh, &seg_a64[h0], G2, A);
+#endif
       } else
 #endif
       if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
@@ -874,12 +1054,21 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         /* most buckets are smaller than a batch (median 18 records): only the 64-record groups that hold data get
          * their bin arithmetic, through an instantiation per group count */
         static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
+#if PPF_VOTE_FIXED
+        switch (n_valid) {
+          case 1: vote_hits_fx<1>(acc_bytes, ea, 1, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
+          case 2: vote_hits_fx<2>(acc_bytes, ea, 2, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
+          case 3: vote_hits_fx<3>(acc_bytes, ea, 3, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
+          default: vote_hits_fx<4>(acc_bytes, ea, 4, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
+        }
+#else
         switch (n_valid) {
           case 1: vote_hits<1>(acc_bytes, ea, 1, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
           case 2: vote_hits<2>(acc_bytes, ea, 2, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
           case 3: vote_hits<3>(acc_bytes, ea, 3, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
           default: vote_hits<4>(acc_bytes, ea, 4, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
         }
+#endif
 #else
         for (int hh = 0; hh < nh; hh++) {
           const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
