@@ -303,10 +303,13 @@ __host__ __device__ __forceinline__ uint32_t records_for(uint32_t n_entries) {
 }
 
 /* phase 0: count; phase 1: place (rec_off = record offset of the (tile, bucket)) */
+/* rank_mode 0: k = arrival order inside the (level, class) (atomic cursor); 1: k = `rank` (the entry's rank by phase
+ * inside its class, from a sort); 2: k counted down from the top of the class (the few mirrored spill entries, which
+ * are not part of the sort) */
 __device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_bytes, float am, int num_angles, int levels,
                                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
                                             uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
-                                            uint4* __restrict__ records) {
+                                            uint4* __restrict__ records, int rank_mode = 0, uint32_t rank = 0) {
   uint32_t c, lv;
   entry_class_level(row_bytes, am, num_angles, levels, &c, &lv);
   const size_t cbase = tb * (size_t)levels * 32;
@@ -315,7 +318,10 @@ __device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_b
     atomicAdd(&class_cnt[cbase + lv * 32 + c], 1u);
     return;
   }
-  const uint32_t k = atomicAdd(&class_cur[cbase + lv * 32 + c], 1u);
+  uint32_t k;
+  if (rank_mode == 1) k = rank;
+  else if (rank_mode == 2) k = class_cnt[cbase + lv * 32 + c] - 1u - atomicAdd(&class_cur[cbase + lv * 32 + c], 1u);
+  else k = atomicAdd(&class_cur[cbase + lv * 32 + c], 1u);
   uint32_t j = 0;
   for (uint32_t l = 0; l < lv; l++)
     for (uint32_t cc = 0; cc < 32; cc++) j += class_cnt[cbase + l * 32 + cc];
@@ -334,7 +340,8 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
                             const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int n_tiles,
                             int num_angles, int levels, uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
                             uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
-                            uint4* __restrict__ records, uint32_t* __restrict__ bucket_slot, int phase) {
+                            uint4* __restrict__ records, uint32_t* __restrict__ bucket_slot, int phase,
+                            const uint32_t* __restrict__ pair_rank = nullptr) {
   const size_t total = (size_t)n_model * n_model;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -347,12 +354,53 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
   if (phase == 0 && bucket_slot) bucket_slot[b] = slot;
   place_entry(phase, (size_t)tile * n_buckets + b,
               (uint32_t)((vote_guard(num_angles) + (i - tile * tile_refs) * vote_pitch(num_angles)) * 4), am, num_angles,
-              levels, counts, rec_off, class_cnt, class_cur, records);
+              levels, counts, rec_off, class_cnt, class_cur, records, pair_rank ? 1 : 0, pair_rank ? pair_rank[idx] : 0u);
   /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
    * that point lives in the next tile, the entry is mirrored there: bin A -> cell 0, others -> guard. */
   if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1)
     place_entry(phase, (size_t)(tile + 1) * n_buckets + b, (uint32_t)((vote_guard(num_angles) - num_angles) * 4), am,
-                num_angles, levels, counts, rec_off, class_cnt, class_cur, records);
+                num_angles, levels, counts, rec_off, class_cnt, class_cur, records, pair_rank ? 2 : 0, 0u);
+}
+
+/* sort keys of the model pairs for the dealing order: key_class = (tile*n_buckets + bucket)*32 + bank class (invalid pairs:
+ * `invalid`), key_phase = position of alpha_m inside its bin, 16 bits */
+__global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
+                                                    const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int num_angles,
+                                                    uint32_t invalid, uint32_t* __restrict__ key_class, uint32_t* __restrict__ key_phase,
+                                                    uint32_t* __restrict__ vals) {
+  const size_t total = (size_t)n_model * n_model;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  vals[idx] = (uint32_t)idx;
+  const uint32_t slot = pair_slot[idx];
+  if (slot == 0xFFFFFFFFu) { key_class[idx] = invalid; key_phase[idx] = 0; return; }
+  const int i = (int)(idx / n_model);
+  const int b = slot_to_bucket(slotmap, slot);
+  const int tile = i / tile_refs;
+  const float am = pair_alpha[idx];
+  const uint32_t row_bytes = (uint32_t)((vote_guard(num_angles) + (i - tile * tile_refs) * vote_pitch(num_angles)) * 4);
+  uint32_t c, lv;
+  entry_class_level(row_bytes, am, num_angles, 1, &c, &lv);
+  const float q = am * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
+  key_class[idx] = (uint32_t)(((size_t)tile * n_buckets + b) * 32 + c);
+  key_phase[idx] = min((uint32_t)((q - floorf(q)) * 65536.0f), 65535u);
+}
+__global__ __launch_bounds__(256) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, size_t n,
+                                                    uint32_t* __restrict__ dst) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) dst[p] = src[idx[p]];
+}
+/* rank of every pair inside its run of equal class keys: pair_rank[vals[p]] = p - start of p's run */
+__global__ __launch_bounds__(256) void k_train_ranks(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ starts, uint32_t n_runs,
+                                                     size_t n, uint32_t* __restrict__ pair_rank) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t lo = 0, hi = n_runs; /* last run start <= p */
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((size_t)starts[mid] <= p) lo = mid; else hi = mid;
+  }
+  pair_rank[vals[p]] = (uint32_t)(p - starts[lo]);
 }
 
 __global__ void k_record_counts(const uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_cnt, size_t n) {
@@ -1275,8 +1323,14 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(offsets.reserve(ncnt));
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
+  /* Dealing order inside a bucket.  Sorted (default): ONE level, and an entry's round is its RANK BY PHASE inside its
+   * bank class (the position of alpha_m inside its bin), so a round holds entries of similar phase from every class:
+   * they take the one-bin jitter together, and with a single level the classes are four times fuller, hence better
+   * balanced -- fewer 32-groups that straddle rounds and repeat a class.  PPF_TABLE_UNSORTED=1: the earlier scheme,
+   * phase quantised to TABLE_LEVELS_MAX levels and arrival order inside a (level, class). */
+  const bool sorted_deal = getenv("PPF_TABLE_UNSORTED") == nullptr;
   /* per (tile, bucket, phase level, bank class) counters; fewer levels when they would not fit 2 GiB */
-  int levels = TABLE_LEVELS_MAX;
+  int levels = sorted_deal ? 1 : TABLE_LEVELS_MAX;
   while (levels > 1 && ncnt * (size_t)levels * 32 * sizeof(uint32_t) * 2 > (2ull << 30)) levels >>= 1;
   m->levels = levels;
   const size_t ncls = ncnt * (size_t)levels * 32;
@@ -1317,9 +1371,33 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
     k_record_init<<<dim3((n_records + 255) / 256), dim3(256), 0, st>>>(m->records.p, n_records);
     HIPCHK(hipGetLastError());
   }
+  DevBuf<uint32_t> pair_rank;
+  if (sorted_deal) { /* rank of every pair by phase inside its (tile, bucket, class): two stable sorts */
+    DevBuf<uint32_t> kcls, kph, v1, kt, v2, starts;
+    HIPCHK(kcls.reserve(NN)); HIPCHK(kph.reserve(NN)); HIPCHK(v1.reserve(NN)); HIPCHK(kt.reserve(NN)); HIPCHK(v2.reserve(NN));
+    HIPCHK(pair_rank.reserve(NN));
+    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 32);
+    k_train_keys<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets, m->info.tile_refs,
+                                                   m->info.num_angles, invalid, kcls.p, kph.p, v1.p);
+    HIPCHK(hipGetLastError());
+    uint32_t* va = nullptr;
+    uint32_t n_runs = 0;
+    s = sort_segments(kph, v1, kt, v2, (int)NN, 65535ull, starts, &va, &n_runs, st);
+    if (s != PPF_OK) return s;
+    k_gather_u32<<<dim3(nblk), dim3(256), 0, st>>>(kcls.p, va, NN, kph.p); /* class keys in phase order */
+    HIPCHK(hipGetLastError());
+    DevBuf<uint32_t>& vin = va == v1.p ? v1 : v2;
+    DevBuf<uint32_t>& vtmp = va == v1.p ? v2 : v1;
+    s = sort_segments(kph, vin, kt, vtmp, (int)NN, (unsigned long long)invalid, starts, &va, &n_runs, st);
+    if (s != PPF_OK) return s;
+    k_train_ranks<<<dim3(nblk), dim3(256), 0, st>>>(va, starts.p, n_runs, NN, pair_rank.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); /* the sort scratch dies here */
+  }
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
                                                 m->info.tile_refs, T, m->info.num_angles, levels, counts.p, offsets.p,
-                                                class_cnt.p, class_cur.p, m->records.p, nullptr, 1);
+                                                class_cnt.p, class_cur.p, m->records.p, nullptr, 1,
+                                                sorted_deal ? pair_rank.p : nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(m->bucket_total.reserve(std::max<uint32_t>(n_buckets, 1)));
   if (n_buckets) {
