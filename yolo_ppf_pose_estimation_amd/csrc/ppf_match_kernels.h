@@ -26,7 +26,8 @@
  *              loads a batch of 64 x VOTE_UNROLL entries (coalesced 8-byte loads, next batch
  *              prefetched into a second register set) and votes it once per hit of the item straight
  *              from registers: HBM/L2 traffic per vote drops from 8 B to 8/m B and the kernel is bound
- *              by VALU issue (5 VALU per vote) and the LDS atomic rate.
+ *              by the LDS atomic rate (one ds_add_u32 per vote, bank and same-cell conflicts included;
+ *              measured: halving the VALU work per vote does not change its time).
  *
  * Alpha bin, exactly: bin = (int)(A*(alpha_m - alpha_s + 2pi)/(4pi)) in fp64 is what the reference
  * computes.  The fast path evaluates q = (alpha_m - alpha_s)*A/(4pi) + A/2 in fp32 (|error| <= 9e-8*A,
