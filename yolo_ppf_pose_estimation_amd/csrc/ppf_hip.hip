@@ -78,15 +78,16 @@ class DevPool {
     static DevPool* p = new DevPool(); /* never destroyed: no hipFree after the runtime is gone */
     return *p;
   }
-  hipError_t acquire(size_t bytes, void** out, size_t* granted) {
+  hipError_t acquire(size_t bytes, void** out, size_t* granted, int* device) {
     *out = nullptr;
     const size_t want = std::max<size_t>(bytes, 256);
-    if (off_) { *granted = want; return hipMalloc(out, want); }
-    int cls = 8;
-    while (((size_t)1 << cls) < want) cls++;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    *device = dev; /* a block goes back to the list of the device it was allocated on, whatever is current then */
+    if (off_) { *granted = want; return hipMalloc(out, want); }
+    int cls = 8;
+    while (((size_t)1 << cls) < want) cls++;
     {
       std::lock_guard<std::mutex> g(mu_);
       auto& lst = free_[key(dev, cls)];
@@ -100,13 +101,11 @@ class DevPool {
     }
     return e;
   }
-  void release(void* p, size_t granted) {
+  void release(void* p, size_t granted, int dev) {
     if (!p) return;
     if (off_) { (void)hipFree(p); return; }
     int cls = 8;
     while (((size_t)1 << cls) < granted) cls++;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> g(mu_);
     free_[key(dev, cls)].push_back(p);
   }
@@ -131,18 +130,19 @@ struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;      /* elements usable */
   size_t granted = 0;  /* bytes of the block behind p */
+  int device = 0;      /* device the block lives on */
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { DevPool::get().release(p, granted); }
+  ~DevBuf() { DevPool::get().release(p, granted, device); }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) { /* growing a live buffer (rare): earlier asynchronous work may still use the old block */
       (void)hipDeviceSynchronize();
-      DevPool::get().release(p, granted); p = nullptr; cap = 0; granted = 0;
+      DevPool::get().release(p, granted, device); p = nullptr; cap = 0; granted = 0;
     }
     void* q = nullptr;
-    hipError_t e = DevPool::get().acquire(std::max<size_t>(n, 1) * sizeof(T), &q, &granted);
+    hipError_t e = DevPool::get().acquire(std::max<size_t>(n, 1) * sizeof(T), &q, &granted, &device);
     if (e == hipSuccess) { p = static_cast<T*>(q); cap = n; }
     return e;
   }
