@@ -543,6 +543,11 @@ __global__ void k_finalize(FinalArgs a) {
  *    quaternion; cluster votes = sum of member votes.
  * 4. clusters ranked by (votes desc, creation order asc) and written out.
  */
+__global__ __launch_bounds__(256) void k_widen_u32(const uint32_t* __restrict__ in, int n, unsigned long long* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
 /* Generic ranking: perm[rank] = i and rank_of[i] = rank for keys sorted (key desc, index asc).  n may live on the
  * device (n_dev != nullptr).  O(n^2) spread wide: a workgroup ranks 16 keys, 16 threads per key each counting every
  * 16th key of a 1024-key LDS tile, partial counts added by shuffles. */
@@ -1127,6 +1132,7 @@ struct ppf_workspace {
   DevBuf<uint32_t> hit_count;
   DevBuf<unsigned long long> work;
   DevBuf<uint32_t> perm;
+  DevBuf<uint32_t> perm_group;
   DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
@@ -1659,6 +1665,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->hit_count.reserve(batch));
   HIPCHK(ws->work.reserve(batch));
   HIPCHK(ws->perm.reserve(batch));
+  HIPCHK(ws->perm_group.reserve(batch));
   va.bucket_total = m->bucket_total.p; va.work = ws->work.p; va.perm = ws->perm.p;
   va.frames = ws->frames.p; va.hits = ws->hits.p; va.hit_count = ws->hit_count.p; va.hit_cap = n_paired;
   va.keys_a = ws->keys_a.p; va.keys_b = ws->keys_b.p;
@@ -1696,6 +1703,13 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[4], st));
     k_pairs<<<dim3(pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
     HIPCHK(hipGetLastError());
+    if (!getenv("PPF_GROUP_INDEX_ORDER")) { /* k_group takes the reference points with the most hits first */
+      k_widen_u32<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(ws->hit_count.p, va.n_ref, ws->work.p);
+      k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(ws->work.p, va.n_ref, nullptr, ws->perm_group.p, nullptr);
+      va.perm_group = ws->perm_group.p;
+    } else {
+      va.perm_group = nullptr;
+    }
     k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), group_lds, st>>>(va);
     HIPCHK(hipGetLastError());
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);

@@ -183,6 +183,7 @@ struct MatchArgs {
   const uint32_t* bucket_total; /* [n_buckets] entries of a bucket over all tiles */
   unsigned long long* work;     /* [n_ref] votes the reference point will cast (sum of its hits' bucket sizes) */
   uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
+  const uint32_t* perm_group;   /* [n_ref] reference points ordered by hit count, for k_group (may be NULL) */
   /* results, indexed by global r */
   uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   __shared__ uint32_t base[256];
   __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
   extern __shared__ uint32_t gcnt[]; /* LDS path: one counter per bucket (+ wave totals); radix path: wcnt[16][256] */
-  const int r = blockIdx.x;
+  const int r = a.perm_group ? (int)a.perm_group[blockIdx.x] : (int)blockIdx.x; /* most hits first: no long block at the tail */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t n = a.hit_count[r];
   const bool lds_path = a.group_lds_buckets > 0;
