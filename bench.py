@@ -1,69 +1,92 @@
 #!/usr/bin/env python3
-"""bench.py — PPF pair-matches/s of the MI355X voting engine on BASELINE.json's workload.
+"""bench.py — PPF pair-matches/s of the MI355X voting engine on BASELINE.json's workloads.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5] [--shard refs]
 
-A step = one pass of the hot path over one synthetic YOLO crop per rank: pair features + hash +
-table lookup + Hough voting (k_vote) + argmax + pose assembly (k_finalize) + pose clustering, with
-the crop and the model table already resident in HBM.  At N=1 the workload is BASELINE.json
-configs[1] (C2): the bottle model sampled to 2,000 points vs one 50,000-point synthetic crop
-(seed 12345), presampled so all 50k points vote, reference stride 20 -> 2,500 reference points.
-At N>1 every rank matches its own crop (config C3, seeds 1000+rank; weak scaling) and the only
-collective is one all_gather (RCCL) of each rank's top poses per step.
+`--gpus N` with N > 1 starts N ranks BY ITSELF when it was not started under torch.distributed.run
+(no RANK/WORLD_SIZE in the environment): the parent process never imports torch or touches the GPU, it
+only spawns N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and relays rank 0's line.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks already exist and each
+process is one of them.  WORLD_SIZE != --gpus is an error.
+
+A step = one pass of the hot path over one synthetic YOLO crop per rank: pair features + hash + table
+lookup (k_pairs) + grouping (k_group) + Hough voting (k_vote) + argmax + pose assembly (k_finalize) + pose
+clustering, with the crop and the model table already resident in HBM.
+
+  c2  (default) BASELINE.json configs[1]: bottle sampled to 2,000 points vs one 50,000-point crop (seed 12345),
+      presampled so all 50k points vote, reference stride 20 -> 2,500 reference points.  At N > 1 this is
+      configs[2] (C3): every rank matches its own crop (seeds 1000+rank, weak scaling) and the only collective is
+      one all_gather (RCCL) of each rank's top-5 clustered poses per step, taken from device memory.
+  c4  configs[3]: ~10k-point model vs one 200,000-point scene.  `--shard refs` at N > 1 strides the scene's
+      reference points over the ranks (strong scaling), all_gathers the raw per-reference poses on the
+      device and clusters them on rank 0.
+  c5  configs[4]: four resident model tables x 8 crops per rank through the batched entry.
 
 The line printed by rank 0 carries
-  value        whole-job pair-matches (accumulator increments, exact integer) per second
-  roofline     the voting kernel against the HBM roofline: algorithmic bytes per launch
-               (SURVEY.md §8d / DESIGN.md §5) / its average device time measured with HIP events
-               on the launch stream
-  cpu_baseline the CPU oracle (kind "port": our restatement of the reference's library path,
-               OpenMP over reference points where upstream parallelises) timed on a bounded
-               sample of the same workload, N=1 only
+  value        whole-job pair-matches (accumulator increments the reference would make, exact integer) per second
+  roofline     the voting kernel against HBM: measured fabric traffic per launch (committed PMC pass) / its
+               average device time (HIP events on the launch stream); the SURVEY section 8d figure stays beside it as
+               algorithmic_bytes_per_launch
+  lds_roofline what actually bounds k_vote: LDS atomic lane-operations per second against the ds_add_u32 ceiling
+  cpu_baseline the CPU oracle (kind "port", -O3 -march=native build made on this box) on a bounded sample of the
+               same workload: median of 5 repetitions on all usable cores plus a 1-thread figure; N = 1 only
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# ds_add_u32 ceiling measured with profiles/ubench_valu_lds.hip: 14.6 lanes/clk/CU x 256 CUs x 2.4 GHz
-LDS_ATOMIC_PEAK = 8.97e12
-
-MODEL_STEP = 0.036      # bottle -> 2,000 sampled model points
-SCENE_POINTS = 50000
-SCENE_STEP = 1.0 / 20.0  # reference stride 20 -> 2,500 reference points
-TOP_K = 5                # poses kept per crop (CloudProcessing.h:455,508)
+# LDS atomic ceilings, lane-operations per second chip-wide:
+LDS_ATOMIC_PEAK_UBENCH = 8.97e12  # profiles/r01_ubench_valu_lds.txt: ds_add_u32 14.6 lanes/clk/CU x 256 CUs x 2.4 GHz
+LDS_ATOMIC_PEAK_GUIDE = 9.83e12   # MI355X_MICROARCH.md LDS section: 16 lanes/clk/CU x 256 x 2.4 GHz
 
 
-def algorithmic_bytes(n_ref, n_model, num_angles, n_pairs, n_votes):
-    """per reference point 24 B (its xyzn) + accumulator clear and scan
-    2 x 4 x N_m x A + 12 B result; per scene pair 24 B (xyzn) + 8 B (bucket header); per vote 8 B
-    model entry + 8 B accumulator read-modify-write."""
-    return n_ref * (24 + 2 * 4 * n_model * num_angles + 12) + n_pairs * 32 + n_votes * 16
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
+    ap.add_argument("--shard", default="crops", choices=["crops", "refs"],
+                    help="c4 at N > 1: 'refs' strides the reference points of the one scene over the ranks")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU baseline: seconds per repetition")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="crops in flight: 1 (default) = strictly one after another, so the HIP-event kernel times "
+                         "behind `roofline` are the kernel's own; 2-3 overlap independent crops on separate streams")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="ranks rendezvous (gloo, CPU), report RANK/WORLD_SIZE and stop before any device use")
+    return ap.parse_args(argv)
 
 
-def measured_traffic(n_votes):
-    """HBM/fabric bytes per k_vote launch from the committed PMC passes (profiles/*_pmc_traffic.json), if they
-    were taken on this exact workload; otherwise None.  bench.py cannot collect PMC counters on itself."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-        try:
-            t = json.load(open(f))
-            if t.get("n_votes_per_launch") == n_votes:
-                best = t["hbm_bytes_per_launch_k_vote"]["gfx950_corrected_2xFETCH"]
-        except Exception:
-            pass
-    return best
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: runs in a process that has NOT touched the GPU (no torch import up to here)
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def usable_cpus():
@@ -86,62 +109,107 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(bottle, scene, n_ref_total, target_seconds=15.0):
-    """Oracle (CPU restatement) on a bounded sample of the step's reference points."""
+def algorithmic_bytes(n_ref, n_model, num_angles, n_pairs, n_votes):
+    """per reference point 24 B (its xyzn) + accumulator clear and scan 2 x 4 x N_m x A + 12 B
+    result; per scene pair 24 B (xyzn) + 8 B (bucket header); per vote 8 B model entry + 8 B accumulator RMW."""
+    return n_ref * (24 + 2 * 4 * n_model * num_angles + 12) + n_pairs * 32 + n_votes * 16
+
+
+def measured_traffic(n_votes):
+    """HBM/fabric bytes per k_vote launch from the committed PMC passes (profiles/*_pmc_traffic.json) taken on this
+    exact workload (same vote count per launch), newest file first; None when there is none.  bench.py cannot collect
+    PMC counters on itself."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+            if t.get("n_votes_per_launch") == n_votes:
+                return t["hbm_bytes_per_launch_k_vote"]["gfx950_corrected_2xFETCH"], os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
+
+
+def cpu_baseline(model_step, bottle, scene, n_ref_total, seconds_per_rep, reps=5):
+    """The oracle (CPU restatement, -O3 -march=native build made on this machine) on an evenly spaced sample of the
+    step's reference points: median of `reps` runs on every usable core, and one 1-thread run."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
+    from yolo_ppf_pose_estimation_amd import workloads as W
 
+    native = oracle_lib.use_native_build()
     threads = min(oracle_lib.max_threads(), usable_cpus())
-    ora = oracle_lib.OracleDetector(MODEL_STEP, 0.05).train_model(bottle)
-    step = int(1.0 / SCENE_STEP)
-    # calibrate on 2 reference points per thread, then size the sample for ~target_seconds
-    probe = [(k * (n_ref_total // (2 * threads))) * step for k in range(2 * threads)]
-    t0 = time.perf_counter()
-    r = ora.match(scene, relative_scene_sample_step=SCENE_STEP, presampled=True, ref_list=probe, threads=threads,
-                  cluster=False)
-    dt = time.perf_counter() - t0
-    n_sample = int(min(n_ref_total, max(2 * threads, (target_seconds / max(dt, 1e-3)) * len(probe))))
+    ora = oracle_lib.OracleDetector(model_step, W.REL_DISTANCE).train_model(bottle)
+    step = int(1.0 / W.SCENE_STEP)
+
+    def timed(refs, nthreads):
+        t0 = time.perf_counter()
+        r = ora.match(scene, relative_scene_sample_step=W.SCENE_STEP, presampled=True, ref_list=refs, threads=nthreads,
+                      cluster=False)
+        return time.perf_counter() - t0, int(r["votes_per_ref"].sum())
+
+    def spaced(n):
+        return [int(k * n_ref_total / n) * step for k in range(n)]
+
+    # calibrate on 2 reference points per thread, then size one repetition for ~seconds_per_rep
+    dt, _ = timed(spaced(2 * threads), threads)
+    n_sample = int(min(n_ref_total, max(2 * threads, seconds_per_rep / max(dt, 1e-3) * 2 * threads)))
     n_sample = max(threads, (n_sample // threads) * threads)
-    refs = [int(k * n_ref_total / n_sample) * step for k in range(n_sample)]
-    t0 = time.perf_counter()
-    r = ora.match(scene, relative_scene_sample_step=SCENE_STEP, presampled=True, ref_list=refs, threads=threads,
-                  cluster=False)
-    dt = time.perf_counter() - t0
-    votes = int(r["votes_per_ref"].sum())
+    refs = spaced(n_sample)
+    runs = [timed(refs, threads) for _ in range(reps)]
+    votes = runs[0][1]
+    med = float(np.median([d for d, _ in runs]))
+    n1 = max(2, n_sample // threads)
+    d1, v1 = timed(spaced(n1), 1)
     return {
-        "value": votes / dt,
+        "value": votes / med,
         "unit": "pair-matches/s",
         "cores": threads,
         "host_cpus_visible": os.cpu_count(),
         "kind": "port",
+        "build": "-O3 -march=native (oracle/Makefile target native, compiled on this box)" if native
+                 else "-O2 (portable build; the native build failed on this box)",
+        "repetitions": reps,
+        "seconds_per_repetition": [round(d, 3) for d, _ in runs],
         "sample": f"{n_sample} of {n_ref_total} reference points (evenly spaced) of the same crop, all "
-                  f"{scene.shape[0]} paired points each, {votes} pair-matches in {dt:.2f} s, "
-                  f"{n_sample / dt:.2f} poses/s",
-        "poses_per_s": n_sample / dt,
+                  f"{scene.shape[0]} paired points each, {votes} pair-matches, median of {reps} runs {med:.2f} s, "
+                  f"{n_sample / med:.2f} poses/s",
+        "poses_per_s": n_sample / med,
+        "one_thread": {"value": v1 / d1, "unit": "pair-matches/s", "cores": 1,
+                       "sample": f"{n1} reference points, {v1} pair-matches in {d1:.2f} s"},
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
-                    help="c2 (default, BASELINE configs[1]: the contract's workload); c4: 10k-pt model vs 200k-pt scene "
-                         "(HBM-resident stress, informational: no cpu_baseline)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--pipeline-depth", type=int, default=1,
-                    help="crops in flight: 1 (default) = strictly one after another, so the HIP-event kernel times "
-                         "behind `roofline` are clean; 2-3 overlap independent crops on separate streams (+4-6 %% "
-                         "throughput, but concurrent kernels stretch each other's event times)")
-    args = ap.parse_args()
-
-    import torch
-
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above imported torch or initialised HIP.
+        sys.exit(launch_ranks(args, argv))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n")
+        sys.exit(2)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    if args.dry_launch:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world,
+                          "dist_world": dist.get_world_size() if world > 1 else 1}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import numpy as np
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # rehearsal knobs (one-GPU box): PPF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, PPF_BENCH_BACKEND=gloo swaps
@@ -153,91 +221,137 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
 
-    from yolo_ppf_pose_estimation_amd import parallel, synth
-    from yolo_ppf_pose_estimation_amd._capi import Pose
+    from yolo_ppf_pose_estimation_amd import parallel, workloads as W
     from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
-    from yolo_ppf_pose_estimation_amd.device import Workspace
-    import ctypes as C
+    from yolo_ppf_pose_estimation_amd.device import BatchMatcher, Workspace
 
-    global MODEL_STEP, SCENE_POINTS
-    n_instances = 1
-    if args.config == "c4":
-        MODEL_STEP, SCENE_POINTS, n_instances = 0.0135, 200000, 2
+    bottle = W.bottle()
+    shard_refs = args.config == "c4" and args.shard == "refs" and world > 1
+    if args.config == "c2":
+        model_step = W.C2["model_step"]
+        scene = W.c2_scene() if world == 1 else W.c3_scene(rank)
+        scaling = "weak"
+        workload = ("C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
+                    "(presampled, every point paired), reference stride 20 -> 2,500 reference points, 30 alpha bins"
+                    + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"))
+    elif args.config == "c4":
+        model_step = W.C4["model_step"]
+        scene = W.c4_scene()
+        scaling = "strong" if shard_refs else "weak"
+        workload = ("C4: bottle model sampled at 0.0135 (~10k pts) vs one 200,000-pt synthetic scene (presampled), "
+                    "reference stride 20 -> 10,000 reference points, 30 alpha bins"
+                    + (f"; reference points strided over {world} ranks, raw poses all_gathered, clustered on rank 0"
+                       if shard_refs else ("" if world == 1 else f"; {world} replicas")))
         args.no_cpu_baseline = True
-    bottle = np.load(os.path.join(ROOT, "tests", "golden", "bottle_model_xyzn.npy"))
-    det = PPF3DDetector(MODEL_STEP, 0.05, max_tile_refs=int(os.environ.get("PPF_TILE_REFS", "0"))).trainModel(bottle)
-    info = det.info()
-    seed = (12345 if args.config == "c2" else 4) if world == 1 else 1000 + rank
-    scene, _ = synth.make_scene(bottle, n_points=SCENE_POINTS, seed=seed, n_instances=n_instances)
-    d_scene = torch.from_numpy(scene).cuda()
-    # Crops are independent, so consecutive steps CAN be software-pipelined like a serving loop would do: step i is
-    # enqueued on one of `depth` (stream, workspace) pairs before the clustered poses of step i-depth+1 are read back,
-    # which lets the single-workgroup clustering tail of one crop overlap the voting of the next.  The default is
-    # depth 1 (no overlap): with overlap the per-kernel HIP-event times that `roofline` is computed from are no longer
-    # the kernel's own.
-    depth = max(1, min(args.pipeline_depth, max(args.warmup, 1)))
-    streams = [torch.cuda.Stream() for _ in range(depth)]
-    wss = [Workspace(timing=True) for _ in range(depth)]
-    n_ref_total = (SCENE_POINTS + int(1.0 / SCENE_STEP) - 1) // int(1.0 / SCENE_STEP)
-
-    def enqueue(i):
-        s = streams[i % depth]
-        with torch.cuda.stream(s):
-            wss[i % depth].match_device(det, d_scene.data_ptr(), SCENE_POINTS, 6, SCENE_STEP, 0.05, presampled=True,
-                                        stream=s.cuda_stream)
-
-    def collect(i):
-        with torch.cuda.stream(streams[i % depth]):
-            # waits for that step's stream; clustering already ran on the device, only the clustered poses come back
-            fin, k_top, n_clusters, st = wss[i % depth].top_poses(TOP_K)
-            if world > 1:
-                # the path's only collective: all_gather (RCCL) of each rank's top poses, 5 x 216 B per rank
-                parallel.gather_poses(parallel.poses_to_array(fin, k_top, TOP_K), device="cuda" if backend == "nccl" else None)
-        return {"stats": st, "n_clusters": n_clusters}
-
-    def run(n_steps, on_result=None):
-        res = None
-        for i in range(n_steps + depth - 1):
-            if i < n_steps:
-                enqueue(i)
-            if i >= depth - 1:
-                res = collect(i - (depth - 1))
-                if on_result:
-                    on_result(res)
-        return res
+    else:
+        model_step = W.C5_MODEL_STEP
+        scaling = "weak"
+        workload = (f"C5: 4 resident model tables (bottle, box, cylinder, torus at step 0.036) x "
+                    f"{W.C5_CROPS_PER_RANK} crops of 50,000 pts per GPU, every crop matched against every table "
+                    f"through ppf_batch_run (32 matches per step per GPU)")
+        args.no_cpu_baseline = True
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
+    tally = {"votes": 0, "pairs": 0, "atomics": 0}
+    vote_ms, pair_ms, group_ms, dev_ms = [], [], [], []
+    last = {}
+    n_scene = scene.shape[0] if args.config != "c5" else W.C2["n_points"]
+    step_stride = int(1.0 / W.SCENE_STEP)
+
+    if args.config == "c5":
+        models = W.c5_models()
+        dets = [PPF3DDetector(model_step, W.REL_DISTANCE).trainModel(m) for m in models]
+        info = dets[0].info()
+        crops = W.c5_crops(rank, models=models)
+        d_crops = [torch.from_numpy(c).cuda() for c in crops]
+        bm = BatchMatcher(lanes=int(os.environ.get("PPF_BATCH_LANES", "4")))
+
+        def run(n_steps, timed):
+            for _ in range(n_steps):
+                res = bm.run_device(dets, [t.data_ptr() for t in d_crops], [c.shape[0] for c in crops], 6, W.SCENE_STEP,
+                                    W.REL_DISTANCE, presampled=True, top_k=W.TOP_K)
+                if world > 1:
+                    parallel.gather_device(res["d_top"], dist)
+                if timed:
+                    tally["votes"] += res["n_votes"]
+                    tally["pairs"] += res["n_pairs"]
+                    tally["atomics"] += res.get("n_lds_atomics", 0)
+                    last.update(res)
+    else:
+        det = PPF3DDetector(model_step, W.REL_DISTANCE,
+                            max_tile_refs=int(os.environ.get("PPF_TILE_REFS", "0"))).trainModel(bottle)
+        info = det.info()
+        d_scene = torch.from_numpy(scene).cuda()
+        # Crops are independent, so consecutive steps CAN be software-pipelined like a serving loop would do.  The
+        # default is depth 1: with overlap the per-kernel HIP-event times `roofline` is computed from are stretched.
+        depth = max(1, min(args.pipeline_depth, max(args.warmup, 1)))
+        streams = [torch.cuda.Stream() for _ in range(depth)]
+        wss = [Workspace(timing=True) for _ in range(depth)]
+        n_ref_total = (n_scene + step_stride - 1) // step_stride
+        ref_kw = {"ref_offset": rank, "ref_stride": world, "skip_clustering": True} if shard_refs else {}
+        n_ref_rank = len(range(rank, n_ref_total, world)) if shard_refs else n_ref_total
+        n_ref_max = (n_ref_total + world - 1) // world
+        gathered = {}
+        ws_cluster = Workspace() if shard_refs else None  # rank 0 clusters the merged list here
+
+        def enqueue(i):
+            s = streams[i % depth]
+            with torch.cuda.stream(s):
+                wss[i % depth].match_device(det, d_scene.data_ptr(), n_scene, 6, W.SCENE_STEP, W.REL_DISTANCE,
+                                            presampled=True, stream=s.cuda_stream, **ref_kw)
+
+        def collect(i, timed):
+            ws, s = wss[i % depth], streams[i % depth]
+            with torch.cuda.stream(s):
+                st = ws.stats()  # waits for that step's stream (and re-runs a step whose scratch estimate was too small)
+                if shard_refs:
+                    # the path's only collective: all_gather of each rank's raw per-reference poses (216 B each),
+                    # device to device; rank 0 clusters the merged list (ppf_cluster_poses_device)
+                    blk = ws.device_pose_block(n_ref_max, s.cuda_stream)
+                    allp = parallel.gather_device(blk, dist)
+                    if rank == 0:
+                        merged = parallel.merge_reference_shards_device(allp, world, n_ref_total)
+                        gathered["poses"] = ws_cluster.cluster_device(det, merged.data_ptr(), n_ref_total, n_scene // step_stride,
+                                                              stream=s.cuda_stream, top_k=W.TOP_K)
+                else:
+                    blk = ws.device_top_block(W.TOP_K, s.cuda_stream)  # top-5 clustered poses, still in HBM
+                    if world > 1:
+                        gathered["poses"] = parallel.gather_device(blk, dist)  # 5 x 216 B per rank
+                    else:
+                        gathered["poses"] = blk
+            if timed:
+                vote_ms.append(st["ms_vote_kernel"]); pair_ms.append(st["ms_pair_kernel"])
+                group_ms.append(st.get("ms_group_kernel", 0.0)); dev_ms.append(st["ms_total_device"])
+                tally["votes"] += st["n_votes"]; tally["pairs"] += st["n_pairs"]
+                tally["atomics"] += st.get("n_lds_atomics", 0)
+                last.update(st)
+
+        def run(n_steps, timed):
+            for i in range(n_steps + depth - 1):
+                if i < n_steps:
+                    enqueue(i)
+                if i >= depth - 1:
+                    collect(i - (depth - 1), timed)
+
+    run(args.warmup, False)
     sync()
-    vote_ms, pair_ms, tally = [], [], [0, 0]
-
-    def account(r):
-        st = r["stats"]
-        vote_ms.append(st["ms_vote_kernel"])
-        pair_ms.append(st["ms_pair_kernel"])
-        tally[0] += st["n_votes"]
-        tally[1] += st["n_pairs"]
-
     t0 = time.perf_counter()
-    res = run(args.steps, account)
+    run(args.steps, True)
     sync()
     elapsed = time.perf_counter() - t0
-    votes, pairs = tally
 
-    n_poses_clustered = res["n_clusters"]
     red_dev = "cuda" if backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    tot = torch.tensor([float(votes), float(pairs)], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(tally["votes"]), float(tally["pairs"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -245,11 +359,6 @@ def main():
     all_votes, all_pairs = float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
-        st = res["stats"]
-        avg_vote_s = float(np.mean(vote_ms)) * 1e-3
-        abytes = algorithmic_bytes(st["n_ref"], info["n_ref"], info["num_angles"], st["n_pairs"], st["n_votes"])
-        hbm_only = abytes - 8 * st["n_votes"] - st["n_ref"] * 2 * 4 * info["n_ref"] * info["num_angles"]
-        achieved = abytes / avg_vote_s / 1e9
         line = {
             "metric": "PPF pair-matches/sec (accumulator votes) per cropped scene",
             "value": all_votes / elapsed,
@@ -259,54 +368,70 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32 votes / f64 pair features",
             "data": "synthetic",
-            "config": {
-                "workload": ("C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
-                             "(presampled, every point paired), reference stride 20 -> 2,500 reference points, "
-                             "30 alpha bins" if args.config == "c2" else
-                             "C4: bottle model sampled at 0.0135 (~10k pts) vs one 200,000-pt synthetic scene "
-                             "(presampled), reference stride 20 -> 10,000 reference points, 30 alpha bins")
-                            + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"),
-                "n_model": info["n_ref"], "n_scene": SCENE_POINTS, "n_ref": st["n_ref"],
-                "n_tiles": info["n_tiles"], "tile_refs": info["tile_refs"],
-                "table_buckets": info["n_buckets"], "table_entries": info["n_entries"],
-                "parallelism": f"crops sharded 1/GPU x{world}, RCCL all_gather of top-{TOP_K} poses only",
-                "pipeline_depth": depth,
-            },
-            "poses_per_s": world * st["n_ref"] * args.steps / elapsed,
+            "config": {"workload": workload, "n_model": info["n_ref"], "n_scene": n_scene,
+                       "n_tiles": info["n_tiles"], "tile_refs": info["tile_refs"], "table_buckets": info["n_buckets"],
+                       "table_entries": info["n_entries"],
+                       "parallelism": (f"reference points strided over {world} ranks, RCCL all_gather of raw poses"
+                                       if shard_refs else
+                                       f"crops sharded 1/GPU x{world}, RCCL all_gather of top-{W.TOP_K} poses only")},
             "scene_pairs_per_s": all_pairs / elapsed,
-            "votes_per_step_per_gpu": st["n_votes"],
-            "clustered_poses": n_poses_clustered,
-            "kernel_ms": {"k_pairs": float(np.mean(pair_ms)), "k_vote": float(np.mean(vote_ms)),
-                          "device_total": st["ms_total_device"]},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_vote",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(st["n_votes"]) if world == 1 else None,
-                "algorithmic_bytes_per_launch": abytes,
-                "hbm_only_algorithmic_bytes_per_launch": hbm_only,
-                "avg_kernel_ms": avg_vote_s * 1e3,
-                "note": "16 B/vote counts the 8 B accumulator RMW although the accumulator is LDS-resident; "
-                        "hbm_only_* removes the LDS part (8 B/vote + clear/scan)",
-            },
         }
-        # what actually bounds k_vote: one LDS atomic per vote (plus ~5 VALU); reported beside the contract's
-        # HBM roofline because the accumulator never leaves LDS
-        line["lds_atomic_roofline"] = {"kernel": "k_vote", "achieved": st["n_votes"] / avg_vote_s, "peak": LDS_ATOMIC_PEAK,
-                                       "unit": "votes/s", "frac": st["n_votes"] / avg_vote_s / LDS_ATOMIC_PEAK,
-                                       "source": "profiles/r01_ubench_valu_lds.txt"}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(bottle, scene, n_ref_total, args.cpu_seconds)
-        else:
+        if args.config == "c5":
+            n_match = len(dets) * len(crops)
+            line["crops_per_s"] = world * len(crops) * args.steps / elapsed
+            line["matches_per_s"] = world * n_match * args.steps / elapsed
+            line["votes_per_step_per_gpu"] = tally["votes"] // args.steps
+            line["config"]["batch_lanes"] = bm.lanes
+            line["roofline"] = None
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        else:
+            st = last
+            line["config"]["n_ref"] = st["n_ref"]
+            line["config"]["pipeline_depth"] = depth
+            line["poses_per_s"] = world * st["n_ref"] * args.steps / elapsed
+            line["votes_per_step_per_gpu"] = st["n_votes"]
+            line["clustered_poses"] = st.get("n_poses", 0)
+            line["scratch_bytes"] = st.get("scratch_bytes", None)
+            line["batches_per_step"] = st.get("n_batches", None)
+            avg_vote_s = float(np.mean(vote_ms)) * 1e-3
+            line["kernel_ms"] = {"k_pairs": float(np.mean(pair_ms)), "k_group": float(np.mean(group_ms)),
+                                 "k_vote": float(np.mean(vote_ms)), "device_total": float(np.mean(dev_ms))}
+            abytes = algorithmic_bytes(st["n_ref"], info["n_ref"], info["num_angles"], st["n_pairs"], st["n_votes"])
+            traffic, src = measured_traffic(st["n_votes"]) if world == 1 else (None, None)
+            achieved = traffic / avg_vote_s / 1e9 if traffic else None
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "k_vote",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "traffic": traffic, "traffic_source": src,
+                "avg_kernel_ms": avg_vote_s * 1e3,
+                "algorithmic_bytes_per_launch": abytes,
+                "note": "achieved = measured fabric bytes of one k_vote launch (2 x TCC read requests + writes, committed "
+                        "PMC pass) / its HIP-event time.  The section 8d figure (16 B per vote) is kept as "
+                        "algorithmic_bytes_per_launch only: the accumulator lives in LDS and a model entry is read once "
+                        "per run of hits, so the kernel is LDS-bound, see lds_roofline",
+            }
+            atom = tally["atomics"] / args.steps if tally["atomics"] else None
+            line["lds_roofline"] = {
+                "kernel": "k_vote", "unit": "LDS atomic lane-ops/s",
+                "lds_atomics_per_launch": atom,
+                "achieved": atom / avg_vote_s if atom else None,
+                "peak_ubench": LDS_ATOMIC_PEAK_UBENCH, "peak_guide": LDS_ATOMIC_PEAK_GUIDE,
+                "frac_ubench": atom / avg_vote_s / LDS_ATOMIC_PEAK_UBENCH if atom else None,
+                "frac_guide": atom / avg_vote_s / LDS_ATOMIC_PEAK_GUIDE if atom else None,
+                "votes_per_lds_atomic": st["n_votes"] / atom if atom else None,
+                "votes_per_s_kernel": st["n_votes"] / avg_vote_s,
+                "source": "profiles/r01_ubench_valu_lds.txt; MI355X_MICROARCH.md (ds_write-class op: 16 lanes/clk/CU)",
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(model_step, bottle, scene, n_ref_total, args.cpu_seconds)
+            else:
+                line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define PPF_ABI_VERSION 1
+#define PPF_ABI_VERSION 2
 
 typedef enum ppf_status {
   PPF_OK = 0,
@@ -70,6 +70,7 @@ typedef enum ppf_status {
 
 typedef struct ppf_model ppf_model;         /* opaque, ref-counted, device-resident model table */
 typedef struct ppf_workspace ppf_workspace; /* opaque per-caller scratch + result buffers */
+typedef struct ppf_batch ppf_batch;         /* opaque: streams + workspaces of a batched call (crops x models) */
 typedef struct ppf_cloud ppf_cloud;         /* opaque device-resident cloud: rows x y z nx ny nz + curvature */
 
 typedef struct ppf_train_params {
@@ -93,8 +94,11 @@ typedef struct ppf_match_params {
   int32_t ref_offset;                /* sharding over ranks: vote reference points ref_offset, */
   int32_t ref_stride;                /*   ref_offset+ref_stride, ... of the reference list (1 = all) */
   int32_t skip_clustering;           /* 1: stop after per-reference poses */
-  int32_t reserved;
+  int32_t vote_mode;                 /* PPF_VOTE_AUTO (0): runs of many hits vote through per-run count tables;
+                                        PPF_VOTE_DIRECT (1): every (entry, hit) pair casts its own atomic.  Same results. */
 } ppf_match_params;
+#define PPF_VOTE_AUTO 0
+#define PPF_VOTE_DIRECT 1
 
 /* cv::ppf_match_3d::Pose3D fields the reference reads (src/YOLO_cropping_ppf_test.cpp:124-125). */
 typedef struct ppf_pose {
@@ -139,11 +143,25 @@ typedef struct ppf_match_stats {
   int32_t n_poses;         /* clustered poses */
   uint64_t n_pairs;        /* scene pairs hashed and looked up */
   uint64_t n_votes;        /* accumulator increments == pair-matches */
-  float ms_vote_kernel;    /* device time of the voting kernel(s), when timing is enabled */
-  float ms_pair_kernel;
+  float ms_vote_kernel;    /* device time of the voting kernel, summed over the batches of the call (timing enabled) */
+  float ms_pair_kernel;    /* pair kernel, likewise */
   float ms_total_device;   /* first kernel start -> last kernel end */
-  int32_t reserved;
+  float ms_group_kernel;   /* hit grouping (k_group and the two rankings), likewise */
+  uint64_t n_hits;         /* scene pairs that found a non-empty bucket */
+  uint64_t n_lds_atomics;  /* LDS atomic lane-operations the voting kernel issued (<= n_votes when runs vote by counts) */
+  uint64_t scratch_bytes;  /* device scratch of the call: hit pools, run table, frames */
+  int32_t n_batches;       /* batches of reference points the call was cut into */
+  int32_t n_retries;       /* repeats because the hit pools (sized from earlier calls) were too small */
 } ppf_match_stats;
+
+/* totals of one ppf_batch_run */
+typedef struct ppf_batch_stats {
+  uint64_t n_pairs, n_votes, n_hits, n_lds_atomics;
+  int32_t n_matches; /* crops x models */
+  int32_t n_retries;
+  int32_t lanes;
+  float ms_wall;     /* host wall clock of the call */
+} ppf_batch_stats;
 
 /* cv::ppf_match_3d::ICP constructor arguments (uniform sampling, one correspondence per point) */
 typedef struct ppf_icp_params {
@@ -151,8 +169,12 @@ typedef struct ppf_icp_params {
   float tolerance;       /* arg 2 (0.005f) */
   float rejection_scale; /* arg 3 (2.5f); <= 0 disables the median+MAD rejection */
   int32_t num_levels;    /* arg 4 (8) */
-  int32_t reserved[4];
+  int32_t flags;         /* 0; PPF_ICP_NO_SMALL_LEVELS: coarse levels run kernel by kernel instead of in one workgroup;
+                            PPF_ICP_ONE_STREAM: the poses of one call share the caller's stream.  Same results either way. */
+  int32_t reserved[3];
 } ppf_icp_params;
+#define PPF_ICP_NO_SMALL_LEVELS 1
+#define PPF_ICP_ONE_STREAM 2
 
 void ppf_default_train_params(ppf_train_params* p);
 void ppf_default_match_params(ppf_match_params* p);
@@ -175,7 +197,10 @@ ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows);
 ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32_t* bucket_off, int32_t* entry_cell,
                                float* entry_alpha);
 ppf_status ppf_model_save(const ppf_model* m, const char* path);
+/* every field and table of the file is validated before use: a truncated or corrupt file is PPF_ERR_IO */
 ppf_status ppf_model_load(const char* path, ppf_model** out);
+/* the same validation without a device (host only): PPF_OK or PPF_ERR_IO */
+ppf_status ppf_model_check_file(const char* path);
 
 /* ---- matching, host buffers ------------------------------------------------------------- */
 ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
@@ -185,14 +210,34 @@ ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sst
                          int* n_ref, ppf_match_stats* stats);
 
 /* Many crops x many models (BASELINE config C5): every scene is uploaded and sampled once and matched against
- * every model.  out holds n_scenes x n_models blocks of `cap` poses (best first), n_out the count of each block. */
+ * every model.  out holds n_scenes x n_models blocks of `cap` poses (best first), n_out the count of each block.
+ * (= ppf_batch_create(min(4, n_scenes)) + ppf_batch_run + ppf_batch_destroy) */
 ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
                            int sstride, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
+/* The reusable form: `lanes` HIP streams, each with its own workspace and pinned staging.  Crop c runs on lane c mod
+ * lanes, its matches against all models back to back without host involvement; one synchronisation at the end.
+ * scenes_on_device != 0: `scenes` are device pointers (no staging).  out / n_out / stats may be NULL. */
+ppf_status ppf_batch_create(int lanes, ppf_batch** out);
+ppf_status ppf_batch_destroy(ppf_batch* b);
+ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
+                         int sstride, int n_scenes, int scenes_on_device, const ppf_match_params* params, ppf_pose* out, int cap,
+                         int* n_out, ppf_batch_stats* stats);
+/* device block of the last run: n_scenes * n_models * cap pose records (zero rows past each count), e.g. for a gather */
+ppf_status ppf_batch_device_block(ppf_batch* b, void** d_poses, int* n_records);
+/* device-to-device copy of the first n_records of that block into d_dst, enqueued on `stream` */
+ppf_status ppf_batch_copy_block(ppf_batch* b, void* d_dst, int n_records, void* stream);
 
 /* ---- matching, device-resident clouds + explicit stream ---------------------------------- */
 ppf_status ppf_workspace_create(ppf_workspace** out);
 ppf_status ppf_workspace_destroy(ppf_workspace* ws);
-/* record HIP events around the kernels of each call (read back through ppf_workspace_stats) */
+/* Tuning / test knobs of a workspace.  PPF_OPT_HIT_FRACTION: expected hits per scene pair, which sizes the hit pools of
+ * the next call (normally learned from the previous calls; a too small value only costs a repeat of the call).
+ * PPF_OPT_GROUP_ROUND_BUCKETS: bucket ids grouped per pass over a reference point's hits (0 = as many as fit LDS). */
+#define PPF_OPT_HIT_FRACTION 1
+#define PPF_OPT_GROUP_ROUND_BUCKETS 2
+#define PPF_OPT_CLUSTER_SERIAL 3 /* != 0: the serial greedy cluster assignment (the path for > 11,520 poses) for any size */
+ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);
+/* record HIP events around the kernels of each call (read back through ppf_workspace_results' stats) */
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);
 /* Enqueue sampling + voting + pose assembly (+ clustering) on `stream` (a hipStream_t, NULL = default
  * stream).  d_scene/d_edge are DEVICE pointers.  Returns after enqueueing when everything could be
@@ -215,6 +260,15 @@ ppf_status ppf_debug_device_math(int fn, const double* x, const double* y, doubl
 /* device pointer to the per-reference pose records of the last call (n_ref x ppf_pose), for a
  * collective gather without a host copy */
 ppf_status ppf_workspace_device_poses(ppf_workspace* ws, void** d_raw_poses, int* n_ref);
+/* Device-side result blocks, enqueued on `stream` (call ppf_workspace_results first: it is what notices and repeats a
+ * call whose hit pools were too small).  d_dst receives k (cap) ppf_pose records, zero rows past the available count:
+ * the best k clustered poses / the per-reference poses.  For collectives that gather from device memory. */
+ppf_status ppf_workspace_copy_top_poses(ppf_workspace* ws, void* d_dst, int k, void* stream);
+ppf_status ppf_workspace_copy_raw_poses(ppf_workspace* ws, void* d_dst, int cap, void* stream);
+/* clusterPoses on a DEVICE pose list (e.g. the all-gathered per-reference poses of all ranks), enqueued on `stream`;
+ * the clusters are fetched with ppf_workspace_results(poses) or ppf_workspace_copy_top_poses */
+ppf_status ppf_cluster_poses_device(const ppf_model* m, ppf_workspace* ws, const void* d_in, int n, int num_poses,
+                                    const ppf_match_params* params, void* stream);
 /* cluster a caller-supplied pose list (e.g. the all-gathered per-reference poses of all ranks) */
 ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int num_poses,
                              const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);

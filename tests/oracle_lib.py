@@ -46,13 +46,46 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_lib_path = LIB_PATH
+
+
+def _host_tag() -> str:
+    """Short tag of this machine's CPU (model name + flags): a native build is only ever loaded where it was made."""
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [ln for ln in txt.splitlines() if ln.startswith(("model name", "flags"))][:2]
+        return hashlib.sha1("\n".join(keep).encode()).hexdigest()[:10]
+    except Exception:
+        return "unknown"
+
+
+def use_native_build() -> bool:
+    """Switch this process to the -O3 -march=native build of the oracle (oracle/Makefile target `native`), compiling
+    it here if needed.  Used by bench.py's cpu_baseline leg only.  Returns False (and keeps the portable build) when
+    the compile fails.  Results are bit-identical to the portable build (tests/test_oracle_native.py)."""
+    global _lib, _lib_path
+    tag = _host_tag()
+    path = os.path.join(ORACLE_DIR, f"libppf_oracle_native_{tag}.so")
+    try:
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "native", f"NATIVE_TAG={tag}"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    if not os.path.exists(path):
+        return False
+    if _lib_path != path:
+        _lib_path = path
+        _lib = None
+    return True
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(LIB_PATH)
+        if _lib_path == LIB_PATH:
+            build()
+        L = C.CDLL(_lib_path)
         fp = C.POINTER(C.c_float)
         L.oracle_train.restype = C.c_void_p
         L.oracle_train.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]

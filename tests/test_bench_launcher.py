@@ -1,0 +1,38 @@
+"""bench.py --gpus N starts N ranks by itself (no torch.distributed.run around it) before anything touches a GPU; a
+mismatch between --gpus and WORLD_SIZE is an error.  CPU only: --dry-launch stops after the gloo rendezvous."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e["OMP_NUM_THREADS"] = "1"
+    return e
+
+
+def test_plain_invocation_launches_two_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, env=_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"dry_launch": True, "rank": 0, "local_rank": 0, "world": 2, "dist_world": 2}]
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, env=env, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_under_torch_distributed_run_each_process_is_a_rank():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, env=_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = sorted((json.loads(l)["rank"], json.loads(l)["world"]) for l in r.stdout.splitlines() if l.startswith("{"))
+    assert got == [(0, 2), (1, 2)]

@@ -27,20 +27,22 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"libppf_hip.so lacks {n}"
     assert sorted(_capi._SIGNATURES) == names, "python binding table and header disagree"
-    assert lib().ppf_abi_version() == 1
+    assert lib().ppf_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof() of every struct as a C compiler sees include/ppf_hip.h == the ctypes mirror."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "ppf_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ppf_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(ppf_pose),sizeof(ppf_vote),sizeof(ppf_train_params),sizeof(ppf_match_params),'
-                   'sizeof(ppf_model_info),sizeof(ppf_match_stats));return 0;}\n')
+                   'sizeof(ppf_model_info),sizeof(ppf_match_stats),sizeof(ppf_batch_stats),'
+                   'offsetof(ppf_match_stats, n_lds_atomics),offsetof(ppf_match_params, vote_mode));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     want = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    got = [C.sizeof(t) for t in (_capi.Pose, _capi.Vote, TrainParams, MatchParams, _capi.ModelInfo, _capi.MatchStats)]
+    got = [C.sizeof(t) for t in (_capi.Pose, _capi.Vote, TrainParams, MatchParams, _capi.ModelInfo, _capi.MatchStats,
+                                 _capi.BatchStats)] + [_capi.MatchStats.n_lds_atomics.offset, MatchParams.vote_mode.offset]
     assert got == want
 
 
@@ -84,3 +86,37 @@ def test_argument_validation_precedes_any_device_work(bottle):
     lib().ppf_default_train_params(C.byref(tp))
     assert lib().ppf_model_train(None, 10, 6, C.byref(tp), C.byref(out)) == _capi.PPF_ERR_INVALID
     assert "bad argument" in _capi.last_error()
+
+
+def _write_model_file(path, n_ref=2, junk=b""):
+    """A syntactically plausible header of the model file format (include/ppf_hip.h: ppf_model_save) followed by `junk`."""
+    import struct
+    tp = TrainParams()
+    lib().ppf_default_train_params(C.byref(tp))
+    info = _capi.ModelInfo()
+    info.n_ref, info.num_angles, info.slots, info.n_buckets = n_ref, 30, 16, 1
+    info.n_entries, info.n_tiles, info.tile_refs = n_ref * (n_ref - 1), 1, n_ref
+    info.angle_step, info.distance_step, info.diameter = 2 * np.pi / 30, 0.01, 0.2
+    with open(path, "wb") as f:
+        f.write(b"PPFHIP02" + bytes(tp) + bytes(info) + struct.pack("<Q", 1) + junk)
+
+
+def test_model_file_validation_is_host_side_and_loud(tmp_path):
+    """ppf_model_check_file (the validation ppf_model_load runs before anything reaches a kernel) needs no device:
+    missing, truncated, wrong-magic and inconsistent files are PPF_ERR_IO with a message, never an exception."""
+    chk = lib().ppf_model_check_file
+    assert chk(str(tmp_path / "nope.bin").encode()) == _capi.PPF_ERR_IO
+    p = tmp_path / "m.bin"
+    p.write_bytes(b"")
+    assert chk(str(p).encode()) == _capi.PPF_ERR_IO
+    p.write_bytes(b"NOTAMODEL" * 20)
+    assert chk(str(p).encode()) == _capi.PPF_ERR_IO and "magic" in _capi.last_error()
+    _write_model_file(p)  # header only: the tables are missing
+    assert chk(str(p).encode()) == _capi.PPF_ERR_IO and "file size" in _capi.last_error()
+    _write_model_file(p, n_ref=70000)  # N*N overflows the table's 31-bit pair index
+    assert chk(str(p).encode()) == _capi.PPF_ERR_IO and "n_ref" in _capi.last_error()
+    _write_model_file(p, junk=b"\xff" * 4096)  # right prefix, wrong size
+    assert chk(str(p).encode()) == _capi.PPF_ERR_IO
+    if lib().ppf_device_count() == 0:
+        out = C.c_void_p()
+        assert lib().ppf_model_load(str(p).encode(), C.byref(out)) == _capi.PPF_ERR_HIP

@@ -12,6 +12,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PPF_HIP_LIB") or os.path.join(HERE, "csrc", "libppf_hip.so")  # override: diagnostic builds only
 
+PPF_OPT_HIT_FRACTION, PPF_OPT_GROUP_ROUND_BUCKETS, PPF_OPT_CLUSTER_SERIAL = 1, 2, 3
+PPF_ICP_NO_SMALL_LEVELS, PPF_ICP_ONE_STREAM = 1, 2
 PPF_OK, PPF_ERR_INVALID, PPF_ERR_NOT_TRAINED, PPF_ERR_HIP, PPF_ERR_NOMEM, PPF_ERR_IO, PPF_ERR_CAPACITY = range(7)
 STATUS_NAMES = {0: "PPF_OK", 1: "PPF_ERR_INVALID", 2: "PPF_ERR_NOT_TRAINED", 3: "PPF_ERR_HIP", 4: "PPF_ERR_NOMEM",
                 5: "PPF_ERR_IO", 6: "PPF_ERR_CAPACITY"}
@@ -33,12 +35,12 @@ class MatchParams(C.Structure):
     _fields_ = [("relative_scene_sample_step", C.c_double), ("relative_scene_distance", C.c_double),
                 ("position_threshold", C.c_double), ("rotation_threshold", C.c_double),
                 ("use_weighted_avg", C.c_int32), ("presampled", C.c_int32), ("ref_offset", C.c_int32),
-                ("ref_stride", C.c_int32), ("skip_clustering", C.c_int32), ("reserved", C.c_int32)]
+                ("ref_stride", C.c_int32), ("skip_clustering", C.c_int32), ("vote_mode", C.c_int32)]
 
 
 class IcpParams(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("tolerance", C.c_float), ("rejection_scale", C.c_float),
-                ("num_levels", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("num_levels", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Pose(C.Structure):
@@ -63,7 +65,13 @@ class MatchStats(C.Structure):
     _fields_ = [("n_scene_sampled", C.c_int32), ("n_paired", C.c_int32), ("n_ref", C.c_int32),
                 ("n_poses", C.c_int32), ("n_pairs", C.c_uint64), ("n_votes", C.c_uint64),
                 ("ms_vote_kernel", C.c_float), ("ms_pair_kernel", C.c_float), ("ms_total_device", C.c_float),
-                ("reserved", C.c_int32)]
+                ("ms_group_kernel", C.c_float), ("n_hits", C.c_uint64), ("n_lds_atomics", C.c_uint64),
+                ("scratch_bytes", C.c_uint64), ("n_batches", C.c_int32), ("n_retries", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_votes", C.c_uint64), ("n_hits", C.c_uint64), ("n_lds_atomics", C.c_uint64),
+                ("n_matches", C.c_int32), ("n_retries", C.c_int32), ("lanes", C.c_int32), ("ms_wall", C.c_float)]
 
 
 # every symbol include/ppf_hip.h declares (tests/test_capi_symbols.py checks the header against this)
@@ -82,16 +90,25 @@ _SIGNATURES = {
     "ppf_model_get_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppf_model_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ppf_model_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ppf_model_check_file": (C.c_int, [C.c_char_p]),
     "ppf_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                             C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_match_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                   C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
+    "ppf_batch_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ppf_batch_destroy": (C.c_int, [C.c_void_p]),
+    "ppf_batch_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int,
+                                C.c_int, C.c_int, C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int),
+                                C.POINTER(BatchStats)]),
+    "ppf_batch_device_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "ppf_batch_copy_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ppf_raw_votes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.POINTER(MatchParams), C.POINTER(Vote), C.POINTER(Pose), C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(MatchStats)]),
     "ppf_workspace_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppf_workspace_destroy": (C.c_int, [C.c_void_p]),
     "ppf_workspace_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ppf_workspace_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ppf_match_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.POINTER(MatchParams), C.c_void_p]),
     "ppf_workspace_results": (C.c_int, [C.c_void_p, C.POINTER(Vote), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int),
@@ -101,6 +118,10 @@ _SIGNATURES = {
                                          C.POINTER(MatchParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "ppf_debug_device_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_workspace_device_poses": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "ppf_workspace_copy_top_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ppf_workspace_copy_raw_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ppf_cluster_poses_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(MatchParams),
+                                           C.c_void_p]),
     "ppf_cluster_poses": (C.c_int, [C.c_void_p, C.POINTER(Pose), C.c_int, C.c_int, C.POINTER(MatchParams),
                                     C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_sample_cloud": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
@@ -134,6 +155,27 @@ _SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as the system
+    one libppf_hip.so is linked against).  Whichever copy is loaded first serves every later user of that SONAME -- but
+    torch opens its copy by path, so when the system runtime came first the process ends up with two runtimes and
+    torch sees "No HIP GPUs".  Loading torch's copy first (by path, without importing torch) makes both agree,
+    whatever the import order.  Without torch installed nothing happens and the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libppf_hip.so; raises (never falls back) when the extension has not been built."""
     global _lib
@@ -142,12 +184,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()').  There is no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.ppf_abi_version() != 1:
+        if L.ppf_abi_version() != 2:
             raise ImportError("libppf_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,6 +126,8 @@ class DevPool {
   bool off_;
 };
 
+void sync_device_of_block(int dev); /* = sync_device, defined below */
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -138,7 +141,7 @@ struct DevBuf {
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) { /* growing a live buffer (rare): earlier asynchronous work may still use the old block */
-      (void)hipDeviceSynchronize();
+      sync_device_of_block(device);
       DevPool::get().release(p, granted, device); p = nullptr; cap = 0; granted = 0;
     }
     void* q = nullptr;
@@ -149,8 +152,21 @@ struct DevBuf {
   size_t bytes() const { return cap * sizeof(T); }
 };
 
-constexpr int LDS_ACC_BUDGET = 128 * 1024;         /* accumulator bytes per workgroup (160 KiB LDS per CU) */
-constexpr size_t HIT_BYTES_BUDGET = 4ull << 30;    /* hit-list scratch per batch of reference points */
+void sync_device(int dev);
+void sync_device_of_block(int dev) { sync_device(dev); }
+
+/* wait for everything enqueued on device `dev` (the device a buffer lives on, which need not be the current one) */
+void sync_device(int dev) {
+  int cur = -1;
+  if (dev < 0 || hipGetDevice(&cur) != hipSuccess || cur == dev) { (void)hipDeviceSynchronize(); return; }
+  if (hipSetDevice(dev) == hipSuccess) {
+    (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+  }
+}
+
+constexpr int LDS_BYTES = 160 * 1024;              /* LDS per CU == per k_vote workgroup */
+constexpr size_t HIT_BYTES_BUDGET = 4ull << 30;    /* hit scratch per batch of reference points */
 constexpr float SPILL_ALPHA_MIN = 3.1415f;         /* entries with alpha_m >= this can reach alpha bin == numAngles */
 
 }  // namespace
@@ -249,16 +265,6 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
   return (int)(w.rank + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)));
 }
 
-/* pair records with alpha_m as signed 16.16 fixed point of alpha_m * A/(4 pi) (what k_vote adds; see vote_hits_fx) */
-__global__ __launch_bounds__(256) void k_records_to_fixed(const uint4* __restrict__ rec, size_t n, double scale, uint4* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint4 r = rec[i];
-  const long long fa = (long long)__builtin_rint((double)__uint_as_float(r.z) * scale);
-  const long long fb = (long long)__builtin_rint((double)__uint_as_float(r.w) * scale);
-  out[i] = make_uint4(r.x, r.y, (uint32_t)(int32_t)fa, (uint32_t)(int32_t)fb);
-}
-
 /* key_lut[((k0*na + k1)*na + k2)*nd + k3] = dense bucket of hash(k0..k3) % slots, or -1 */
 __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int na, int nd,
                                                        int32_t* __restrict__ lut) {
@@ -288,7 +294,6 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  * Dealing position j -> record 32*(j/64) + j%32, slot (j%64)/32: 32 consecutive dealing positions share a slot of
  * 32 consecutive records.  Unused slots of the last records hold dummies that vote into the LDS guard words.
  */
-constexpr int TABLE_LEVELS_MAX = 4;
 
 __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
                                                   uint32_t* cls, uint32_t* lvl) {
@@ -408,12 +413,15 @@ __global__ void k_record_counts(const uint32_t* __restrict__ counts, uint32_t* _
   if (i < n) rec_cnt[i] = records_for(counts[i]);
 }
 
-/* every slot starts as a dummy: row = one of the first 64 guard words (never a cell), alpha = 0 */
+/* every slot starts as a dummy: row = one of the first 64 guard words (never a cell), alpha = 0.0065 (any value whose
+ * alpha*A/(4 pi) sits in the middle of a 1/32 cell for the usual A: the count-table path of k_vote then treats it like any
+ * other entry instead of taking its on-a-cell-boundary route) */
 __global__ void k_record_init(uint4* __restrict__ records, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint32_t w = (uint32_t)(i & 63u) * 4u;
-    records[i] = make_uint4(w, w, 0u, 0u);
+    const uint32_t al = __float_as_uint(0.0065f);
+    records[i] = make_uint4(w, w, al, al);
   }
 }
 
@@ -1114,11 +1122,9 @@ struct ppf_model {
   DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
   DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
   DevBuf<uint4> records;          /* pair records, see place_entry */
-  DevBuf<uint4> records_fx;       /* the same records, alpha_m in 16.16 fixed point (k_records_to_fixed) */
   DevBuf<int32_t> key_lut;        /* quantised key -> bucket, see k_build_key_lut */
   int lut_na = 0, lut_nd = 0;
   uint64_t n_records = 0;
-  int levels = 1;
   int device = 0;
 };
 
@@ -1126,14 +1132,20 @@ struct ppf_workspace {
   CloudDev surf, edge;
   DevBuf<float> staging;
   DevBuf<uint2> partial;
+  /* hit scratch of one batch of reference points (see ppf_match_kernels.h) */
   DevBuf<double> frames;
-  DevBuf<HitRec> hits;
-  DevBuf<uint2> keys_a, keys_b;
-  DevBuf<uint32_t> hit_count;
+  DevBuf<uint2> raw;                     /* striped pool of {bucket, j} */
+  DevBuf<uint32_t> cursors;              /* CUR_WORDS */
+  DevBuf<uint2> chunk_desc;
+  DevBuf<unsigned long long> hit_count;
+  DevBuf<double> s_a64;
+  DevBuf<uint16_t> s_cell;
+  DevBuf<uint4> runs;
+  DevBuf<uint2> run_blocks;
   DevBuf<unsigned long long> work;
   DevBuf<uint32_t> perm;
   DevBuf<uint32_t> perm_group;
-  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] */
+  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[2] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
   DevBuf<ppf_pose> d_final;
@@ -1144,15 +1156,25 @@ struct ppf_workspace {
   std::vector<ppf_pose> final_poses;
   bool clustered = false;
   ppf_match_stats stats{};
-  const ppf_model* model = nullptr;
+  ppf_model* model = nullptr;           /* retained while the workspace may still read it */
   ppf_match_params params{};
   int n_ref = 0, n_ref_total = 0, rows = 0;
   hipStream_t stream = nullptr;
   bool timing = false;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr}; /* first kernel start, last kernel end */
+  std::vector<hipEvent_t> batch_ev;      /* 4 per batch: k_pairs start / end, k_vote start / end */
+  int n_batches = 0;
   bool pending = false;
+  bool checked = false;                  /* the overflow flag of the pending call has been read */
   bool has_edge = false;
+  double hit_frac = 0.25;                /* expected hits per scene pair: sizes the hit pools, learned from every call */
+  bool frac_known = false;               /* false: the next call first COUNTS its hits (one extra pair pass and one wait) */
+  std::vector<std::pair<const ppf_model*, double>> frac_by_model; /* hit_frac remembered per model (batches alternate models) */
+  int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
+  bool cluster_serial = false;           /* force the serial greedy assignment (otherwise only used above 11,520 poses) */
+  int device = -1;
   uint32_t* acc_dump = nullptr; /* set by ppf_debug_accumulators for one call */
+  ~ppf_workspace();
 };
 
 namespace {
@@ -1197,7 +1219,7 @@ ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int n
     const int np = std::min(num_poses, n);
     const int words = (np + 63) / 64;
     const size_t matrix_words = (size_t)np * words;
-    if (np > 0 && words <= CLM_MAX_WORDS && !getenv("PPF_CLUSTER_SERIAL")) {
+    if (np > 0 && words <= CLM_MAX_WORDS && !ws->cluster_serial) {
       /* match matrix + one wave walking the rows (see k_clm_heads) */
       static std::once_flag once_h;
       static hipError_t attr_h = hipSuccess;
@@ -1268,6 +1290,12 @@ int ppf_device_count(void) {
 }
 
 /* ---- model ------------------------------------------------------------------------------------ */
+/* model reference points whose accumulator rows fit one k_vote workgroup's LDS next to its fixed part */
+static int max_tile_rows(int num_angles) {
+  const long budget = (long)LDS_BYTES - (long)VOTE_LDS_FIXED - 4L * vote_guard(num_angles);
+  return budget <= 0 ? 0 : (int)(budget / (4L * vote_pitch(num_angles)));
+}
+
 /* tabulate hash -> bucket for every key with angle bins 0..floor(pi/angle_step)+1 and distance bins 0..1023 (pairs up
  * to ~1000 distance steps apart: tens of model diameters); everything else keeps the hash path in k_pairs */
 static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
@@ -1278,12 +1306,6 @@ static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
     m->lut_nd = (int)std::max<size_t>(1, ((size_t)1 << 26) / ((size_t)m->lut_na * m->lut_na * m->lut_na));
   }
   const size_t n = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
-  if (PPF_VOTE_FIXED && m->n_records) { /* fixed-point twin of the records (only when k_vote is built to use it) */
-    HIPCHK(m->records_fx.reserve(m->n_records));
-    const double scale = (double)m->info.num_angles / (4 * PPF_PI) * 65536.0;
-    k_records_to_fixed<<<dim3((unsigned)((m->n_records + 255) / 256)), dim3(256), 0, st>>>(m->records.p, m->n_records, scale, m->records_fx.p);
-    HIPCHK(hipGetLastError());
-  }
   HIPCHK(m->key_lut.reserve(n));
   k_build_key_lut<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(m->slotmap.p, m->info.slots - 1, m->lut_na, m->lut_nd, m->key_lut.p);
   HIPCHK(hipGetLastError());
@@ -1329,16 +1351,11 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(offsets.reserve(ncnt));
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
-  /* Dealing order inside a bucket.  Sorted (default): ONE level, and an entry's round is its RANK BY PHASE inside its
-   * bank class (the position of alpha_m inside its bin), so a round holds entries of similar phase from every class:
-   * they take the one-bin jitter together, and with a single level the classes are four times fuller, hence better
-   * balanced -- fewer 32-groups that straddle rounds and repeat a class.  PPF_TABLE_UNSORTED=1: the earlier scheme,
-   * phase quantised to TABLE_LEVELS_MAX levels and arrival order inside a (level, class). */
-  const bool sorted_deal = getenv("PPF_TABLE_UNSORTED") == nullptr;
-  /* per (tile, bucket, phase level, bank class) counters; fewer levels when they would not fit 2 GiB */
-  int levels = sorted_deal ? 1 : TABLE_LEVELS_MAX;
-  while (levels > 1 && ncnt * (size_t)levels * 32 * sizeof(uint32_t) * 2 > (2ull << 30)) levels >>= 1;
-  m->levels = levels;
+  /* Dealing order inside a bucket: ONE phase level, and an entry's round is its RANK BY PHASE inside its bank class
+   * (the position of alpha_m inside its bin), so a round holds entries of similar phase from every class: they take
+   * the one-bin jitter together, and the classes are as full, hence as balanced, as they can be. */
+  const bool sorted_deal = true;
+  const int levels = 1;
   const size_t ncls = ncnt * (size_t)levels * 32;
   DevBuf<uint32_t> class_cnt, class_cur;
   HIPCHK(class_cnt.reserve(ncls));
@@ -1414,7 +1431,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   ppf_status sl = build_key_lut(m, st);
   if (sl != PPF_OK) return sl;
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
-                         m->records.bytes() + m->records_fx.bytes() + m->key_lut.bytes();
+                         m->records.bytes() + m->key_lut.bytes();
   return PPF_OK;
 }
 
@@ -1468,7 +1485,7 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   m->info.position_threshold_default = params->relative_sampling_step;
   m->info.rotation_threshold_default = ((360 / angle_step) / 180.0 * PPF_PI);
   const int A = m->info.num_angles;
-  int max_refs = (LDS_ACC_BUDGET - 4 * vote_guard(A)) / (4 * vote_pitch(A));
+  int max_refs = max_tile_rows(A);
   if (params->max_tile_refs > 0) max_refs = std::min(max_refs, params->max_tile_refs);
   if (max_refs < 1) {
     return fail(PPF_ERR_INVALID, "ppf_model_train: num_angles %d too large for the LDS accumulator", A);
@@ -1491,7 +1508,7 @@ ppf_status ppf_model_retain(ppf_model* m) {
 ppf_status ppf_model_release(ppf_model* m) {
   if (!m) return PPF_OK;
   if (m->refcount.fetch_sub(1) == 1) {
-    (void)hipDeviceSynchronize(); /* the table returns to the block cache: no match may still be reading it */
+    sync_device(m->device); /* the table returns to the block cache: no match may still be reading it */
     delete m;
   }
   return PPF_OK;
@@ -1547,16 +1564,33 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
 /* ---- workspace / matching --------------------------------------------------------------------- */
 ppf_status ppf_workspace_create(ppf_workspace** out) {
   if (!out) return fail(PPF_ERR_INVALID, "ppf_workspace_create: NULL");
-  *out = new ppf_workspace();
+  *out = new (std::nothrow) ppf_workspace();
+  if (!*out) return fail(PPF_ERR_NOMEM, "ppf_workspace_create: out of memory");
   return PPF_OK;
 }
 ppf_status ppf_workspace_destroy(ppf_workspace* ws) {
   if (!ws) return PPF_OK;
-  (void)hipDeviceSynchronize(); /* its buffers return to the block cache: nothing may still be using them */
-  for (auto& e : ws->ev)
-    if (e) (void)hipEventDestroy(e);
-  delete ws;
+  delete ws; /* the destructor drains the device its buffers live on before they return to the block cache */
   return PPF_OK;
+}
+ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value) {
+  if (!ws) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: NULL");
+  switch (option) {
+    case PPF_OPT_HIT_FRACTION:
+      if (!(value > 0 && value <= 1)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: hit fraction must be in (0, 1]");
+      ws->hit_frac = value;
+      ws->frac_known = true;
+      return PPF_OK;
+    case PPF_OPT_GROUP_ROUND_BUCKETS:
+      if (!(value >= 0 && value <= 1e9)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: bad bucket count");
+      ws->round_buckets_cap = (int)value;
+      return PPF_OK;
+    case PPF_OPT_CLUSTER_SERIAL:
+      ws->cluster_serial = value != 0;
+      return PPF_OK;
+    default:
+      return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: unknown option %d", option);
+  }
 }
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on) {
   if (!ws) return fail(PPF_ERR_INVALID, "ppf_workspace_enable_timing: NULL");
@@ -1575,6 +1609,10 @@ static ppf_status check_match_args(const ppf_model* m, const void* scene, int ns
     return fail(PPF_ERR_INVALID, "match: relativeSceneSampleStep must be in (0, 1]");
   if (!p->presampled && !(p->relative_scene_distance > 0)) return fail(PPF_ERR_INVALID, "match: relativeSceneDistance must be > 0");
   if (p->ref_stride < 1 || p->ref_offset < 0) return fail(PPF_ERR_INVALID, "match: bad ref_offset/ref_stride");
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev != m->device)
+    return fail(PPF_ERR_INVALID, "match: the model lives on device %d, the calling thread's current device is %d", m->device, dev);
   return PPF_OK;
 }
 
@@ -1592,30 +1630,76 @@ static ppf_status prepare_scene(ppf_workspace* ws, const float* d_scene, int ns,
   return s;
 }
 
-static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st);
+static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st, bool retry = false);
 
 ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride,
                             const float* d_edge, int ne, int estride, const ppf_match_params* params, void* stream) {
   if (!ws) return fail(PPF_ERR_INVALID, "ppf_match_device: workspace is NULL");
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_device: no HIP device (this engine has no CPU fallback)");
   ppf_status s = check_match_args(m, d_scene, ns, sstride, d_edge, ne, estride, params);
   if (s != PPF_OK) return s;
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_device: no HIP device (this engine has no CPU fallback)");
   hipStream_t st = (hipStream_t)stream;
   s = prepare_scene(ws, d_scene, ns, sstride, d_edge, ne, estride, params, st);
   if (s != PPF_OK) return s;
   return match_prepared(m, ws, params, st);
 }
 
-/* everything after A2: frames -> pairs -> group -> rank -> vote -> finalize -> cluster, on the clouds held by ws */
-static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st) {
+/* store the current model's learned hit fraction (at most 16 models are remembered) */
+static void workspace_remember_frac(ppf_workspace* ws) {
+  if (!ws->model || !ws->frac_known) return;
+  for (auto& fm : ws->frac_by_model)
+    if (fm.first == ws->model) { fm.second = ws->hit_frac; return; }
+  if (ws->frac_by_model.size() >= 16) ws->frac_by_model.erase(ws->frac_by_model.begin());
+  ws->frac_by_model.emplace_back(ws->model, ws->hit_frac);
+}
+
+/* the workspace keeps the model alive until its next call (or its destruction): results are fetched later */
+static void workspace_hold_model(ppf_workspace* ws, const ppf_model* m) {
+  if (ws->model == m) return;
+  ppf_model* old = ws->model;
+  ws->model = const_cast<ppf_model*>(m);
+  if (ws->model) ws->model->refcount.fetch_add(1);
+  if (old) (void)ppf_model_release(old);
+}
+
+ppf_workspace::~ppf_workspace() {
+  sync_device(device); /* buffers return to the block cache: nothing may still be using them */
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : batch_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (model) (void)ppf_model_release(model);
+}
+
+/* bytes of hit scratch one hit costs: raw {bucket, j} + sorted payload (alpha_s, cell) + its share of the run table */
+constexpr double HIT_SCRATCH_BYTES = 8.0 + 8.0 + 2.0 + 16.0 / 6.0;
+
+/* everything after A2: frames -> pairs -> group -> rank -> vote -> finalize -> cluster, on the clouds held by ws.
+ * Nothing here waits for the device: the hit pools are sized from ws->hit_frac (hits per scene pair, learned from the
+ * previous calls); a pool that turns out too small raises a device flag, which the first accessor of the results reads
+ * (workspace_finish) and answers by repeating the call with bigger pools. */
+static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st, bool retry) {
   ppf_status s = PPF_OK;
   const bool d_edge = ws->has_edge;
-  ws->model = m;
+  if (ws->model != m) { /* another model: its own hit density (remembered if it has been here before) */
+    workspace_remember_frac(ws);
+    bool found = false;
+    for (auto& fm : ws->frac_by_model)
+      if (fm.first == m) { ws->hit_frac = fm.second; found = true; }
+    if (found) ws->frac_known = true;
+    else if (!ws->frac_by_model.empty()) ws->frac_known = false; /* a model this workspace has not met: count first */
+  }
+  workspace_hold_model(ws, m);
+  HIPCHK(hipGetDevice(&ws->device));
   ws->params = *params;
   ws->stream = st;
   ws->clustered = false;
+  ws->checked = false;
   ws->final_poses.clear();
+  const int retries = retry ? ws->stats.n_retries : 0;
   memset(&ws->stats, 0, sizeof(ws->stats));
+  ws->stats.n_retries = retries;
   const int rows = ws->surf.n;
   const int scene_step = (int)(1.0 / params->relative_scene_sample_step);
   const int n_ref_total = (rows + scene_step - 1) / scene_step;
@@ -1623,6 +1707,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   ws->rows = rows;
   ws->n_ref_total = n_ref_total;
   ws->n_ref = n_ref;
+  ws->n_batches = 0;
   ws->stats.n_scene_sampled = rows;
   ws->stats.n_paired = d_edge ? ws->edge.n : rows;
   ws->stats.n_ref = n_ref;
@@ -1631,7 +1716,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
 
   const int T = m->info.n_tiles;
   HIPCHK(ws->partial.reserve((size_t)n_ref * T));
-  const size_t n_cnt = (size_t)n_ref * T + n_ref + 2;
+  const size_t n_cnt = (size_t)n_ref * T + n_ref + 4;
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
   HIPCHK(ws->raw_poses.reserve(n_ref));
@@ -1639,13 +1724,13 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(hipMemsetAsync(ws->counters.p, 0, n_cnt * sizeof(unsigned long long), st));
 
   MatchArgs va;
+  memset(&va, 0, sizeof(va));
   va.surf = ws->surf.view();
   va.paired = d_edge ? ws->edge.view() : ws->surf.view();
   va.same_cloud = d_edge ? 0 : 1;
   va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride;
   va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
   va.key_lut = m->key_lut.p; va.lut_na = m->lut_na; va.lut_nd = m->lut_nd;
-  va.records_fx = m->records_fx.p;
   va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
   va.records = m->records.p;
   va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
@@ -1653,71 +1738,130 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.partial = ws->partial.p;
   va.cellsum = ws->counters.p;
   va.pairs = ws->counters.p + (size_t)n_ref * T;
+  va.tally = ws->counters.p + (size_t)n_ref * T + n_ref + 2;
   va.acc_dump = ws->acc_dump;
-  va.ablate = 0;
+  va.bucket_total = m->bucket_total.p;
+  va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
   const int n_paired = va.paired.n;
-  /* reference points are processed in batches whose worst-case hit lists (every pair hits) fit the scratch budget */
-  const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_ref, HIT_BYTES_BUDGET / ((size_t)n_paired * (sizeof(HitRec) + 2 * sizeof(uint2)))));
+  va.pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
+  const uint32_t round_cap = ws->round_buckets_cap > 0 ? (uint32_t)std::min(ws->round_buckets_cap, GROUP_MAX_BUCKETS) : (uint32_t)GROUP_MAX_BUCKETS;
+  va.n_rounds = std::max(1, (int)((m->info.n_buckets + round_cap - 1) / round_cap));
+  va.round_buckets = (int)std::min<uint32_t>(std::max<uint32_t>(m->info.n_buckets, 1u), round_cap);
+
+  HIPCHK(ws->cursors.reserve(CUR_WORDS));
+  va.cursors = ws->cursors.p;
+  if (!ws->frac_known) {
+    /* Cold workspace: nothing is known about this scene's hit density, so the pair kernel first only counts its hits
+     * (same arithmetic, nothing stored) and the pools are sized from the exact number.  Costs one extra pair pass and
+     * one wait for the device, once: later calls size their pools from what the previous call saw. */
+    HIPCHK(hipMemsetAsync(ws->cursors.p, 0, CUR_WORDS * sizeof(uint32_t), st));
+    va.count_only = 1;
+    va.stripe_bits = 6;
+    for (int base = 0; base < n_ref; base += 32768) {
+      va.ref_base = base;
+      va.n_ref = std::min(32768, n_ref - base);
+      k_pairs<<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+      HIPCHK(hipGetLastError());
+    }
+    va.count_only = 0;
+    std::vector<uint32_t> cw(CUR_SORTED);
+    HIPCHK(hipMemcpyAsync(cw.data(), ws->cursors.p, cw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    unsigned long long hits = 0;
+    for (int sidx = 0; sidx < POOL_STRIPES; sidx++)
+      hits += (unsigned long long)cw[sidx * CUR_STRIDE] | ((unsigned long long)cw[sidx * CUR_STRIDE + 1] << 32);
+    const double pairs_total = (double)n_ref * (double)n_paired;
+    ws->hit_frac = std::min(1.0, std::max(1e-3, 1.06 * (double)hits / std::max(1.0, pairs_total)));
+    ws->frac_known = true;
+  }
+  /* batch of reference points: its expected hits fit the scratch budget (and 32-bit pool offsets) */
+  const double frac = std::min(1.0, std::max(ws->hit_frac, 1e-3));
+  const double hits_per_ref = std::max(64.0, frac * (double)n_paired);
+  int batch = (int)std::min<double>((double)n_ref, std::max(1.0, (double)HIT_BYTES_BUDGET / (hits_per_ref * HIT_SCRATCH_BYTES)));
+  batch = (int)std::min<double>((double)batch, std::max(1.0, 2.0e9 / hits_per_ref));
+  batch = std::min(batch, 32768); /* grid.y of k_pairs */
+  const bool worst_case = frac >= 1.0;
+  const double est = hits_per_ref * (double)batch;
+  /* a stripe receives whole workgroups of up to PAIR_BLOCK*PAIRS_PER_THREAD hits; at worst-case size every workgroup of
+   * the batch could be full and land anywhere, otherwise 4 % + two workgroups of slack over an even share */
+  const uint32_t wg_hits = PAIR_BLOCK * PAIRS_PER_THREAD;
+  int stripe_bits = 6; /* 64 stripes, fewer while a stripe would average over less than 512 workgroups */
+  while (stripe_bits > 0 && ((size_t)batch * va.pair_chunks >> stripe_bits) < 512) stripe_bits--;
+  if (worst_case) stripe_bits = 0; /* one stripe that holds every pair of the batch: nothing can overflow */
+  const uint32_t n_stripes = 1u << stripe_bits;
+  const uint32_t stripe_cap = worst_case ? (uint32_t)std::min<double>(4.0e9 / n_stripes, (double)batch * va.pair_chunks * wg_hits)
+                                         : (uint32_t)(est / n_stripes * 1.04) + 2 * wg_hits;
+  const uint32_t sorted_cap = (uint32_t)std::min(4.0e9, est + 4096.0);
+  const uint32_t run_cap = worst_case ? sorted_cap : (uint32_t)std::min<double>((double)sorted_cap, std::max(est / 6.0, 64.0 * batch) + 1024.0);
   HIPCHK(ws->frames.reserve((size_t)batch * 12));
-  HIPCHK(ws->hits.reserve((size_t)batch * n_paired));
-  HIPCHK(ws->keys_a.reserve((size_t)batch * n_paired));
-  HIPCHK(ws->keys_b.reserve((size_t)batch * n_paired));
+  HIPCHK(ws->raw.reserve((size_t)stripe_cap * n_stripes));
+  HIPCHK(ws->chunk_desc.reserve((size_t)batch * va.pair_chunks));
   HIPCHK(ws->hit_count.reserve(batch));
+  HIPCHK(ws->s_a64.reserve(sorted_cap));
+  HIPCHK(ws->s_cell.reserve(sorted_cap));
+  HIPCHK(ws->runs.reserve(run_cap));
+  HIPCHK(ws->run_blocks.reserve((size_t)batch * va.n_rounds));
   HIPCHK(ws->work.reserve(batch));
   HIPCHK(ws->perm.reserve(batch));
   HIPCHK(ws->perm_group.reserve(batch));
-  va.bucket_total = m->bucket_total.p; va.work = ws->work.p; va.perm = ws->perm.p;
-  va.frames = ws->frames.p; va.hits = ws->hits.p; va.hit_count = ws->hit_count.p; va.hit_cap = n_paired;
-  va.keys_a = ws->keys_a.p; va.keys_b = ws->keys_b.p;
-  va.keys_sorted = nullptr; /* set once group_lds_buckets is known */
-  va.key_bits = 1;
-  while (va.key_bits < 32 && (1ull << va.key_bits) < (unsigned long long)m->info.n_buckets) va.key_bits++;
+  ws->stats.scratch_bytes = ws->frames.bytes() + ws->raw.bytes() + ws->cursors.bytes() + ws->chunk_desc.bytes() + ws->hit_count.bytes() +
+                            ws->s_a64.bytes() + ws->s_cell.bytes() + ws->runs.bytes() + ws->run_blocks.bytes() +
+                            ws->work.bytes() + ws->perm.bytes() + ws->perm_group.bytes();
+  va.frames = ws->frames.p;
+  va.raw = ws->raw.p; va.stripe_cap = stripe_cap; va.stripe_bits = stripe_bits;
+  va.chunk_desc = ws->chunk_desc.p; va.hit_count = ws->hit_count.p;
+  va.s_a64 = ws->s_a64.p; va.s_cell = ws->s_cell.p; va.sorted_cap = sorted_cap;
+  va.runs = ws->runs.p; va.run_cap = run_cap; va.run_blocks = ws->run_blocks.p;
+  va.work = ws->work.p; va.perm = ws->perm.p; va.perm_group = ws->perm_group.p;
+
   const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)m->info.tile_refs * vote_pitch(m->info.num_angles)) * 4;
+  if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
+  /* k_group's dynamic LDS: counters, chunk prefix, and as many cached alpha_s as the rest holds */
+  const size_t group_fixed = (size_t)va.round_buckets * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
+  if (group_fixed + 2048 > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: %d paired points are more than one call can group", n_paired);
+  va.group_cache = (int)std::min<size_t>((size_t)n_paired, ((size_t)LDS_BYTES - 1024 - group_fixed) / sizeof(double));
+  const size_t group_lds = group_fixed + (size_t)va.group_cache * sizeof(double);
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024);
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES - 1024);
   });
   HIPCHK(attr_err);
-  /* timing: ev[1]..ev[2] bracket the voting kernel of the first batch only when there are several;
-   * with one batch (every measured configuration) they bracket exactly one k_vote launch */
-  const int pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
-  /* k_group: one LDS counter per bucket when that fits (<= 30k buckets), else the radix-sort path */
-  va.group_lds_buckets = m->info.n_buckets <= 30000 ? (int)m->info.n_buckets : 0;
-  va.keys_sorted = va.group_lds_buckets ? va.keys_b : va.keys_a;
-  const size_t group_lds = va.group_lds_buckets ? ((size_t)va.group_lds_buckets + 1 + 16) * sizeof(uint32_t)
-                                                : (size_t)(GROUP_BLOCK / 64) * 256 * sizeof(uint32_t);
-  static std::once_flag once_g;
-  static hipError_t attr_g = hipSuccess;
-  std::call_once(once_g, [] {
-    attr_g = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group), hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
-  });
-  HIPCHK(attr_g);
-  for (int base = 0; base < n_ref; base += batch) {
+  const int n_batches = (n_ref + batch - 1) / batch;
+  ws->n_batches = n_batches;
+  ws->stats.n_batches = n_batches;
+  if (ws->timing)
+    while (ws->batch_ev.size() < (size_t)n_batches * 4) {
+      hipEvent_t e = nullptr;
+      HIPCHK(hipEventCreate(&e));
+      ws->batch_ev.push_back(e);
+    }
+  HIPCHK(hipMemsetAsync(ws->cursors.p, 0, CUR_WORDS * sizeof(uint32_t), st));
+  for (int bi = 0; bi < n_batches; bi++) {
+    const int base = bi * batch;
     va.ref_base = base;
     va.n_ref = std::min(batch, n_ref - base);
-    HIPCHK(hipMemsetAsync(ws->hit_count.p, 0, (size_t)va.n_ref * sizeof(uint32_t), st));
+    if (bi) HIPCHK(hipMemsetAsync(ws->cursors.p, 0, CUR_OVERFLOW * sizeof(uint32_t), st)); /* the overflow word lives on */
     k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
     HIPCHK(hipGetLastError());
-    if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[4], st));
-    k_pairs<<<dim3(pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 0], st));
+    k_pairs<<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
     HIPCHK(hipGetLastError());
-    if (!getenv("PPF_GROUP_INDEX_ORDER")) { /* k_group takes the reference points with the most hits first */
-      k_widen_u32<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(ws->hit_count.p, va.n_ref, ws->work.p);
-      k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(ws->work.p, va.n_ref, nullptr, ws->perm_group.p, nullptr);
-      va.perm_group = ws->perm_group.p;
-    } else {
-      va.perm_group = nullptr;
-    }
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 1], st));
+    k_ref_hits<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va);
+    /* k_group takes the reference points with the most hits first */
+    k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.hit_count, va.n_ref, nullptr, ws->perm_group.p, nullptr);
     k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), group_lds, st>>>(va);
     HIPCHK(hipGetLastError());
+    /* k_vote takes the reference points that will cast the most votes first */
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
-    if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[1], st));
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 2], st));
     k_vote<<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
     HIPCHK(hipGetLastError());
-    if (ws->timing && base == 0) HIPCHK(hipEventRecord(ws->ev[2], st));
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 3], st));
   }
 
   FinalArgs fa;
@@ -1739,32 +1883,74 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     if (s != PPF_OK) return s;
     ws->clustered = true;
   }
-  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[3], st));
+  if (ws->timing) HIPCHK(hipEventRecord(ws->ev[1], st));
   return PPF_OK;
+}
+
+/* Wait for the workspace's pending call and make sure it ran with big enough hit pools: when a pool overflowed (device
+ * flag), the call is repeated on the same stream with a doubled estimate, until it fits (at hit_frac == 1 the pools
+ * hold every scene pair).  Also reads the counters and learns hit_frac for the next call. */
+static ppf_status workspace_finish(ppf_workspace* ws) {
+  if (!ws->pending) return fail(PPF_ERR_INVALID, "no call in this workspace");
+  HIPCHK(hipStreamSynchronize(ws->stream));
+  if (ws->checked || ws->n_ref == 0) { ws->checked = true; return PPF_OK; }
+  for (;;) {
+    const int T = ws->model->info.n_tiles;
+    unsigned long long tot[4];
+    uint32_t ovf = 0;
+    HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
+    if (!ovf) {
+      ws->stats.n_votes = tot[0];
+      ws->stats.n_pairs = tot[1];
+      ws->stats.n_lds_atomics = tot[2];
+      ws->stats.n_hits = tot[3];
+      if (tot[1]) ws->hit_frac = std::min(1.0, std::max(1e-3, 1.06 * (double)tot[3] / (double)tot[1]));
+      ws->frac_known = true;
+      if (ws->clustered) {
+        uint32_t nf = 0;
+        HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ws->stats.n_poses = (int)nf;
+      }
+      if (ws->timing) {
+        float pr = 0, gr = 0, vo = 0;
+        for (int b = 0; b < ws->n_batches; b++) {
+          float t0 = 0, t1 = 0, t2 = 0;
+          HIPCHK(hipEventElapsedTime(&t0, ws->batch_ev[b * 4 + 0], ws->batch_ev[b * 4 + 1]));
+          HIPCHK(hipEventElapsedTime(&t1, ws->batch_ev[b * 4 + 1], ws->batch_ev[b * 4 + 2]));
+          HIPCHK(hipEventElapsedTime(&t2, ws->batch_ev[b * 4 + 2], ws->batch_ev[b * 4 + 3]));
+          pr += t0; gr += t1; vo += t2;
+        }
+        ws->stats.ms_pair_kernel = pr; ws->stats.ms_group_kernel = gr; ws->stats.ms_vote_kernel = vo;
+        HIPCHK(hipEventElapsedTime(&ws->stats.ms_total_device, ws->ev[0], ws->ev[1]));
+      }
+      ws->checked = true;
+      return PPF_OK;
+    }
+    if (ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
+    ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0);
+    ws->stats.n_retries++;
+    const ppf_match_params p = ws->params;
+    ppf_model* m = ws->model;
+    ppf_status s = match_prepared(m, ws, &p, ws->stream, true);
+    if (s != PPF_OK) return s;
+    HIPCHK(hipStreamSynchronize(ws->stream));
+  }
 }
 
 ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* raw_poses, int cap_ref, int* n_ref,
                                  ppf_pose* poses, int cap_poses, int* n_poses, ppf_match_stats* stats) {
   if (!ws || !ws->pending) return fail(PPF_ERR_INVALID, "ppf_workspace_results: no call in this workspace");
-  HIPCHK(hipStreamSynchronize(ws->stream));
+  ppf_status sf = workspace_finish(ws);
+  if (sf != PPF_OK) return sf;
   const int nr = ws->n_ref;
   if (n_ref) *n_ref = nr;
   if ((votes || raw_poses) && cap_ref < nr) return fail(PPF_ERR_CAPACITY, "ppf_workspace_results: need room for %d reference points", nr);
   if (nr > 0) {
-    const int T = ws->model->info.n_tiles;
-    unsigned long long tot[2];
-    HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)nr * T + nr, sizeof(tot), hipMemcpyDeviceToHost));
-    ws->stats.n_votes = tot[0];
-    ws->stats.n_pairs = tot[1];
-    if (ws->timing) {
-      HIPCHK(hipEventElapsedTime(&ws->stats.ms_vote_kernel, ws->ev[1], ws->ev[2]));
-      HIPCHK(hipEventElapsedTime(&ws->stats.ms_pair_kernel, ws->ev[4], ws->ev[1]));
-      HIPCHK(hipEventElapsedTime(&ws->stats.ms_total_device, ws->ev[0], ws->ev[3]));
-    }
     if (votes) HIPCHK(hipMemcpy(votes, ws->votes.p, (size_t)nr * sizeof(ppf_vote), hipMemcpyDeviceToHost));
     if (raw_poses) HIPCHK(hipMemcpy(raw_poses, ws->raw_poses.p, (size_t)nr * sizeof(ppf_pose), hipMemcpyDeviceToHost));
   }
-  if ((poses || n_poses) && !ws->params.skip_clustering && ws->clustered) {
+  if ((poses || n_poses) && ws->clustered) {
     if (ws->final_poses.empty() && nr > 0) {
       uint32_t nf = 0;
       HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1790,7 +1976,8 @@ static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int s
 
 ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref, uint64_t* pairs_per_ref, int cap) {
   if (!ws || !ws->pending) return fail(PPF_ERR_INVALID, "ppf_workspace_ref_counters: no call in this workspace");
-  HIPCHK(hipStreamSynchronize(ws->stream));
+  ppf_status sf = workspace_finish(ws);
+  if (sf != PPF_OK) return sf;
   const int nr = ws->n_ref;
   if (cap < nr) return fail(PPF_ERR_CAPACITY, "ppf_workspace_ref_counters: need room for %d reference points", nr);
   if (nr == 0) return PPF_OK;
@@ -1852,6 +2039,77 @@ ppf_status ppf_workspace_device_poses(ppf_workspace* ws, void** d_raw_poses, int
   return PPF_OK;
 }
 
+/* copy `cap` pose records to dst: the first min(n, cap) from src, zeros after them (num_votes == 0 marks an empty row);
+ * n comes from the device (n_dev) when given.  Optionally also saves the count, the overflow flag of the call and its
+ * four 64-bit totals (votes, pairs, LDS operations, hits) next to the block: what a batch needs per (crop, model). */
+__global__ __launch_bounds__(256) void k_pose_block(const ppf_pose* __restrict__ src, const uint32_t* __restrict__ n_dev, int n_host,
+                                                    ppf_pose* __restrict__ dst, int cap, uint32_t* __restrict__ meta_out,
+                                                    const uint32_t* __restrict__ flag_in, unsigned long long* __restrict__ tot_out,
+                                                    const unsigned long long* __restrict__ tot_in) {
+  constexpr int W = (int)(sizeof(ppf_pose) / 8);
+  const int n = n_dev ? (int)*n_dev : n_host;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap * W) {
+    const int row = i / W;
+    const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(src);
+    reinterpret_cast<unsigned long long*>(dst)[i] = row < n ? s64[i] : 0ull;
+  }
+  if (i == 0 && meta_out) { meta_out[0] = (uint32_t)n; meta_out[1] = flag_in ? *flag_in : 0u; }
+  if (i < 4 && tot_out && tot_in) tot_out[i] = tot_in[i];
+}
+
+ppf_status ppf_workspace_copy_top_poses(ppf_workspace* ws, void* d_dst, int k, void* stream) {
+  if (!ws || !ws->pending || !d_dst || k <= 0) return fail(PPF_ERR_INVALID, "ppf_workspace_copy_top_poses: bad argument");
+  if (!ws->clustered || ws->n_ref == 0) {
+    HIPCHK(hipMemsetAsync(d_dst, 0, (size_t)k * sizeof(ppf_pose), (hipStream_t)stream));
+    return PPF_OK;
+  }
+  const int words = k * (int)(sizeof(ppf_pose) / 8);
+  k_pose_block<<<dim3((words + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ws->d_final.p, ws->cl_u32.p, 0, (ppf_pose*)d_dst, k, nullptr,
+                                                                                 nullptr, nullptr, nullptr);
+  HIPCHK(hipGetLastError());
+  return PPF_OK;
+}
+
+ppf_status ppf_workspace_copy_raw_poses(ppf_workspace* ws, void* d_dst, int cap, void* stream) {
+  if (!ws || !ws->pending || !d_dst || cap <= 0) return fail(PPF_ERR_INVALID, "ppf_workspace_copy_raw_poses: bad argument");
+  if (cap < ws->n_ref) return fail(PPF_ERR_CAPACITY, "ppf_workspace_copy_raw_poses: need room for %d reference points", ws->n_ref);
+  if (ws->n_ref == 0) {
+    HIPCHK(hipMemsetAsync(d_dst, 0, (size_t)cap * sizeof(ppf_pose), (hipStream_t)stream));
+    return PPF_OK;
+  }
+  const int words = cap * (int)(sizeof(ppf_pose) / 8);
+  k_pose_block<<<dim3((words + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ws->raw_poses.p, nullptr, ws->n_ref, (ppf_pose*)d_dst, cap,
+                                                                                 nullptr, nullptr, nullptr, nullptr);
+  HIPCHK(hipGetLastError());
+  return PPF_OK;
+}
+
+ppf_status ppf_cluster_poses_device(const ppf_model* m, ppf_workspace* ws, const void* d_in, int n, int num_poses,
+                                    const ppf_match_params* params, void* stream) {
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "ppf_cluster_poses_device: model is NULL");
+  if (!ws || (!d_in && n > 0) || n < 0 || !params) return fail(PPF_ERR_INVALID, "ppf_cluster_poses_device: bad argument");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_cluster_poses_device: no HIP device (this engine has no CPU fallback)");
+  workspace_hold_model(ws, m);
+  HIPCHK(hipGetDevice(&ws->device));
+  ws->params = *params;
+  ws->stream = (hipStream_t)stream;
+  ws->final_poses.clear();
+  memset(&ws->stats, 0, sizeof(ws->stats));
+  ws->n_ref = 0; ws->n_ref_total = 0; ws->n_batches = 0;
+  ws->pending = true; ws->checked = true; /* no hit pools involved */
+  ws->clustered = false;
+  if (n == 0) return PPF_OK;
+  double pos, rot;
+  resolve_thresholds(m, params, &pos, &rot);
+  ppf_status s = enqueue_cluster(ws, (const ppf_pose*)d_in, n, num_poses, pos, rot, params->use_weighted_avg != 0, (hipStream_t)stream);
+  if (s != PPF_OK) return s;
+  ws->clustered = true;
+  ws->n_ref = n; /* d_final / cl_u32 hold the clusters; results come back through ppf_workspace_results(poses) / _copy_top_poses */
+  ws->stats.n_ref = n;
+  return PPF_OK;
+}
+
 ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int num_poses,
                              const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
   if (!m) return fail(PPF_ERR_NOT_TRAINED, "ppf_cluster_poses: model is NULL");
@@ -1881,9 +2139,10 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
 /* host-buffer conveniences: upload, run on the default stream, download */
 static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
                            int estride, const ppf_match_params* params, ppf_workspace* ws) {
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  if (!have_device()) return fail(PPF_ERR_HIP, "match: no HIP device (this engine has no CPU fallback)");
   ppf_status s = check_match_args(m, scene, ns, sstride, edge, ne, estride, params);
   if (s != PPF_OK) return s;
-  if (!have_device()) return fail(PPF_ERR_HIP, "match: no HIP device (this engine has no CPU fallback)");
   DevBuf<float> d_scene, d_edge;
   HIPCHK(d_scene.reserve((size_t)ns * sstride));
   HIPCHK(hipMemcpy(d_scene.p, scene, (size_t)ns * sstride * sizeof(float), hipMemcpyHostToDevice));
@@ -1904,9 +2163,225 @@ ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride
   ppf_workspace ws;
   ppf_status s = run_host(m, scene, ns, sstride, edge, ne, estride, params, &ws);
   if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
-  for (auto& e : ws.ev)
-    if (e) (void)hipEventDestroy(e);
   return s;
+}
+
+/* ---- many crops x many models (BASELINE config C5) ------------------------------------------------------------------
+ * A batch context owns `lanes` (stream, workspace) pairs.  Crop c goes to lane c mod lanes: its rows are staged through
+ * pinned memory (host scenes), uploaded and sampled once, then matched against every model back to back on the lane's
+ * stream; after each match a small kernel saves the best `cap` clustered poses, their count, the hit-pool flag and the
+ * counters into the batch's device block, so nothing waits for the host between matches.  One synchronisation per lane
+ * at the end, one read-back of the block.  A match whose hit pools were too small (flag) is repeated afterwards. */
+struct ppf_batch {
+  int lanes = 0;
+  int device = 0;
+  std::vector<ppf_workspace*> ws;
+  std::vector<hipStream_t> streams;
+  std::vector<float*> pinned;        /* 2 staging buffers per lane */
+  std::vector<size_t> pinned_cap;
+  std::vector<hipEvent_t> pinned_ev; /* upload from that staging buffer finished */
+  std::vector<DevBuf<float>*> d_scene;
+  DevBuf<ppf_pose> d_out;
+  DevBuf<uint32_t> d_meta;
+  DevBuf<unsigned long long> d_tot;
+  int last_records = 0;
+};
+
+ppf_status ppf_batch_create(int lanes, ppf_batch** out) {
+  if (!out || lanes < 1 || lanes > 64) return fail(PPF_ERR_INVALID, "ppf_batch_create: bad argument");
+  *out = nullptr;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_batch_create: no HIP device (this engine has no CPU fallback)");
+  std::unique_ptr<ppf_batch> b(new (std::nothrow) ppf_batch());
+  if (!b) return fail(PPF_ERR_NOMEM, "ppf_batch_create: out of memory");
+  HIPCHK(hipGetDevice(&b->device));
+  b->lanes = lanes;
+  for (int l = 0; l < lanes; l++) {
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)ppf_batch_destroy(b.release()); return fail(PPF_ERR_HIP, "ppf_batch_create: %s", hipGetErrorString(e)); }
+    b->streams.push_back(st);
+    b->ws.push_back(new ppf_workspace());
+    b->d_scene.push_back(new DevBuf<float>());
+    for (int k = 0; k < 2; k++) {
+      hipEvent_t ev = nullptr;
+      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      b->pinned.push_back(nullptr); b->pinned_cap.push_back(0); b->pinned_ev.push_back(ev);
+      if (e != hipSuccess) { (void)ppf_batch_destroy(b.release()); return fail(PPF_ERR_HIP, "ppf_batch_create: %s", hipGetErrorString(e)); }
+    }
+  }
+  *out = b.release();
+  return PPF_OK;
+}
+
+ppf_status ppf_batch_destroy(ppf_batch* b) {
+  if (!b) return PPF_OK;
+  sync_device(b->device);
+  for (auto* w : b->ws) delete w;
+  for (auto* d : b->d_scene) delete d;
+  for (auto st : b->streams) if (st) (void)hipStreamDestroy(st);
+  for (auto p : b->pinned) if (p) (void)hipHostFree(p);
+  for (auto e : b->pinned_ev) if (e) (void)hipEventDestroy(e);
+  delete b;
+  return PPF_OK;
+}
+
+ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
+                         int sstride, int n_scenes, int scenes_on_device, const ppf_match_params* params, ppf_pose* out, int cap,
+                         int* n_out, ppf_batch_stats* stats) {
+  if (!b || !models || n_models <= 0 || !scenes || !ns || n_scenes <= 0 || !params || cap <= 0)
+    return fail(PPF_ERR_INVALID, "ppf_batch_run: bad argument");
+  for (int k = 0; k < n_models; k++)
+    if (!models[k]) return fail(PPF_ERR_NOT_TRAINED, "ppf_batch_run: model %d is not trained", k);
+  ppf_match_params p = *params;
+  if (p.skip_clustering) return fail(PPF_ERR_INVALID, "ppf_batch_run: a batch returns clustered poses");
+  for (int c = 0; c < n_scenes; c++) {
+    ppf_status s = check_match_args(models[0], scenes[c], ns[c], sstride, nullptr, 0, 6, &p);
+    if (s != PPF_OK) return s;
+  }
+  const auto t_start = std::chrono::steady_clock::now();
+  const size_t n_match = (size_t)n_scenes * n_models;
+  HIPCHK(b->d_out.reserve(n_match * cap));
+  HIPCHK(b->d_meta.reserve(n_match * 2));
+  HIPCHK(b->d_tot.reserve(n_match * 4));
+  b->last_records = (int)(n_match * cap);
+  const int words = cap * (int)(sizeof(ppf_pose) / 8);
+
+  /* one (crop, model) match on a lane, results saved to the block */
+  auto enqueue_pair = [&](int lane, int c, int k) -> ppf_status {
+    ppf_workspace* ws = b->ws[lane];
+    hipStream_t st = b->streams[lane];
+    ppf_status s = match_prepared(models[k], ws, &p, st);
+    if (s != PPF_OK) return s;
+    const size_t idx = (size_t)c * n_models + k;
+    if (ws->n_ref == 0) {
+      HIPCHK(hipMemsetAsync(b->d_out.p + idx * cap, 0, (size_t)cap * sizeof(ppf_pose), st));
+      HIPCHK(hipMemsetAsync(b->d_meta.p + idx * 2, 0, 2 * sizeof(uint32_t), st));
+      HIPCHK(hipMemsetAsync(b->d_tot.p + idx * 4, 0, 4 * sizeof(unsigned long long), st));
+      return PPF_OK;
+    }
+    const unsigned long long* tot = ws->counters.p + (size_t)ws->n_ref * models[k]->info.n_tiles + ws->n_ref;
+    k_pose_block<<<dim3((words + 255) / 256), dim3(256), 0, st>>>(ws->d_final.p, ws->cl_u32.p, 0, b->d_out.p + idx * cap, cap,
+                                                                   b->d_meta.p + idx * 2, ws->cursors.p + CUR_OVERFLOW,
+                                                                   b->d_tot.p + idx * 4, tot);
+    HIPCHK(hipGetLastError());
+    return PPF_OK;
+  };
+  /* bring crop c into the lane's workspace (upload if it is a host cloud, then A2) */
+  auto stage_crop = [&](int lane, int c, int use) -> ppf_status {
+    hipStream_t st = b->streams[lane];
+    const float* d_src = scenes[c];
+    if (!scenes_on_device) {
+      const size_t floats = (size_t)ns[c] * sstride;
+      const int slot = lane * 2 + (use & 1);
+      HIPCHK(hipEventSynchronize(b->pinned_ev[slot])); /* the upload that last used this staging buffer is done */
+      if (b->pinned_cap[slot] < floats) {
+        if (b->pinned[slot]) HIPCHK(hipHostFree(b->pinned[slot]));
+        b->pinned[slot] = nullptr; b->pinned_cap[slot] = 0;
+        HIPCHK(hipHostMalloc((void**)&b->pinned[slot], floats * sizeof(float), hipHostMallocDefault));
+        b->pinned_cap[slot] = floats;
+      }
+      memcpy(b->pinned[slot], scenes[c], floats * sizeof(float));
+      HIPCHK(b->d_scene[lane]->reserve(floats));
+      HIPCHK(hipMemcpyAsync(b->d_scene[lane]->p, b->pinned[slot], floats * sizeof(float), hipMemcpyHostToDevice, st));
+      HIPCHK(hipEventRecord(b->pinned_ev[slot], st));
+      d_src = b->d_scene[lane]->p;
+    }
+    return prepare_scene(b->ws[lane], d_src, ns[c], sstride, nullptr, 0, 6, &p, st);
+  };
+
+  std::vector<int> uses(b->lanes, 0);
+  for (int c = 0; c < n_scenes; c++) {
+    const int lane = c % b->lanes;
+    ppf_status s = stage_crop(lane, c, uses[lane]++);
+    if (s != PPF_OK) return s;
+    for (int k = 0; k < n_models; k++) {
+      s = enqueue_pair(lane, c, k);
+      if (s != PPF_OK) return s;
+    }
+  }
+  for (int l = 0; l < b->lanes; l++) HIPCHK(hipStreamSynchronize(b->streams[l]));
+  std::vector<uint32_t> meta(n_match * 2);
+  std::vector<unsigned long long> tot(n_match * 4);
+  HIPCHK(hipMemcpy(meta.data(), b->d_meta.p, meta.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(tot.data(), b->d_tot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  /* learn the hit fraction per lane; repeat the matches whose pools overflowed, one at a time, with doubled pools */
+  int retries = 0;
+  for (int c = 0; c < n_scenes; c++) {
+    const int lane = c % b->lanes;
+    ppf_workspace* ws = b->ws[lane];
+    bool staged = false;
+    for (int k = 0; k < n_models; k++) {
+      const size_t idx = (size_t)c * n_models + k;
+      bool at_full = false;
+      while (meta[idx * 2 + 1]) {
+        if (at_full) return fail(PPF_ERR_CAPACITY, "ppf_batch_run: hit pools overflowed at worst-case size");
+        retries++;
+        ppf_status s = PPF_OK;
+        if (!staged) { s = stage_crop(lane, c, uses[lane]++); staged = true; }
+        if (s != PPF_OK) return s;
+        /* pools twice what this (crop, model) match had: match_prepared looks the model's fraction up itself */
+        workspace_hold_model(ws, nullptr);
+        double f = 0.25;
+        for (auto& fm : ws->frac_by_model)
+          if (fm.first == models[k]) f = fm.second;
+        f = std::min(1.0, 2.0 * f);
+        at_full = f >= 1.0;
+        bool found = false;
+        for (auto& fm : ws->frac_by_model)
+          if (fm.first == models[k]) { fm.second = f; found = true; }
+        if (!found) ws->frac_by_model.emplace_back(models[k], f);
+        s = enqueue_pair(lane, c, k);
+        if (s != PPF_OK) return s;
+        HIPCHK(hipStreamSynchronize(b->streams[lane]));
+        HIPCHK(hipMemcpy(&meta[idx * 2], b->d_meta.p + idx * 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&tot[idx * 4], b->d_tot.p + idx * 4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      }
+    }
+  }
+  /* what every lane remembers per model: the densest crop it saw */
+  std::vector<double> lane_frac((size_t)b->lanes * n_models, 0.0);
+  ppf_batch_stats st{};
+  for (size_t idx = 0; idx < n_match; idx++) {
+    st.n_votes += tot[idx * 4 + 0]; st.n_pairs += tot[idx * 4 + 1]; st.n_lds_atomics += tot[idx * 4 + 2]; st.n_hits += tot[idx * 4 + 3];
+    const size_t slot = (size_t)((idx / n_models) % b->lanes) * n_models + idx % n_models;
+    if (tot[idx * 4 + 1]) lane_frac[slot] = std::max(lane_frac[slot], (double)tot[idx * 4 + 3] / (double)tot[idx * 4 + 1]);
+  }
+  for (int l = 0; l < b->lanes; l++) {
+    ppf_workspace* ws = b->ws[l];
+    workspace_hold_model(ws, nullptr); /* the next call looks its model up */
+    for (int k = 0; k < n_models; k++) {
+      const double f = lane_frac[(size_t)l * n_models + k];
+      if (!(f > 0)) continue;
+      const double learned = std::min(1.0, std::max(1e-3, 1.06 * f));
+      bool found = false;
+      for (auto& fm : ws->frac_by_model)
+        if (fm.first == models[k]) { fm.second = learned; found = true; }
+      if (!found) ws->frac_by_model.emplace_back(models[k], learned);
+    }
+  }
+  if (out) HIPCHK(hipMemcpy(out, b->d_out.p, n_match * cap * sizeof(ppf_pose), hipMemcpyDeviceToHost));
+  if (n_out)
+    for (size_t idx = 0; idx < n_match; idx++) n_out[idx] = (int)std::min<uint32_t>(meta[idx * 2], (uint32_t)cap);
+  st.n_matches = (int)n_match;
+  st.n_retries = retries;
+  st.lanes = b->lanes;
+  st.ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  if (stats) *stats = st;
+  return PPF_OK;
+}
+
+ppf_status ppf_batch_device_block(ppf_batch* b, void** d_poses, int* n_records) {
+  if (!b || !d_poses) return fail(PPF_ERR_INVALID, "ppf_batch_device_block: bad argument");
+  *d_poses = b->d_out.p;
+  if (n_records) *n_records = b->last_records;
+  return PPF_OK;
+}
+
+ppf_status ppf_batch_copy_block(ppf_batch* b, void* d_dst, int n_records, void* stream) {
+  if (!b || !d_dst || n_records < 0 || n_records > b->last_records) return fail(PPF_ERR_INVALID, "ppf_batch_copy_block: bad argument");
+  if (n_records)
+    HIPCHK(hipMemcpyAsync(d_dst, b->d_out.p, (size_t)n_records * sizeof(ppf_pose), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return PPF_OK;
 }
 
 ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
@@ -1916,28 +2391,12 @@ ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const f
   for (int k = 0; k < n_models; k++)
     if (!models[k]) return fail(PPF_ERR_NOT_TRAINED, "ppf_match_batch: model %d is not trained", k);
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_batch: no HIP device (this engine has no CPU fallback)");
-  ppf_workspace ws;
-  DevBuf<float> d_scene;
-  for (int c = 0; c < n_scenes; c++) {
-    ppf_status s = check_match_args(models[0], scenes[c], ns[c], sstride, nullptr, 0, 6, params);
-    if (s != PPF_OK) return s;
-    HIPCHK(d_scene.reserve((size_t)ns[c] * sstride));
-    HIPCHK(hipMemcpy(d_scene.p, scenes[c], (size_t)ns[c] * sstride * sizeof(float), hipMemcpyHostToDevice));
-    s = prepare_scene(&ws, d_scene.p, ns[c], sstride, nullptr, 0, 6, params, nullptr); /* sampled once per crop */
-    if (s != PPF_OK) return s;
-    for (int k = 0; k < n_models; k++) {
-      s = match_prepared(models[k], &ws, params, nullptr);
-      if (s != PPF_OK) return s;
-      int n = 0;
-      ppf_pose* dst = out + ((size_t)c * n_models + k) * cap;
-      s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, nullptr, 0, &n, nullptr);
-      if (s != PPF_OK) return s;
-      const int take = std::min(n, cap); /* poses are sorted by votes: keep the best `cap` */
-      if (take) memcpy(dst, ws.final_poses.data(), (size_t)take * sizeof(ppf_pose));
-      n_out[(size_t)c * n_models + k] = take;
-    }
-  }
-  return PPF_OK;
+  ppf_batch* b = nullptr;
+  ppf_status s = ppf_batch_create(std::min(4, n_scenes), &b);
+  if (s != PPF_OK) return s;
+  s = ppf_batch_run(b, models, n_models, scenes, ns, sstride, n_scenes, 0, params, out, cap, n_out, nullptr);
+  (void)ppf_batch_destroy(b);
+  return s;
 }
 
 ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
@@ -1947,8 +2406,6 @@ ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sst
   ppf_status s = ppf_workspace_enable_timing(&ws, 1);
   if (s == PPF_OK) s = run_host(m, scene, ns, sstride, edge, ne, estride, params, &ws);
   if (s == PPF_OK) s = ppf_workspace_results(&ws, votes, raw_poses, cap, n_ref, nullptr, 0, nullptr, stats);
-  for (auto& e : ws.ev)
-    if (e) (void)hipEventDestroy(e);
   return s;
 }
 
@@ -1982,43 +2439,91 @@ ppf_status ppf_model_save(const ppf_model* m, const char* path) {
   return PPF_OK;
 }
 
-ppf_status ppf_model_load(const char* path, ppf_model** out) {
-  if (!path || !out) return fail(PPF_ERR_INVALID, "ppf_model_load: NULL");
-  *out = nullptr;
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_load: no HIP device");
+/* Everything read from the file is checked before it reaches a kernel: header fields against each other and against
+ * the file size, the CSR rows, the record rows (LDS byte offsets k_vote adds to) and alphas, the slot map's ranks.  A file
+ * that fails any check is PPF_ERR_IO; no exception leaves this function. */
+static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_only) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(PPF_ERR_IO, "ppf_model_load: cannot open %s", path);
+  struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+  auto bad = [&](const char* what) { return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file (%s)", path, what); };
+  if (fseek(f, 0, SEEK_END) != 0) return bad("seek");
+  const long fsize = ftell(f);
+  if (fsize < 0 || fseek(f, 0, SEEK_SET) != 0) return bad("seek");
   char magic[8];
   std::unique_ptr<ppf_model> owner(new ppf_model()); /* released on every early return */
   ppf_model* m = owner.get();
-  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, PPF_MAGIC, 8) == 0;
-  ok = ok && fread(&m->params, sizeof(m->params), 1, f) == 1;
-  ok = ok && fread(&m->info, sizeof(m->info), 1, f) == 1;
-  ok = ok && fread(&m->n_records, sizeof(m->n_records), 1, f) == 1;
-  ok = ok && m->info.n_ref >= 2 && m->info.n_ref < 65536 && m->info.slots >= 16 && (m->info.slots & (m->info.slots - 1)) == 0 &&
-       m->info.n_tiles >= 1 && m->info.n_entries < 0xFFFFFFFFull && m->n_records < 0xFFFFFFFFull;
-  std::vector<SlotWord> slotmap;
-  std::vector<uint32_t> boff, bslot;
-  std::vector<uint4> ent;
-  if (ok) {
-    const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->n_records;
-    m->sampled.resize((size_t)m->info.n_ref * 6);
-    slotmap.resize(words);
-    boff.resize((size_t)m->info.n_tiles * (nb + 1));
-    bslot.resize(nb);
-    ent.resize(ne);
-    ok = fread(m->sampled.data(), sizeof(float), m->sampled.size(), f) == m->sampled.size();
-    ok = ok && fread(slotmap.data(), sizeof(SlotWord), words, f) == words;
-    ok = ok && fread(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
-    ok = ok && fread(bslot.data(), sizeof(uint32_t), nb, f) == nb;
-    ok = ok && fread(ent.data(), sizeof(uint4), ne, f) == ne;
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, PPF_MAGIC, 8) != 0) return bad("magic");
+  if (fread(&m->params, sizeof(m->params), 1, f) != 1 || fread(&m->info, sizeof(m->info), 1, f) != 1 ||
+      fread(&m->n_records, sizeof(m->n_records), 1, f) != 1)
+    return bad("header");
+  const ppf_model_info& I = m->info;
+  const uint64_t N = (uint64_t)(I.n_ref > 0 ? I.n_ref : 0);
+  if (I.n_ref < 2 || N * N > 0x7FFFFFFFull) return bad("n_ref");
+  if (I.slots != next_pow2(std::max<uint32_t>((uint32_t)(N * N), 16u))) return bad("slots");
+  if (!(I.num_angles >= 1 && I.num_angles <= 4096) || !(I.angle_step > 0) || !(I.distance_step > 0) || !std::isfinite(I.diameter)) return bad("steps");
+  if (I.num_angles != (int)std::floor(2 * PPF_PI / I.angle_step)) return bad("num_angles");
+  const int A = I.num_angles, P = vote_pitch(A), GW = vote_guard(A);
+  if (I.n_tiles < 1 || I.tile_refs < 1 || (uint64_t)I.n_tiles * I.tile_refs < N || (uint64_t)(I.n_tiles - 1) * I.tile_refs >= N)
+    return bad("tiles");
+  if (I.tile_refs > max_tile_rows(A)) return bad("tile does not fit this build's LDS accumulator");
+  if (I.n_buckets > I.slots || (uint64_t)I.n_buckets > N * N) return bad("n_buckets");
+  if (I.n_entries > N * N + N) return bad("n_entries");
+  const uint64_t nb = I.n_buckets, ne = m->n_records, T = (uint64_t)I.n_tiles;
+  if (ne > I.n_entries / 2 + 32ull * T * nb + 64 || ne >= 0xFFFFFFFFull) return bad("n_records");
+  const uint64_t words = ((uint64_t)I.slots + 63) / 64;
+  const uint64_t expect = 8 + sizeof(m->params) + sizeof(m->info) + sizeof(m->n_records) + N * 6 * sizeof(float) +
+                          words * sizeof(SlotWord) + T * (nb + 1) * sizeof(uint32_t) + nb * sizeof(uint32_t) + ne * sizeof(uint4);
+  if ((uint64_t)fsize != expect) return bad("file size does not match its header");
+  std::vector<SlotWord> slotmap(words);
+  std::vector<uint32_t> boff(T * (nb + 1)), bslot(nb);
+  std::vector<uint4> ent(ne);
+  m->sampled.resize(N * 6);
+  bool ok = fread(m->sampled.data(), sizeof(float), m->sampled.size(), f) == m->sampled.size();
+  ok = ok && fread(slotmap.data(), sizeof(SlotWord), words, f) == words;
+  ok = ok && fread(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
+  ok = ok && (nb == 0 || fread(bslot.data(), sizeof(uint32_t), nb, f) == nb);
+  ok = ok && (ne == 0 || fread(ent.data(), sizeof(uint4), ne, f) == ne);
+  if (!ok) return bad("short read");
+  for (float v : m->sampled)
+    if (!std::isfinite(v)) return bad("sampled cloud");
+  { /* slot map: ranks are the running popcount, which ends at n_buckets */
+    uint64_t run = 0;
+    for (uint64_t w = 0; w < words; w++) {
+      if (slotmap[w].rank != run) return bad("slot map ranks");
+      run += (uint64_t)__builtin_popcount(slotmap[w].bits_lo) + (uint64_t)__builtin_popcount(slotmap[w].bits_hi);
+    }
+    if (run != nb) return bad("slot map population");
   }
-  fclose(f);
-  if (!ok) {
-    return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file", path);
+  for (uint64_t k = 0; k < nb; k++)
+    if (bslot[k] >= I.slots) return bad("bucket slots");
+  { /* per-tile CSR rows over the records: monotone, chained tile to tile, ending at n_records */
+    uint32_t prev = 0;
+    for (uint64_t t = 0; t < T; t++) {
+      const uint32_t* row = &boff[t * (nb + 1)];
+      if (row[0] != prev) return bad("bucket offsets (tile start)");
+      for (uint64_t k = 0; k < nb; k++)
+        if (row[k + 1] < row[k]) return bad("bucket offsets (order)");
+      prev = row[nb];
+    }
+    if (prev != ne) return bad("bucket offsets (total)");
   }
+  { /* records: LDS byte offsets inside guard + tile rows (a vote adds up to A*4 bytes), finite alphas within (-pi, pi) */
+    const uint32_t limit_words = (uint32_t)(GW + I.tile_refs * P);
+    for (uint64_t k = 0; k < ne; k++) {
+      const uint32_t rows[2] = {ent[k].x, ent[k].y}, al[2] = {ent[k].z, ent[k].w};
+      for (int sl = 0; sl < 2; sl++) {
+        if ((rows[sl] & 3u) || rows[sl] / 4 + (uint32_t)A + 1 > limit_words) return bad("record row");
+        float av;
+        memcpy(&av, &al[sl], 4);
+        if (!(std::fabs(av) <= 3.1416f)) return bad("record alpha");
+      }
+    }
+  }
+  if (check_only) return PPF_OK;
   m->refcount = 1;
-  ppf_status s = m->cloud.load_host(m->sampled.data(), m->info.n_ref, nullptr);
+  HIPCHK(hipGetDevice(&m->device));
+  ppf_status s = m->cloud.load_host(m->sampled.data(), I.n_ref, nullptr);
   auto up = [&](auto& dst, const auto& src) -> ppf_status {
     HIPCHK(dst.reserve(std::max<size_t>(src.size(), 1)));
     if (!src.empty()) HIPCHK(hipMemcpy(dst.p, src.data(), src.size() * sizeof(src[0]), hipMemcpyHostToDevice));
@@ -2029,22 +2534,44 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
   if (s == PPF_OK) s = up(m->bucket_slot, bslot);
   if (s == PPF_OK) s = up(m->records, ent);
   if (s == PPF_OK) {
-    hipError_t e = m->bucket_total.reserve(std::max<uint32_t>(m->info.n_buckets, 1));
+    hipError_t e = m->bucket_total.reserve(std::max<uint32_t>(I.n_buckets, 1));
     if (e != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: %s", hipGetErrorString(e));
-    else if (m->info.n_buckets) {
-      k_bucket_total<<<dim3((m->info.n_buckets + 255) / 256), dim3(256)>>>(m->bucket_off.p, (int)m->info.n_buckets, m->info.n_tiles, m->bucket_total.p);
+    else if (I.n_buckets) {
+      k_bucket_total<<<dim3((I.n_buckets + 255) / 256), dim3(256)>>>(m->bucket_off.p, (int)I.n_buckets, I.n_tiles, m->bucket_total.p);
       if (hipDeviceSynchronize() != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: bucket totals failed");
     }
   }
   if (s == PPF_OK) s = build_key_lut(m, nullptr); /* not stored in the file: rebuilt from the slot map */
-  if (s != PPF_OK) {
-    return s;
-  }
+  if (s != PPF_OK) return s;
   m->info.device_bytes = m->cloud.buf.bytes() + m->slotmap.bytes() + m->bucket_off.bytes() + m->bucket_slot.bytes() +
-                         m->records.bytes() + m->records_fx.bytes() + m->key_lut.bytes();
-  HIPCHK(hipGetDevice(&m->device));
+                         m->records.bytes() + m->key_lut.bytes();
   *out = owner.release();
   return PPF_OK;
+}
+
+ppf_status ppf_model_load(const char* path, ppf_model** out) {
+  if (!path || !out) return fail(PPF_ERR_INVALID, "ppf_model_load: NULL");
+  *out = nullptr;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_load: no HIP device");
+  try {
+    return model_load_impl(path, out, false);
+  } catch (const std::bad_alloc&) {
+    return fail(PPF_ERR_NOMEM, "ppf_model_load: out of host memory reading %s", path);
+  } catch (...) {
+    return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file", path);
+  }
+}
+
+ppf_status ppf_model_check_file(const char* path) {
+  if (!path) return fail(PPF_ERR_INVALID, "ppf_model_check_file: NULL");
+  ppf_model* none = nullptr;
+  try {
+    return model_load_impl(path, &none, true);
+  } catch (const std::bad_alloc&) {
+    return fail(PPF_ERR_NOMEM, "ppf_model_check_file: out of host memory reading %s", path);
+  } catch (...) {
+    return fail(PPF_ERR_IO, "ppf_model_check_file: %s is not a valid model file", path);
+  }
 }
 
 }  // extern "C"

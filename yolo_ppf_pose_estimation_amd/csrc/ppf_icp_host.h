@@ -47,7 +47,7 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
   const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
   auto grid = [](size_t items, int block) { return dim3((unsigned)((items + block - 1) / block)); };
   const int robust = prm.rejection_scale > 0 ? 1 : 0;
-  const int icp_batch = getenv("PPF_ICP_BATCH") ? std::max(1, atoi(getenv("PPF_ICP_BATCH"))) : ICP_BATCH;
+  const int icp_batch = ICP_BATCH;
   for (size_t j = 0; j < jobs.size(); j++) {
     IcpJob& J = *jobs[j];
     IcpScratch& sc = J.sc;
@@ -124,7 +124,7 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
     });
     HIPCHK(attr_thr);
     const int staged = ns <= 32768 ? 1 : 0; /* the level's distances fit LDS (4 bytes each): the selection passes read them there */
-    const bool small = ns <= ICP_SMALL_NS && !getenv("PPF_ICP_NO_SMALL"); /* the whole level in one workgroup, one launch */
+    const bool small = ns <= ICP_SMALL_NS && !(prm.flags & PPF_ICP_NO_SMALL_LEVELS); /* the whole level in one workgroup, one launch */
     for (bool any = true; any;) {
       for (auto& jp : jobs) {
         IcpJob& J = *jp;
@@ -205,7 +205,7 @@ IcpPool& g_icp_pool = *new IcpPool();
  * caller's stream) nothing is allocated after the first call: streams, scratch and pinned mirrors are reused.  Pool
  * streams are ordered after whatever the caller's stream has enqueued so far. */
 ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<IcpJob*>& jobs, std::vector<std::unique_ptr<IcpJob>>& owned,
-                         std::unique_lock<std::mutex>& pool_lock) {
+                         std::unique_lock<std::mutex>& pool_lock, bool one_stream = false) {
   jobs.clear();
   owned.clear();
   bool pooled = false;
@@ -226,7 +226,7 @@ ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<IcpJob*>& jobs
     }
     pooled = true;
   }
-  const bool own_streams = pooled && count > 1 && !getenv("PPF_ICP_ONE_STREAM");
+  const bool own_streams = pooled && count > 1 && !one_stream;
   hipEvent_t ready = nullptr;
   if (own_streams) {
     HIPCHK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
@@ -278,7 +278,7 @@ ppf_status icp_refine_device(const float* d_model, int n, int mstride, const flo
     std::vector<IcpJob*> jobs;
     std::vector<std::unique_ptr<IcpJob>> owned;
     std::unique_lock<std::mutex> pool_lock;
-    ppf_status s = icp_make_jobs(cnt, st, jobs, owned, pool_lock);
+    ppf_status s = icp_make_jobs(cnt, st, jobs, owned, pool_lock, (prm->flags & PPF_ICP_ONE_STREAM) != 0);
     if (s != PPF_OK) return s;
     const double* init[ICP_MAX_JOBS];
     double inc[ICP_MAX_JOBS * 16], res[ICP_MAX_JOBS];

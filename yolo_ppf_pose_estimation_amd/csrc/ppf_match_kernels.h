@@ -3,37 +3,50 @@
  * ppf_hip.hip.  Reference call sites: /root/reference/include/CloudProcessing.h:442 (match), :495
  * (match_S2B).
  *
- * Four kernels per batch of scene reference points:
+ * Per batch of scene reference points:
  *
  *   k_frames   one thread per reference point: the rotation/translation (Rsg, tsg) that takes the
  *              reference point to the origin with its normal on +x (fp64, 12 doubles per point).
  *
- *   k_pairs    one thread per scene pair (s_r, s_i): pair feature (fp64, deterministic math) ->
- *              4 x int32 key -> MurmurHash3 -> slot -> dense bucket id through the slot map (one
- *              16-byte load).  Only ~1-2 % of the pairs of a real crop land in a non-empty slot;
- *              for those the lane also computes alpha_s and the wave appends a 16-byte hit record
- *              {bucket, alpha_s} to the reference point's hit list (ballot + one atomic per wave).
- *              VALU(fp64)-bound; reads 24 B per pair from the L2-resident scene SoA.
+ *   k_pairs    one thread per scene pair (s_r, s_i): pair feature -> 4 x int32 key -> dense bucket id
+ *              (key table, MurmurHash3 for keys outside it).  About 15 % of the pairs of a crop land in a
+ *              non-empty slot; a workgroup (2,048 pairs of one reference point) appends its hits
+ *              {bucket, j} to a striped pool with ONE atomic, so the pool holds exactly the hits that
+ *              exist (capacity is an estimate; running out raises a flag and the host repeats the call
+ *              with a bigger pool).  VALU(fp64)-bound.
  *
- *   k_group    one workgroup per reference point: stable LSD radix sort (8-bit digits, in L2-resident
- *              global memory) of the point's hit list by bucket id.  On a real crop many pairs of one
- *              reference point fall into the same few heavy buckets (measured: votes / distinct
- *              bucket entries = 31), so grouping them lets k_vote read a bucket once for all of them.
+ *   k_group    one workgroup per reference point: alpha_s of every hit, counting sort of the hits by
+ *              bucket (one LDS counter per bucket), the run table {bucket, first hit, m hits} (runs with
+ *              many hits first) and the per-hit payload in sorted order: (float)alpha_s, alpha_s, and the
+ *              hit's cell (Y, p) in units of alpha bins (see "aggregated votes").
  *
- *   k_vote     one workgroup per (reference point, accumulator tile).  The tile's Hough accumulator
- *              lives in LDS.  Sorted hits form runs (one bucket, m hits with different alpha_s); a run
- *              is cut into work items of <= VOTE_CHUNK table entries x <= VOTE_MAX_HITS hits.  A wave
- *              loads a batch of 64 x VOTE_UNROLL entries (coalesced 8-byte loads, next batch
- *              prefetched into a second register set) and votes it once per hit of the item straight
- *              from registers: HBM/L2 traffic per vote drops from 8 B to 8/m B and the kernel is bound
- *              by the LDS atomic rate (one ds_add_u32 per vote, bank and same-cell conflicts included;
- *              measured: halving the VALU work per vote does not change its time).
+ *   k_vote     one workgroup per (reference point, accumulator tile); the tile's Hough accumulator
+ *              lives in LDS.  A run (one bucket, m hits) meets the bucket's entries in one of two ways:
+ *                direct      every entry votes once per hit: 1 fma + cvt + fract + address + ds_add_u32
+ *                            per vote, entries held in registers while the hits go by;
+ *                aggregated  (m >= PPF_AGG_MIN_HITS) the hits of the run are first histogrammed by cell,
+ *                            then every entry adds COUNTS: 17 ds_add_u32 per entry and <= 191 hits
+ *                            instead of one per hit (see below).
+ *              Work items (run x chunk of entries x group of hits) are claimed by waves from an LDS
+ *              counter.
  *
  * Alpha bin, exactly: bin = (int)(A*(alpha_m - alpha_s + 2pi)/(4pi)) in fp64 is what the reference
- * computes.  The fast path evaluates q = (alpha_m - alpha_s)*A/(4pi) + A/2 in fp32 (|error| <= 9e-8*A,
- * folded as alpha_m*S + (A/2 - alpha_s*S): |error| <= 1.1e-7*A) and takes trunc(q)
- * whenever q is farther than G = 5e-7*A from an integer; otherwise
- * (about 3e-5 of the votes) the lane re-evaluates the fp64 chain.  Both paths give the same integer.
+ * computes.  The direct path evaluates q = (alpha_m - alpha_s)*A/(4pi) + A/2 in fp32 (|error| <= 1.1e-7*A,
+ * DESIGN.md section 4) and takes trunc(q) whenever q is farther than G = 5e-7*A from an integer; otherwise
+ * (about 3e-5 of the votes) the lane re-evaluates the fp64 chain.  Both give the same integer.
+ *
+ * Aggregated votes.  With x = alpha_m*A/(4pi) + A/2 = X + phi and y = alpha_s*A/(4pi) = Y + psi
+ * (X, Y integers, 0 <= phi, psi < 1) the bin is floor(x - y) = X - Y - [phi < psi].  The fraction is cut
+ * into Q = 32 cells: an entry in cell q = floor(32 phi) and a hit in cell p = floor(32 psi) with p != q
+ * are ordered by their cells alone, so for one entry all hits of a run with p < q and the same Y land
+ * in bin X - Y, those with p > q in bin X - Y - 1: a table T[q][j] (j = Y + 8 = 0..16, built per run
+ * from the hits' cell histogram) holds the COUNT that bin X + 8 - j receives, and the entry casts 17
+ * counted atomics whatever m is.  Hits in the entry's own cell (1/32 of them) are voted one by one
+ * with the direct arithmetic.  Exactness: the table is only used for pairs separated by a cell boundary
+ * from which the entry is provably away (fp32 cell index with a guard band, fp64 when inside the band,
+ * one-by-one votes when fp64 is still within 1e-7 of a boundary), where the fp64 chain's rounding
+ * (1.5e-14 bins) cannot change floor().  alpha_m < -pi (only (float)-pi) could make x - y negative, where
+ * the reference truncates towards zero: such entries vote one by one.  Needs Y in [-8, 7]: A <= 31.
  */
 #ifndef PPF_MATCH_KERNELS_H
 #define PPF_MATCH_KERNELS_H
@@ -41,8 +54,14 @@
 #ifndef PPF_GUARD_REL
 #define PPF_GUARD_REL 5e-7f /* alpha-bin guard band relative to A; the fp32 error bound is 1.1e-7 */
 #endif
-#ifndef PPF_ABL
-#define PPF_ABL 0 /* diagnostic ablations of k_vote; 0 in every shipped build */
+#ifndef PPF_AGG_MIN_HITS
+#define PPF_AGG_MIN_HITS 24 /* runs with at least this many hits vote through the count table */
+#endif
+#ifndef PPF_AGG_MIN_RECORDS
+#define PPF_AGG_MIN_RECORDS 32 /* ... when the (tile, bucket) holds at least this many pair records */
+#endif
+#ifndef PPF_PIPE_VALU
+#define PPF_PIPE_VALU 4 /* VALU instructions scheduled between two LDS atomics of the pipelined direct loop */
 #endif
 
 constexpr int PAIR_BLOCK = 256;
@@ -50,37 +69,36 @@ constexpr int PAIRS_PER_THREAD = 8;   /* one k_pairs workgroup covers 2048 paire
 constexpr int VOTE_BLOCK = 1024;
 constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
 constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded per lane per batch */
-#ifndef PPF_VOTE_CHUNK_BATCHES
-#define PPF_VOTE_CHUNK_BATCHES 4
-#endif
-#ifndef PPF_VOTE_MAX_HITS
-#define PPF_VOTE_MAX_HITS 16
-#endif
-#ifndef PPF_VOTE_DYNAMIC
-#define PPF_VOTE_DYNAMIC 1
-#endif
-#ifndef PPF_PIPE_VALU
-#define PPF_PIPE_VALU 4 /* VALU instructions scheduled between two LDS atomics of the pipelined vote loop */
-#endif
-#ifndef PPF_VOTE_FIXED
-#define PPF_VOTE_FIXED 0 /* 1: 16.16 fixed-point alpha bins, 2.5-2.75 VALU per vote instead of 4.9 (vote_hits_fx).  Bit-exact (same
-                          parity tests), but NOT faster on gfx950 today: with the VALU work halved the kernel sits on its LDS-atomic
-                          bound (13.8 ms either way; 11.7 ms with conflict-free addresses), so the plain fp32 path stays the default */
-#endif
-#ifndef PPF_VOTE_PIPE
-#define PPF_VOTE_PIPE 1 /* atomics of hit h issued under the arithmetic of hit h+1 (vote_hits) */
-#endif
-constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * PPF_VOTE_CHUNK_BATCHES; /* pair records per work item (1024 = 2048 entries) */
-constexpr int VOTE_MAX_HITS = PPF_VOTE_MAX_HITS; /* hits of one bucket run voted per work item */
+constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * 4; /* pair records per direct work item (1024 = 2048 entries) */
+constexpr int VOTE_MAX_HITS = 16;     /* hits of one run voted per direct work item */
+constexpr int AGG_CHUNK = 2048;       /* pair records per aggregated work item */
+constexpr int AGG_Q = 32;             /* cells per alpha bin */
+constexpr int AGG_NY = 16;            /* integer parts Y + 8 of a hit */
+constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes; 3 hits per lane) */
+constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in [-8, 7] */
+constexpr int RUN_SEG = 256;          /* runs staged in LDS per segment */
 constexpr int GROUP_BLOCK = 1024;
-constexpr int VOTE_SEG = VOTE_BLOCK;  /* hits staged in LDS per segment: one per thread */
-constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + run-start masks (16 x u64) */
+constexpr int GROUP_MAX_BUCKETS = 36000; /* LDS counters of k_group per round (144 KB) */
+constexpr int POOL_STRIPES = 64;      /* the raw hit pool is cut into stripes with one cursor each */
+constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + claim counter */
 
-struct HitRec {
-  uint32_t bucket;   /* dense bucket id */
-  uint32_t alpha32;  /* k_pairs: index j of the paired point; after k_group: (float)alpha_s bits for the fp32 vote path */
-  double alpha_s;    /* exact alpha_s (k_group) */
-};
+/* cursor words (each on its own 128-byte line): stripe s at s*32, then sorted hits, runs, overflow flag */
+constexpr int CUR_STRIDE = 32;
+constexpr int CUR_SORTED = POOL_STRIPES * CUR_STRIDE;
+constexpr int CUR_RUNS = CUR_SORTED + CUR_STRIDE;
+constexpr int CUR_OVERFLOW = CUR_RUNS + CUR_STRIDE;
+constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
+
+/* per-wave LDS scratch of the aggregated path */
+constexpr int AGG_ROW = 28;                           /* bytes per table row: 17 counts + padding; 7 words: rows q and q' never share a bank */
+constexpr int AGG_OFF_CE = 928;                       /* 33 rows end at 924 (row AGG_Q is all zero: entries that vote one by one) */
+constexpr int AGG_OFF_A32 = 1072;                     /* cell ends / starts: 33 u32 from 928 */
+constexpr int AGG_OFF_IDX = AGG_OFF_A32 + 768;        /* folded offsets Ohg of the hits in cell order: AGG_SUB x 4 B (first: 512 B of byte counters) */
+constexpr int AGG_SCRATCH = AGG_OFF_IDX + 192;        /* position of each sorted hit inside the table's hit range: AGG_SUB x 1 B */
+static_assert((AGG_Q + 1) * AGG_ROW <= AGG_OFF_CE, "table rows overlap the cell table");
+static_assert(AGG_OFF_CE + (AGG_Q + 1) * 4 <= AGG_OFF_A32, "cell table overlaps");
+static_assert(AGG_SUB * 4 <= 768 && AGG_SUB <= 192 && AGG_NY * AGG_Q <= 768 && AGG_SUB < 256, "aggregation scratch too small");
+static_assert(AGG_SCRATCH % 16 == 0, "wave scratch must keep 16-byte alignment");
 
 /* fp32 acos for BIN SELECTION only: acos(|x|) = sqrt(1-|x|) * P(|x|), degree-7 least-squares/minimax fit,
  * measured max error 3.4e-7 rad including fp32 evaluation (tests/test_gpu_fastkeys.py re-checks the keys
@@ -143,13 +161,6 @@ __device__ __forceinline__ void pair_key(const ppf_vec3& p1, const ppf_vec3& n1,
     k[3] = ppf_d2i(f[3] / dist_step);
   }
 }
-__device__ __forceinline__ uint32_t pair_slot_hash(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2,
-                                                   const ppf_vec3& n2, const double angle_step, const double dist_step,
-                                                   const FastKeyConsts& fk) {
-  int32_t k[4];
-  pair_key(p1, n1, p2, n2, angle_step, dist_step, fk, k);
-  return ppf_murmur_key16(k[0], k[1], k[2], k[3]);
-}
 
 struct MatchArgs {
   CloudSoA surf;   /* reference points come from here */
@@ -167,29 +178,38 @@ struct MatchArgs {
   const uint32_t* bucket_off;
   int n_buckets;
   const uint4* records;    /* pair records {row_a, row_b, alpha_a, alpha_b}; bucket_off counts records */
-  const uint4* records_fx; /* the same records with alpha_m as signed 16.16 fixed point of alpha_m*A/(4pi): what k_vote adds */
   int n_tiles, tile_refs, num_angles, n_model;
   double angle_step, dist_step;
   /* per-batch scratch */
   double* frames;          /* [n_ref][12] */
-  HitRec* hits;            /* [n_ref][hit_cap] */
-  uint32_t* hit_count;     /* [n_ref] */
-  uint2* keys_a;           /* [n_ref][hit_cap] {bucket, hit index}: sorted by bucket after k_group */
-  uint2* keys_b;           /* [n_ref][hit_cap] ping-pong */
-  const uint2* keys_sorted; /* where k_group leaves the grouped keys: keys_b on the LDS path, keys_a on the radix path */
-  int hit_cap;
-  int key_bits;            /* bits of a bucket id */
-  int group_lds_buckets;   /* n_buckets when one LDS counter per bucket fits (single-pass grouping), else 0 */
+  uint2* raw;              /* hit pool {bucket, j}: POOL_STRIPES stripes of stripe_cap */
+  uint32_t stripe_cap;
+  int stripe_bits;         /* log2 of the stripes in use (<= POOL_STRIPES): few workgroups share few stripes, so that every
+                              stripe averages over hundreds of them */
+  uint32_t* cursors;       /* CUR_WORDS */
+  uint2* chunk_desc;       /* [n_ref][pair_chunks] {first raw hit, count} of each k_pairs workgroup */
+  int pair_chunks;
+  unsigned long long* hit_count; /* [n_ref] raw hits (also the k_rank key of k_group's launch order) */
+  double* s_a64;           /* sorted payload: alpha_s */
+  uint16_t* s_cell;        /*                 (Y + 8) * AGG_Q + p */
+  uint32_t sorted_cap;
+  uint4* runs;             /* {bucket, first sorted hit, m, 0} */
+  uint32_t run_cap;
+  uint2* run_blocks;       /* [n_ref][n_rounds] {first run, runs} */
+  int n_rounds, round_buckets; /* k_group sorts round_buckets bucket ids per pass over the reference point's hits */
   const uint32_t* bucket_total; /* [n_buckets] entries of a bucket over all tiles */
   unsigned long long* work;     /* [n_ref] votes the reference point will cast (sum of its hits' bucket sizes) */
   uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
-  const uint32_t* perm_group;   /* [n_ref] reference points ordered by hit count, for k_group (may be NULL) */
+  const uint32_t* perm_group;   /* [n_ref] reference points ordered by hit count, for k_group */
+  int agg_min_hits;             /* 0: every run votes directly */
+  int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
+  int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
   uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
+  unsigned long long* tally;    /* [2] LDS atomic lane-operations issued by k_vote, hits grouped by k_group */
   uint32_t* acc_dump;           /* optional [n_ref_all][n_model*num_angles] full accumulators (debug/tests) */
-  int ablate;                   /* PPF_ABLATE env (diagnostic builds only): 1 conflict-free atomics, 2 no atomics, 3 no entry loads */
 };
 
 __device__ __forceinline__ int ref_row(const MatchArgs& a, int r_local) {
@@ -209,11 +229,19 @@ __global__ __launch_bounds__(64) void k_frames(MatchArgs a) {
   for (int k = 0; k < 3; k++) f[9 + k] = t[k];
 }
 
+/* stripe of the raw pool a k_pairs workgroup appends to: a multiplicative hash of its linear index, so that no stripe
+ * collects a systematic share of the (shorter) last chunks of the paired cloud */
+__device__ __forceinline__ uint32_t pool_stripe(const uint32_t wg, const int stripe_bits) {
+  return stripe_bits ? (wg * 2654435761u) >> (32 - stripe_bits) : 0u;
+}
+
 /* grid: x = chunks of PAIR_BLOCK*PAIRS_PER_THREAD paired points, y = reference point of the batch */
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   __shared__ uint2 stash[PAIRS_PER_THREAD][PAIR_BLOCK]; /* {bucket, j} of this thread's hits, one slot per iteration */
+  __shared__ uint32_t wtot[PAIR_BLOCK / 64];
+  __shared__ uint32_t wg_base;
   const int r = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i_ref = ref_row(a, r);
   const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
   FastKeyConsts fk;
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
           b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
         }
         /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
-         * computed later (k_group), only for the ~6 % of pairs that found a bucket. */
+         * computed later (k_group), only for the pairs that found a bucket. */
         my_pairs += 1u;
         if (b >= 0) {
           stash[it][tid] = make_uint2((uint32_t)b, (uint32_t)j);
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
       }
     }
   }
-  /* one returned atomic per wave: wave-wide exclusive scan of the per-lane hit counts */
+  /* one returned atomic per WORKGROUP: exclusive scan of the per-lane hit counts over the wave, wave totals in LDS */
   const uint32_t mine = (uint32_t)__popc(hit_mask);
   uint32_t incl = mine;
 #pragma unroll
@@ -274,24 +302,40 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
     const uint32_t y = __shfl_up(incl, o);
     if (lane >= o) incl += y;
   }
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  if (total) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&a.hit_count[r], total);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    uint32_t pos = base + incl - mine;
-    HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
-    uint2* __restrict__ keys = a.keys_a + (size_t)r * a.hit_cap;
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < PAIR_BLOCK / 64; k++) {
+    const uint32_t w = wtot[k];
+    if (k < wave) woff += w;
+    total += w;
+  }
+  if (a.count_only) { /* cold workspace: only the number of hits is wanted (one 64-bit counter per stripe) */
+    if (tid == 0 && total) {
+      const uint32_t stripe = pool_stripe(blockIdx.y * gridDim.x + blockIdx.x, a.stripe_bits);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&a.cursors[stripe * CUR_STRIDE]), (unsigned long long)total);
+    }
+    return;
+  }
+  if (tid == 0) {
+    uint32_t base = 0xFFFFFFFFu;
+    if (total) {
+      const uint32_t stripe = pool_stripe(blockIdx.y * gridDim.x + blockIdx.x, a.stripe_bits);
+      const uint32_t b = atomicAdd(&a.cursors[stripe * CUR_STRIDE], total);
+      if (b <= a.stripe_cap && total <= a.stripe_cap - b) base = stripe * a.stripe_cap + b;
+      else atomicOr(&a.cursors[CUR_OVERFLOW], 1u); /* pool estimate too small: the host repeats the call */
+    }
+    wg_base = base;
+    a.chunk_desc[(size_t)r * a.pair_chunks + blockIdx.x] = base == 0xFFFFFFFFu ? make_uint2(0u, 0u) : make_uint2(base, total);
+  }
+  __syncthreads();
+  const uint32_t base = wg_base;
+  if (base != 0xFFFFFFFFu) {
+    uint32_t pos = base + woff + incl - mine;
 #pragma unroll 1
     for (int it = 0; it < PAIRS_PER_THREAD; it++) {
-      if (hit_mask & (1u << it)) {
-        const uint2 h = stash[it][tid];
-        HitRec rec;
-        rec.bucket = h.x; rec.alpha32 = h.y; rec.alpha_s = 0.0;
-        hits[pos] = rec;
-        keys[pos] = make_uint2(h.x, pos);
-        pos++;
-      }
+      if (hit_mask & (1u << it)) a.raw[pos++] = stash[it][tid];
     }
   }
 #pragma unroll
@@ -299,158 +343,181 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   if (lane == 0 && my_pairs) atomicAdd(&a.pairs[a.ref_base + r], my_pairs);
 }
 
+/* raw hits per reference point = sum of its workgroups' counts */
+__global__ __launch_bounds__(256) void k_ref_hits(MatchArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n_ref) return;
+  unsigned long long s = 0;
+  for (int c = 0; c < a.pair_chunks; c++) s += a.chunk_desc[(size_t)r * a.pair_chunks + c].y;
+  a.hit_count[r] = s;
+}
+
+/* cell of a hit: y = alpha_s * A/(4 pi) = Y + psi; cell = (Y + 8) * AGG_Q + floor(AGG_Q * psi) */
+__device__ __forceinline__ uint32_t hit_cell(const double alpha_s, const double s64) {
+  const double y = alpha_s * s64;
+  const double Y = __builtin_floor(y);
+  int p = (int)((y - Y) * (double)AGG_Q);
+  p = min(max(p, 0), AGG_Q - 1);
+  const int yy = min(max((int)Y + 8, 0), AGG_NY - 1);
+  return (uint32_t)(yy * AGG_Q + p);
+}
+
 /*
- * k_group: stable LSD radix sort of one reference point's {bucket, hit index} keys by bucket id.
- * Elements are taken 1024 at a time in list order; inside a tile, wave w owns elements 64w..64w+63,
- * so (wave, lane) order is list order.  Rank of an element among equal digits = digits before it in
- * earlier tiles (running base) + in earlier waves of the tile (wave counts) + in lower lanes of its
- * wave (ballot match).  The result always ends in keys_a.
+ * k_group: one workgroup per reference point.  Per round (round_buckets bucket ids; one round unless the table
+ * has more buckets than LDS counters): count the hits per bucket (alpha_s is evaluated here: a NaN alpha makes the
+ * reference skip the pair, the hit is retired), scan, write the run table -- runs that will vote through the count
+ * table first, so the long work items of k_vote are claimed early --, then scatter the payload of every hit to its
+ * sorted position through the counters (any order inside a bucket: votes commute).
+ * The reference point's raw hits sit in pair_chunks pieces of the pool; the passes walk them as ONE list (thread t
+ * takes hits t, t + 1024, ...) and the alpha_s of the first group_cache hits stays in LDS between the two passes.
+ * Dynamic LDS: [round_buckets counters][pair_chunks + 1 prefix][group_cache doubles].
  */
 __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
-  __shared__ uint32_t base[256];
+  extern __shared__ __align__(8) uint32_t gcnt[]; /* round_buckets counters, then cursors */
   __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
-  extern __shared__ uint32_t gcnt[]; /* LDS path: one counter per bucket (+ wave totals); radix path: wcnt[16][256] */
+  __shared__ uint32_t wtot[3][GROUP_BLOCK / 64];
+  __shared__ uint32_t sh[4];
   const int r = a.perm_group ? (int)a.perm_group[blockIdx.x] : (int)blockIdx.x; /* most hits first: no long block at the tail */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t n = a.hit_count[r];
-  const bool lds_path = a.group_lds_buckets > 0;
-  const int nb1 = a.group_lds_buckets + 1;
-  if (lds_path) {
-    for (int k = tid; k < nb1; k += GROUP_BLOCK) gcnt[k] = 0;
-    __syncthreads();
+  uint32_t* cpre = gcnt + a.round_buckets;                                  /* pair_chunks + 1 */
+  double* acache = reinterpret_cast<double*>(cpre + ((a.pair_chunks + 2) & ~1)); /* group_cache */
+  const uint32_t n_raw = (uint32_t)a.hit_count[r];
+  const uint2* __restrict__ desc = a.chunk_desc + (size_t)r * a.pair_chunks;
+  if (tid == 0) {
+    uint32_t base = 0, ok = 1;
+    if (n_raw) {
+      base = atomicAdd(&a.cursors[CUR_SORTED], n_raw);
+      if (!(base <= a.sorted_cap && n_raw <= a.sorted_cap - base)) { ok = 0; atomicOr(&a.cursors[CUR_OVERFLOW], 2u); }
+    }
+    sh[0] = base; sh[1] = ok;
+    uint32_t run = 0;
+    for (int c = 0; c < a.pair_chunks; c++) { cpre[c] = run; run += desc[c].y; }
+    cpre[a.pair_chunks] = run;
   }
-  {
-    /* ONE pass over the hits: alpha_s of every hit (dense: only pairs that found a bucket) = angle of
-     * (tsg + Rsg p2) about x; the exact number of votes this reference point will cast (used to launch the heaviest
-     * first); and, on the LDS path, the per-bucket histogram.  A NaN alpha (non-finite cloud) makes the reference
-     * skip the pair: the hit is retired by emptying its key. */
-    const double* __restrict__ fr = a.frames + (size_t)r * 12;
-    const double R10 = fr[3], R11 = fr[4], R12 = fr[5], R20 = fr[6], R21 = fr[7], R22 = fr[8], ty = fr[10], tz = fr[11];
-    HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
-    uint2* kk = a.keys_a + (size_t)r * a.hit_cap;
-    unsigned long long w = 0;
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) {
-      const int j = (int)hits[i].alpha32;
-      uint32_t key = kk[i].x;
-      const uint32_t total = a.bucket_total[min(key, (uint32_t)(a.n_buckets - 1))]; /* independent gather, issued with the others */
-      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j);
-      const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
-      const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
-      double as = 0.0;
-      if (ppf_alpha_in_frame(qy, qz, &as)) {
-        hits[i].alpha32 = __float_as_uint((float)as);
-        hits[i].alpha_s = as;
-        w += total;
-      } else {
-        hits[i].alpha32 = 0; hits[i].alpha_s = 0.0;
-        key = 0xFFFFFFFFu;
-        kk[i].x = key; /* sorts last; k_vote gives it no entries */
+  __syncthreads();
+  const uint32_t hit_base = sh[0];
+  const bool ok = sh[1] != 0;
+  const double* __restrict__ fr = a.frames + (size_t)r * 12;
+  const double R10 = fr[3], R11 = fr[4], R12 = fr[5], R20 = fr[6], R21 = fr[7], R22 = fr[8], ty = fr[10], tz = fr[11];
+  const double s64 = (double)a.num_angles / (4 * PPF_PI);
+  const uint32_t agg_min = a.agg_min_hits > 0 ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
+  const uint32_t n_list = ok ? n_raw : 0u;
+  const uint32_t n_cache = (uint32_t)a.group_cache;
+  unsigned long long w = 0;
+  uint32_t placed = 0;
+  for (int round = 0; round < a.n_rounds; round++) {
+    const uint32_t b0 = (uint32_t)round * (uint32_t)a.round_buckets;
+    const uint32_t nb = min((uint32_t)a.round_buckets, (uint32_t)a.n_buckets - b0);
+    for (uint32_t k = tid; k < nb; k += GROUP_BLOCK) gcnt[k] = 0;
+    __syncthreads();
+    {
+      int c = 0;
+      for (uint32_t g = tid; g < n_list; g += GROUP_BLOCK) {
+        while (g >= cpre[c + 1]) c++;
+        const uint32_t at = desc[c].x + (g - cpre[c]);
+        const uint2 key = a.raw[at];
+        const uint32_t bl = key.x - b0;
+        if (bl < nb) {
+          const uint32_t total = a.bucket_total[key.x]; /* independent gather, issued with the others */
+          const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key.y);
+          const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
+          const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
+          double as = 0.0;
+          if (ppf_alpha_in_frame(qy, qz, &as)) {
+            atomicAdd(&gcnt[bl], 1u);
+            w += total;
+            if (g < n_cache) acache[g] = as;
+          } else {
+            a.raw[at].x = 0xFFFFFFFFu; /* retired: matches no round */
+          }
+        }
       }
-      if (lds_path) atomicAdd(&gcnt[min(key, (uint32_t)(nb1 - 1))], 1u);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
-    if (lane == 0) wsum[wave] = w;
     __syncthreads();
-    if (tid == 0) {
-      unsigned long long t = 0;
-      for (int k = 0; k < GROUP_BLOCK / 64; k++) t += wsum[k];
-      a.work[r] = t;
+    /* each thread owns a contiguous slice of the counters: hits, count-table runs, direct runs in it */
+    const uint32_t per = (nb + GROUP_BLOCK - 1) / GROUP_BLOCK;
+    const uint32_t k0 = min((uint32_t)tid * per, nb), k1 = min(k0 + per, nb);
+    uint32_t th = 0, tH = 0, tL = 0;
+    for (uint32_t k = k0; k < k1; k++) {
+      const uint32_t c = gcnt[k];
+      th += c;
+      if (c) { if (c >= agg_min) tH++; else tL++; }
     }
-  }
-  uint2* src = a.keys_a + (size_t)r * a.hit_cap;
-  uint2* dst = a.keys_b + (size_t)r * a.hit_cap;
-  if (n < 2 && !lds_path) return;
-  if (lds_path) {
-    /* Grouping only needs equal buckets to be adjacent (any order inside a bucket: votes commute), so when one
-     * counter per bucket fits in LDS the histogram of the pass above, a scan and one scatter through cursors do it.
-     * Retired hits (key 0xFFFFFFFF) go to the extra last counter.  The grouped keys stay in keys_b (k_vote reads
-     * a.keys_sorted). */
-    uint32_t* wtot = gcnt + nb1;
-    /* exclusive scan of nb1 counters: each thread owns a contiguous slice */
-    const int per = (nb1 + GROUP_BLOCK - 1) / GROUP_BLOCK;
-    const int k0 = tid * per, k1 = min(k0 + per, nb1);
-    uint32_t tsum = 0;
-    for (int k = k0; k < k1; k++) tsum += gcnt[k];
-    uint32_t incl = tsum;
+    uint32_t ih = th, iH = tH, iL = tL;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y = __shfl_up(incl, o);
-      if (lane >= o) incl += y;
+      const uint32_t y0 = __shfl_up(ih, o), y1 = __shfl_up(iH, o), y2 = __shfl_up(iL, o);
+      if (lane >= o) { ih += y0; iH += y1; iL += y2; }
     }
-    if (lane == 63) wtot[wave] = incl;
+    if (lane == 63) { wtot[0][wave] = ih; wtot[1][wave] = iH; wtot[2][wave] = iL; }
     __syncthreads();
-    uint32_t run = incl - tsum;
-    for (int w = 0; w < wave; w++) run += wtot[w];
-    for (int k = k0; k < k1; k++) { const uint32_t c = gcnt[k]; gcnt[k] = run; run += c; }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) {
-      const uint2 key = src[i];
-      dst[atomicAdd(&gcnt[min(key.x, (uint32_t)(nb1 - 1))], 1u)] = key;
+    uint32_t oh = ih - th, oH = iH - tH, oL = iL - tL, nh = 0, nH = 0, nL = 0;
+#pragma unroll
+    for (int k = 0; k < GROUP_BLOCK / 64; k++) {
+      const uint32_t v0 = wtot[0][k], v1 = wtot[1][k], v2 = wtot[2][k];
+      if (k < wave) { oh += v0; oH += v1; oL += v2; }
+      nh += v0; nH += v1; nL += v2;
     }
-    return;
+    if (tid == 0) {
+      const uint32_t R = nH + nL;
+      uint32_t rb = 0, okr = 1;
+      if (R) {
+        rb = atomicAdd(&a.cursors[CUR_RUNS], R);
+        if (!(rb <= a.run_cap && R <= a.run_cap - rb)) { okr = 0; atomicOr(&a.cursors[CUR_OVERFLOW], 4u); }
+      }
+      sh[2] = rb; sh[3] = okr;
+      a.run_blocks[(size_t)r * a.n_rounds + round] = okr ? make_uint2(rb, R) : make_uint2(0u, 0u);
+    }
+    __syncthreads();
+    {
+      const uint32_t rb = sh[2];
+      const bool okr = sh[3] != 0;
+      uint32_t pos = oh, rh = oH, rl = nH + oL;
+      for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t c = gcnt[k];
+        gcnt[k] = placed + pos; /* the bucket's cursor */
+        if (c) {
+          const uint32_t idx = c >= agg_min ? rh++ : rl++;
+          if (okr) a.runs[rb + idx] = make_uint4(b0 + k, hit_base + placed + pos, c, 0u);
+        }
+        pos += c;
+      }
+    }
+    __syncthreads();
+    {
+      int c = 0;
+      for (uint32_t g = tid; g < n_list; g += GROUP_BLOCK) {
+        while (g >= cpre[c + 1]) c++;
+        const uint2 key = a.raw[desc[c].x + (g - cpre[c])];
+        const uint32_t bl = key.x - b0;
+        if (bl < nb) {
+          double as = 0.0;
+          if (g < n_cache) {
+            as = acache[g];
+          } else {
+            const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key.y);
+            const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
+            const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
+            (void)ppf_alpha_in_frame(qy, qz, &as);
+          }
+          const uint32_t gi = hit_base + atomicAdd(&gcnt[bl], 1u);
+          a.s_a64[gi] = as;
+          a.s_cell[gi] = (uint16_t)hit_cell(as, s64);
+        }
+      }
+    }
+    placed += nh;
+    __syncthreads();
   }
-  uint32_t (*wcnt)[256] = reinterpret_cast<uint32_t (*)[256]>(gcnt);
-  const int passes = (a.key_bits + 7) / 8;
-  for (int pass = 0; pass < passes; pass++) {
-    const int shift = pass * 8;
-    if (tid < 256) base[tid] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) atomicAdd(&base[(src[i].x >> shift) & 255u], 1u);
-    __syncthreads();
-    if (wave == 0) { /* exclusive scan of the 256 digit counts: 4 per lane */
-      uint32_t c[4], tsum = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) { c[k] = base[lane * 4 + k]; tsum += c[k]; }
-      uint32_t incl = tsum;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-      }
-      uint32_t ex = incl - tsum;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { base[lane * 4 + k] = ex; ex += c[k]; }
-    }
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < n; t0 += GROUP_BLOCK) {
-      for (int k = tid; k < (GROUP_BLOCK / 64) * 256; k += GROUP_BLOCK) (&wcnt[0][0])[k] = 0;
-      __syncthreads();
-      const uint32_t i = t0 + tid;
-      const bool valid = i < n;
-      uint2 key = make_uint2(0, 0);
-      uint32_t d = 0;
-      if (valid) { key = src[i]; d = (key.x >> shift) & 255u; }
-      /* lanes of this wave with the same digit */
-      unsigned long long same = __ballot(valid);
-#pragma unroll
-      for (int bit = 0; bit < 8; bit++) {
-        const unsigned long long bb = __ballot((d >> bit) & 1u);
-        same &= ((d >> bit) & 1u) ? bb : ~bb;
-      }
-      const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-      if (valid && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(same);
-      __syncthreads();
-      if (valid) {
-        uint32_t pos = base[d] + rank;
-        for (int w = 0; w < wave; w++) pos += wcnt[w][d];
-        dst[pos] = key;
-      }
-      __syncthreads();
-      if (tid < 256) {
-        uint32_t add = 0;
-#pragma unroll
-        for (int w = 0; w < GROUP_BLOCK / 64; w++) add += wcnt[w][tid];
-        base[tid] += add;
-      }
-      __syncthreads();
-    }
-    uint2* tmp = src; src = dst; dst = tmp;
-  }
-  if (passes & 1) { /* result sits in keys_b: copy back */
-    uint2* ka = a.keys_a + (size_t)r * a.hit_cap;
-    const uint2* kb = a.keys_b + (size_t)r * a.hit_cap;
-    for (uint32_t i = tid; i < n; i += GROUP_BLOCK) ka[i] = kb[i];
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
+  if (lane == 0) wsum[wave] = w;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long t = 0;
+    for (int k = 0; k < GROUP_BLOCK / 64; k++) t += wsum[k];
+    a.work[r] = t;
+    atomicAdd(&a.tally[1], (unsigned long long)placed);
   }
 }
 
@@ -464,99 +531,50 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
  *   (word offset GW-A) with any bin other than A, and the lanes past the end of a bucket (word = lane).
  *   With it the vote needs no range check at all.  Entry offsets are bytes from the guard's start.
  *
- * Two votes (one pair record) = 2 x v_fma_f32 (q'), 2 x v_cvt_i32_f32 (k), 2 x v_fract_f32 + a shared v_min3
+ * Two direct votes (one pair record) = 2 x v_fma_f32 (q'), 2 x v_cvt_i32_f32 (k), 2 x v_fract_f32 + a shared v_min3
  * reduction (guard band), 2 x v_lshl_add_u32 (byte address), 2 x ds_add_u32.
  *   q' = alpha_m*S + Ohg,  Ohg = A/2 - alpha_s*S + G  (folded once per hit), k = trunc(q')
  *   k is the reference's integer whenever fract(q') >= 2G; otherwise the lane
  *   re-evaluates the fp64 chain.  That happens for ~3e-5 of the votes, so the re-evaluation is
  *   taken once per batch of U entries and only when some lane of the wave needs it.
  */
+typedef __attribute__((address_space(3))) unsigned char lds_byte; /* explicit LDS pointers: 32-bit arithmetic, ds_* ops */
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+__device__ __forceinline__ void lds_add(const uint32_t addr, const uint32_t v) {
+  (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_add_rtn(const uint32_t addr, const uint32_t v) {
+  return __hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t addr) { return *(volatile lds_u32*)(uintptr_t)addr; }
+/* two consecutive words at a 4-byte aligned address (ds_read2_b32; an 8-byte typed load would let the compiler assume
+ * 8-byte alignment, which the 28-byte table rows and the cell table do not have) */
+struct __attribute__((packed, aligned(4))) lds_pair_t { uint32_t x, y; };
+typedef __attribute__((address_space(3))) lds_pair_t lds_pair;
+__device__ __forceinline__ uint2 lds_ld2(const uint32_t addr) {
+  const lds_pair* p = (const lds_pair*)(uintptr_t)addr;
+  return make_uint2(p->x, p->y);
+}
+__device__ __forceinline__ void lds_st(const uint32_t addr, const uint32_t v) { *(volatile lds_u32*)(uintptr_t)addr = v; }
+__device__ __forceinline__ void lds_st8(const uint32_t addr, const uint32_t v) { *(volatile lds_byte*)(uintptr_t)addr = (unsigned char)v; }
+__device__ __forceinline__ uint32_t lds_ld8(const uint32_t addr) { return *(volatile lds_byte*)(uintptr_t)addr; }
+/* order the LDS phases of one wave (LDS executes a wave's operations in order; this keeps the compiler from moving them) */
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 template <int U>
 __device__ __forceinline__ void load_records(uint4* rec, const uint4* __restrict__ src, const uint32_t e0, const int lane) {
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-#if PPF_ABL == 3 || PPF_ABL == 5 /* diagnostic: no record loads */
-    const uint32_t x = e0 + u * 64 + lane;
-    rec[u] = make_uint4(((x * 2u) & 1023u) * 124u + 504u, ((x * 2u + 1u) & 1023u) * 124u + 504u,
-                        0x3a000000u + (x & 0xffffu) * 64u, 0x3a000000u + (x & 0xffffu) * 64u + 32u);
-#else
-    rec[u] = src[e0 + u * 64 + lane];
-#endif
-  }
+  for (int u = 0; u < U; u++) rec[u] = src[e0 + u * 64 + lane];
 }
 
-/* U pair records per lane -> 2U votes per lane.  n_valid = number of 64-record groups (of the U) holding data. */
+/* the bins of 2U votes against one hit; frmin = smallest fractional part (guard-band check) */
 template <int U>
-__device__ __forceinline__ void cast_votes(unsigned char* __restrict__ acc_bytes, const uint4* rec, const int n_valid,
-                                           const float S, const float Ohg, const double* __restrict__ asd_lds,
-                                           const float G2, const int A) {
-  int ka[U], kb[U];
+__device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const float Ohg, int (&ka)[U], int (&kb)[U], float& frmin_out) {
   float fa[U], fb[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    /* two scalar v_fma_f32: measured faster than one v_pk_fma_f32 on gfx950 (compute-only k_vote 10.0 vs 13.0 ms) */
-    const float qa = __builtin_fmaf(__uint_as_float(rec[u].z), S, Ohg);
-    const float qb = __builtin_fmaf(__uint_as_float(rec[u].w), S, Ohg);
-    ka[u] = (int)qa;
-    kb[u] = (int)qb;
-    fa[u] = __builtin_amdgcn_fractf(qa);
-    fb[u] = __builtin_amdgcn_fractf(qb);
-  }
-  /* smallest fractional part of the 2U votes with as few v_min3_f32 as possible (3 inputs each) */
-  float frmin = fa[0];
-  {
-    float pend[2 * U];
-    int np = 0;
-#pragma unroll
-    for (int u = 0; u < U; u++) { if (u) pend[np++] = fa[u]; pend[np++] = fb[u]; }
-    int i = 0;
-#pragma unroll
-    for (; i + 2 <= np; i += 2) frmin = __builtin_fminf(__builtin_fminf(frmin, pend[i]), pend[i + 1]);
-    if (i < np) frmin = __builtin_fminf(frmin, pend[i]);
-  }
-  if (__builtin_expect(__any(frmin < G2), 0)) {
-    const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      uint32_t za = rec[u].z, zb = rec[u].w;
-      asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the hot loop */
-      const float aa = __uint_as_float(za), ab = __uint_as_float(zb);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = ppf_alpha_bin_exact(aa, asd, A);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = ppf_alpha_bin_exact(ab, asd, A);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    if (u < n_valid) {
-      int adr_a = (int)rec[u].x + ka[u] * 4, adr_b = (int)rec[u].y + kb[u] * 4;
-#if PPF_ABL == 1 /* diagnostic: same instruction stream, conflict-free addresses */
-      asm volatile("" ::"v"(adr_a), "v"(adr_b));
-      adr_a = (int)((threadIdx.x & 63) * 4 + u * 512 + 1024);
-      adr_b = adr_a + 256;
-#endif
-#if PPF_ABL == 2 || PPF_ABL == 5 /* diagnostic: no atomics */
-      asm volatile("" ::"v"(adr_a), "v"(adr_b));
-#else
-      atomicAdd(reinterpret_cast<uint32_t*>(acc_bytes + adr_a), 1u);
-      atomicAdd(reinterpret_cast<uint32_t*>(acc_bytes + adr_b), 1u);
-#endif
-    }
-  }
-}
-
-/* ---- the same votes with the LDS atomics of hit h issued in the shadow of hit h+1's arithmetic ------------------
- * cast_votes emits [39 VALU][8 ds_add] per hit; with 4 waves per SIMD the waves bunch up at their LDS phases and the
- * two pipes alternate instead of overlapping.  Here the addresses of a hit are kept in registers and its atomics are
- * interleaved (sched_group_barrier: 5 VALU, 1 DS, ...) with the bin arithmetic of the next hit of the item. */
-typedef __attribute__((address_space(3))) unsigned char lds_byte; /* explicit LDS pointers: 32-bit arithmetic, ds_* atomics */
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-template <int U>
-__device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const float Ohg, const double* __restrict__ asd_lds,
-                                          const float G2, const int A, int (&ka)[U], int (&kb)[U], float& frmin_out) {
-  float fa[U], fb[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) {
+    /* two scalar v_fma_f32: measured faster than one v_pk_fma_f32 on gfx950 */
     const float qa = __builtin_fmaf(__uint_as_float(rec[u].z), S, Ohg);
     const float qb = __builtin_fmaf(__uint_as_float(rec[u].w), S, Ohg);
     ka[u] = (int)qa;
@@ -574,21 +592,20 @@ __device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const
   for (; i + 2 <= np; i += 2) frmin = __builtin_fminf(__builtin_fminf(frmin, pend[i]), pend[i + 1]);
   if (i < np) frmin = __builtin_fminf(frmin, pend[i]);
   frmin_out = frmin;
-  (void)asd_lds; (void)G2; (void)A;
 }
 /* rare path: votes within the guard band of a bin edge get the exact fp64 bin */
 template <int U>
-__device__ __forceinline__ void vote_fix(const uint4* rec, const float S, const float Ohg, const double* __restrict__ asd_lds,
+__device__ __forceinline__ void vote_fix(const uint4* rec, const float S, const float Ohg, const double* __restrict__ asd,
                                          const float G2, const int A, const float frmin, int (&ka)[U], int (&kb)[U]) {
   if (__builtin_expect(__any(frmin < G2), 0)) {
-    const double asd = *asd_lds; /* exact alpha_s of this hit, only needed here */
+    const double as = *asd; /* exact alpha_s of this hit, only needed here */
 #pragma unroll
     for (int u = 0; u < U; u++) {
       uint32_t za = rec[u].z, zb = rec[u].w;
       asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the hot loop */
       const float aa = __uint_as_float(za), ab = __uint_as_float(zb);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = ppf_alpha_bin_exact(aa, asd, A);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = ppf_alpha_bin_exact(ab, asd, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = ppf_alpha_bin_exact(aa, as, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = ppf_alpha_bin_exact(ab, as, A);
     }
   }
 }
@@ -599,249 +616,313 @@ __device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32
 #pragma unroll
   for (int u = 0; u < U; u++) {
     if (u < n_valid) {
-      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)(pa[u] + ((uint32_t)ka[u] << 2)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)(pb[u] + ((uint32_t)kb[u] << 2)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      lds_add(pa[u] + ((uint32_t)ka[u] << 2), 1u);
+      lds_add(pb[u] + ((uint32_t)kb[u] << 2), 1u);
     }
   }
 }
 /* one pipeline stage: the atomics of the previous hit (bins pka/pkb) under the bin arithmetic of hit hh (-> nka/nkb) */
 template <int U>
 __device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, const float S, const float ohg_v, const int hh,
-                                           const double* __restrict__ asd_lds, const float G2, const int A, const uint32_t (&pa)[U],
+                                           const double* __restrict__ asd, const float G2, const int A, const uint32_t (&pa)[U],
                                            const uint32_t (&pb)[U], const int (&pka)[U], const int (&pkb)[U], int (&nka)[U], int (&nkb)[U]) {
   float frmin;
   const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
   vote_issue<U>(pa, pb, pka, pkb, n_valid);
-  vote_bins<U>(rec, S, Ohg, asd_lds + hh, G2, A, nka, nkb, frmin);
+  vote_bins<U>(rec, S, Ohg, nka, nkb, frmin);
 #pragma unroll
   for (int i = 0; i < 2 * U; i++) {
     __builtin_amdgcn_sched_group_barrier(0x002, PPF_PIPE_VALU, 0); /* VALU */
     __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); /* DS */
   }
-  vote_fix<U>(rec, S, Ohg, asd_lds + hh, G2, A, frmin, nka, nkb);
+  vote_fix<U>(rec, S, Ohg, asd + hh, G2, A, frmin, nka, nkb);
 }
-/* all hits of a work item against one register batch of records; two sets of bins alternate so that a set is only
+/* all hits of a direct work item against one register batch of records; two sets of bins alternate so that a set is only
  * overwritten a full stage after the atomics that used it were issued */
 template <int U>
-__device__ __forceinline__ void vote_hits(unsigned char* __restrict__ acc_bytes, const uint4* rec, const int n_valid, const float S,
-                                          const float ohg_v, const int nh, const double* __restrict__ asd_lds, const float G2,
+__device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* rec, const int n_valid, const float S,
+                                          const float ohg_v, const int nh, const double* __restrict__ asd, const float G2,
                                           const int A) {
   uint32_t pa[U], pb[U];
   int ka0[U], kb0[U], ka1[U], kb1[U];
-  const uint32_t base = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes; /* LDS byte address of the guard region */
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    pa[u] = base + rec[u].x;
-    pb[u] = base + rec[u].y;
+    pa[u] = acc_base + rec[u].x;
+    pb[u] = acc_base + rec[u].y;
     asm volatile("" : "+v"(pa[u]), "+v"(pb[u])); /* computed once per batch, not rematerialised per vote */
   }
   {
     float frmin;
     const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), 0));
-    vote_bins<U>(rec, S, Ohg, asd_lds, G2, A, ka0, kb0, frmin);
-    vote_fix<U>(rec, S, Ohg, asd_lds, G2, A, frmin, ka0, kb0);
+    vote_bins<U>(rec, S, Ohg, ka0, kb0, frmin);
+    vote_fix<U>(rec, S, Ohg, asd, G2, A, frmin, ka0, kb0);
   }
   int hh = 1;
   for (; hh + 1 < nh; hh += 2) {
-    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd_lds, G2, A, pa, pb, ka0, kb0, ka1, kb1);
-    vote_stage<U>(rec, n_valid, S, ohg_v, hh + 1, asd_lds, G2, A, pa, pb, ka1, kb1, ka0, kb0);
+    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
+    vote_stage<U>(rec, n_valid, S, ohg_v, hh + 1, asd, G2, A, pa, pb, ka1, kb1, ka0, kb0);
   }
   if (hh < nh) {
-    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd_lds, G2, A, pa, pb, ka0, kb0, ka1, kb1);
+    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
     vote_issue<U>(pa, pb, ka1, kb1, n_valid);
   } else {
     vote_issue<U>(pa, pb, ka0, kb0, n_valid);
   }
 }
 
-/* Buckets of at most 32 pair records (64 entries: more than half of all (tile, bucket) runs): one ENTRY per lane
- * instead of one pair record per lane, so the 64 lanes of the single group are filled twice as well and a hit costs
+/* Runs of at most 32 pair records in this tile (64 entries: more than half of all (tile, bucket) runs): one ENTRY per
+ * lane instead of one pair record per lane, so the 64 lanes of the single group are filled twice as well and a hit costs
  * one fma/cvt/fract/lshl_add/ds_add instead of two of each.  Same bins, same guard band, same exact fallback. */
-__device__ __forceinline__ void vote_hits_single(unsigned char* __restrict__ acc_bytes, const uint32_t row_bytes, const uint32_t alpha_bits,
-                                                 const float S, const float ohg_v, const int nh, const double* __restrict__ asd_lds,
+__device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const uint32_t row_bytes, const uint32_t alpha_bits,
+                                                 const float S, const float ohg_v, const int nh, const double* __restrict__ asd,
                                                  const float G2, const int A) {
-  uint32_t pr = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes + row_bytes;
+  uint32_t pr = acc_base + row_bytes;
   asm volatile("" : "+v"(pr));
   const float am = __uint_as_float(alpha_bits);
   uint32_t adr_prev = 0;
   for (int hh = 0; hh < nh; hh++) {
     const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
-    if (hh) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)adr_prev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (hh) lds_add(adr_prev, 1u);
     const float q = __builtin_fmaf(am, S, Ohg);
     int k = (int)q;
     if (__builtin_expect(__any(__builtin_amdgcn_fractf(q) < G2), 0)) {
-      const double asd = asd_lds[hh];
+      const double as = asd[hh];
       uint32_t z = alpha_bits;
       asm volatile("" : "+v"(z));
       const float az = __uint_as_float(z);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(az, S, Ohg)) < G2) k = ppf_alpha_bin_exact(az, asd, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(az, S, Ohg)) < G2) k = ppf_alpha_bin_exact(az, as, A);
     }
     adr_prev = pr + ((uint32_t)k << 2);
   }
-  if (nh > 0) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)adr_prev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (nh > 0) lds_add(adr_prev, 1u);
 }
 
-/* ---- 16.16 fixed-point votes --------------------------------------------------------------------------------
- * bin = floor(x), x = (alpha_m - alpha_s)*A/(4pi) + A/2.  Per entry fx = rint(alpha_m * A/(4pi) * 65536) (signed, built
- * with the table), per hit C = rint((A/2 - alpha_s*A/(4pi)) * 65536) + 2 (fp64, once per staged hit): the integer sum
- * s = fx + C equals x*65536 + 2 + e with |e| <= 1.01 (two roundings; the fp64 products are exact to 1e-9 units), so
- * whenever the 16 fraction bits of s are >= 4, floor(x) = s >> 16 -- and it is also what the reference's fp64 chain
- * gives, which differs from x by ~1e-14.  Otherwise (6e-5 of the votes) the lane evaluates that fp64 chain.
- * Cost per vote: v_add_u32 (s), v_mad_u32_u16 (LDS address = hi16(s)*4 + row: the shift, the mask and the add in
- * one instruction), half a v_min3_u16 (the guard: running minimum of the low halves), ds_add_u32. */
-#ifndef PPF_FX_ASM
-#define PPF_FX_ASM 1 /* v_mad_u32_u16 / v_min3_u16 through inline asm (the compiler does not select them from C++) */
-#endif
-__device__ __forceinline__ uint32_t fx_min3(uint32_t m, uint32_t a, uint32_t b) {
-#if PPF_FX_ASM
-  uint32_t r;
-  asm("v_min3_u16 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-  return r;
-#else /* 16-bit minimum of the low halves: selected as v_min3_u16 */
-  const unsigned short x = (unsigned short)m, y = (unsigned short)a, z = (unsigned short)b;
-  const unsigned short t = x < y ? x : y;
-  return (uint32_t)(t < z ? t : z);
-#endif
-}
-__device__ __forceinline__ uint32_t fx_addr(uint32_t s, uint32_t row) { /* hi16(s) * 4 + row */
-#if PPF_FX_ASM
-  uint32_t r;
-  asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(s), "v"(row));
-  return r;
-#else
-  return (uint32_t)(unsigned short)(s >> 16) * (uint32_t)(unsigned short)4 + row;
-#endif
-}
-template <int U>
-__device__ __forceinline__ void fx_sums(const uint4* rec, const uint32_t C, uint32_t (&sa)[U], uint32_t (&sb)[U], uint32_t& guard) {
-  uint32_t m = 0xFFFFu;
+/* ---- aggregated votes ------------------------------------------------------------------------------------------- */
+struct AggConsts {
+  uint32_t acc_base; /* LDS byte address of the guard region */
+  uint32_t ws;       /* LDS byte address of this wave's scratch */
+  float S, half_a, Og, G2;
+  double s64, half_a64;
+  int A;
+};
+
+/* Count table of one range of <= AGG_SUB hits (global indices g0 .. g0+ms of the sorted payload), built by one wave in its
+ * own LDS scratch:
+ *   T[q][j], q < AGG_Q, j = 0..16   hits with cell p < q and Y + 8 == j, plus hits with p > q and Y + 8 == j - 1: what an
+ *                                   entry in cell q adds to its bin X + 8 - j (bytes; row AGG_Q stays zero)
+ *   ce[p], ce[p+1]                  range of the hits of cell p in the cell-sorted copy sa32[] / sidx[] */
+__device__ __forceinline__ void agg_build(const AggConsts& k, const double* __restrict__ g_a64, const uint16_t* __restrict__ g_cell,
+                                          const int ms, const int lane) {
+  const uint32_t ws = k.ws;
+  lds_st(ws + AGG_OFF_A32 + lane * 8, 0u);     /* byte counters cnt[Y][p]: 512 B */
+  lds_st(ws + AGG_OFF_A32 + lane * 8 + 4, 0u);
+  if (lane < AGG_Q + 1) lds_st(ws + AGG_OFF_CE + lane * 4, 0u);
+  if (lane < AGG_ROW / 4) lds_st(ws + AGG_Q * AGG_ROW + lane * 4, 0u); /* the all-zero row */
+  uint32_t cell[3], a32[3];
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    sa[u] = rec[u].z + C;
-    sb[u] = rec[u].w + C;
-    m = fx_min3(m, sa[u], sb[u]);
+  for (int t = 0; t < 3; t++) {
+    const int i = lane + 64 * t;
+    const bool v = i < ms;
+    cell[t] = v ? (uint32_t)g_cell[i] : 0xFFFFu;
+    a32[t] = v ? __float_as_uint(k.Og - (float)g_a64[i] * k.S) : 0u; /* Ohg = A/2 + G - alpha_s*S of the direct arithmetic */
   }
-  guard = m;
-}
-/* rare path: votes whose fraction is inside the guard get the exact fp64 bin (alpha_m comes from the float records) */
-template <int U>
-__device__ __forceinline__ void fx_fix(const uint4* __restrict__ srcf, const uint32_t e0, const uint32_t c, const int lane,
-                                       const double* __restrict__ asd_lds, const int A, const uint32_t T, const uint32_t guard,
-                                       uint32_t (&sa)[U], uint32_t (&sb)[U]) {
-  if (__builtin_expect(__any((guard & 0xFFFFu) < T), 0)) {
-    const double asd = *asd_lds; /* exact alpha_s of this hit */
+  wave_lds_fence();
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (__any(((sa[u] & 0xFFFFu) < T) | ((sb[u] & 0xFFFFu) < T))) {
-        const uint4 rf = srcf[min(e0 + (uint32_t)(u * 64 + lane), c - 1u)];
-        if ((sa[u] & 0xFFFFu) < T) sa[u] = (uint32_t)ppf_alpha_bin_exact(__uint_as_float(rf.z), asd, A) << 16;
-        if ((sb[u] & 0xFFFFu) < T) sb[u] = (uint32_t)ppf_alpha_bin_exact(__uint_as_float(rf.w), asd, A) << 16;
-      }
+  for (int t = 0; t < 3; t++) {
+    if (cell[t] != 0xFFFFu) {
+      lds_add(ws + AGG_OFF_A32 + (cell[t] & ~3u), 1u << (8u * (cell[t] & 3u)));
+      lds_add(ws + AGG_OFF_CE + (cell[t] & (AGG_Q - 1)) * 4, 1u);
     }
   }
-}
-template <int U>
-__device__ __forceinline__ void fx_issue(const uint32_t (&pa)[U], const uint32_t (&pb)[U], const uint32_t (&sa)[U], const uint32_t (&sb)[U],
-                                         const int n_valid) {
+  wave_lds_fence();
+  /* lane L holds cnt[Y = L/4][p = 8*(L%4) .. +8] */
+  const uint2 cw = lds_ld2(ws + AGG_OFF_A32 + lane * 8);
+  uint32_t c[8], less[8], more[8];
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    if (u < n_valid) {
-#ifdef PPF_FX_NOCONFLICT /* diagnostic: same instruction stream, conflict-free addresses */
-      uint32_t aa = fx_addr(sa[u], pa[u]), ab = fx_addr(sb[u], pb[u]);
-      asm volatile("" ::"v"(aa), "v"(ab));
-      aa = (uint32_t)((threadIdx.x & 63) * 4 + u * 512 + 29184 + 1024);
-      ab = aa + 256;
-      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)aa, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)ab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(sa[u], pa[u]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(sb[u], pb[u]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int t = 0; t < 8; t++) c[t] = ((t < 4 ? cw.x : cw.y) >> (8 * (t & 3))) & 0xFFu;
+  uint32_t run = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) { less[t] = run; run += c[t]; }
+  const int quarter = lane & 3;
+  const uint32_t t1 = __shfl_up(run, 1, 4), t2 = __shfl_up(run, 2, 4), t3 = __shfl_up(run, 3, 4);
+  const uint32_t before = (quarter >= 1 ? t1 : 0u) + (quarter >= 2 ? t2 : 0u) + (quarter >= 3 ? t3 : 0u);
+  const uint32_t tot = __shfl(before + run, 3, 4); /* hits with this Y */
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    less[t] += before;
+    more[t] = tot - less[t] - c[t];
+  }
+  const int yy = lane >> 2;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const uint32_t mprev = __shfl_up(more[t], 4);
+    const uint32_t v = less[t] + (lane >= 4 ? mprev : 0u);
+    const uint32_t p = (uint32_t)(quarter * 8 + t);
+    lds_st8(ws + p * AGG_ROW + yy, v);
+    if (yy == AGG_NY - 1) lds_st8(ws + p * AGG_ROW + AGG_NY, more[t]);
+  }
+  wave_lds_fence();
+  /* cell ends: inclusive scan of the per-p counts; the scatter below counts them down to the cell starts */
+  uint32_t h = lane < AGG_Q ? lds_ld(ws + AGG_OFF_CE + lane * 4) : 0u;
+#pragma unroll
+  for (int o = 1; o < AGG_Q; o <<= 1) {
+    const uint32_t y = __shfl_up(h, o);
+    if (lane >= o) h += y;
+  }
+  wave_lds_fence();
+  if (lane < AGG_Q) lds_st(ws + AGG_OFF_CE + lane * 4, h);
+  if (lane == AGG_Q) lds_st(ws + AGG_OFF_CE + AGG_Q * 4, (uint32_t)ms);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    if (cell[t] != 0xFFFFu) {
+      const uint32_t pos = lds_add_rtn(ws + AGG_OFF_CE + (cell[t] & (AGG_Q - 1)) * 4, 0xFFFFFFFFu) - 1u;
+      lds_st(ws + AGG_OFF_A32 + pos * 4, a32[t]);
+      lds_st8(ws + AGG_OFF_IDX + pos, (uint32_t)(lane + 64 * t));
+    }
+  }
+  wave_lds_fence();
+}
+
+/* cell of an entry: x = alpha_m*A/(4 pi) + A/2 = X + phi, q = floor(AGG_Q * phi) (row AGG_Q: the entry votes one by one) */
+__device__ __forceinline__ void agg_cell(const AggConsts& k, const float am, int& X, int& q) {
+  const float x = __builtin_fmaf(am, k.S, k.half_a);
+  X = (int)x;
+  const float qf = __builtin_amdgcn_fractf(x) * (float)AGG_Q;
+  q = (int)qf;
+  const float fq = __builtin_amdgcn_fractf(qf);
+  /* fp32 error of x: <= 1.5e-6 bins (S rounding 6e-8*7.5, fma 9.5e-7) = 4.8e-5 cells; band 1.5e-4 cells */
+  const bool near = !(fq > 1.5e-4f && fq < 1.0f - 1.5e-4f);
+  bool one_by_one = am < -3.1415925f; /* (float)-pi and below: x - y may be negative, where the reference truncates to 0 */
+  if (__builtin_expect(__any(near), 0)) {
+    if (near) {
+      const double xd = (double)am * k.s64 + k.half_a64;
+      const double Xd = __builtin_floor(xd);
+      const double qd = (xd - Xd) * (double)AGG_Q;
+      const double qfl = __builtin_floor(qd);
+      const double fqd = qd - qfl;
+      X = (int)Xd;
+      q = (int)qfl;
+      one_by_one |= !(fqd > 1e-7 && fqd < 1.0 - 1e-7);
+    }
+  }
+  q = one_by_one ? AGG_Q : min(q, AGG_Q - 1);
+}
+
+/* The two model entries of one pair record against the count table: 17 counted atomics each, then one vote per hit of
+ * each entry's own cell (all hits for an entry that votes one by one) with the direct arithmetic -- both entries walk
+ * their cells in one loop, so the LDS round trip of a hit's offset is shared.  `votes` counts the one-by-one votes. */
+__device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, const double* __restrict__ g_a64, const int ms,
+                                         uint32_t& votes) {
+  const float am_a = __uint_as_float(rec.z), am_b = __uint_as_float(rec.w);
+  int Xa, qa, Xb, qb;
+  agg_cell(k, am_a, Xa, qa);
+  agg_cell(k, am_b, Xb, qb);
+  const uint32_t ta = k.ws + (uint32_t)qa * AGG_ROW, tb = k.ws + (uint32_t)qb * AGG_ROW;
+  const uint2 a01 = lds_ld2(ta), a23 = lds_ld2(ta + 8), a45 = lds_ld2(ta + 16);
+  const uint2 b01 = lds_ld2(tb), b23 = lds_ld2(tb + 8), b45 = lds_ld2(tb + 16);
+  /* the cells' hit ranges in the cell-sorted copy */
+  uint2 ca = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qa, AGG_Q - 1) * 4), cb = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qb, AGG_Q - 1) * 4);
+  if (qa == AGG_Q) { ca.x = 0u; ca.y = (uint32_t)ms; }
+  if (qb == AGG_Q) { cb.x = 0u; cb.y = (uint32_t)ms; }
+  const uint32_t pa = k.acc_base + rec.x, pb = k.acc_base + rec.y;
+  const uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
+  const uint32_t wa[5] = {a01.x, a01.y, a23.x, a23.y, a45.x}, wb[5] = {b01.x, b01.y, b23.x, b23.y, b45.x};
+#pragma unroll
+  for (int j = 0; j <= AGG_NY; j++) {
+    lds_add(va + (uint32_t)((AGG_NY - j) * 4), (wa[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+    lds_add(vb + (uint32_t)((AGG_NY - j) * 4), (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+  }
+  votes += (ca.y - ca.x) + (cb.y - cb.x);
+  uint32_t ia = ca.x, ib = cb.x;
+  while (__any((ia < ca.y) | (ib < cb.y))) {
+    const bool da = ia < ca.y, db = ib < cb.y;
+    const float oa = __uint_as_float(lds_ld(k.ws + AGG_OFF_A32 + min(ia, (uint32_t)(AGG_SUB - 1)) * 4));
+    const float ob = __uint_as_float(lds_ld(k.ws + AGG_OFF_A32 + min(ib, (uint32_t)(AGG_SUB - 1)) * 4));
+    const float xa = __builtin_fmaf(am_a, k.S, oa), xb = __builtin_fmaf(am_b, k.S, ob);
+    int ba = (int)xa, bb = (int)xb;
+    const bool ga = da & (__builtin_amdgcn_fractf(xa) < k.G2), gb = db & (__builtin_amdgcn_fractf(xb) < k.G2);
+    if (__builtin_expect(__any(ga | gb), 0)) { /* inside the guard band of a bin edge: the exact fp64 chain */
+      if (ga) ba = ppf_alpha_bin_exact(am_a, g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ia)], k.A);
+      if (gb) bb = ppf_alpha_bin_exact(am_b, g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ib)], k.A);
+    }
+    if (da) lds_add(pa + ((uint32_t)ba << 2), 1u);
+    if (db) lds_add(pb + ((uint32_t)bb << 2), 1u);
+    ia++; ib++;
+  }
+}
+
+/* one work item of k_vote, located and with its first loads issued (wave-uniform fields live in scalar registers) */
+struct VoteItem {
+  const uint4* src; /* first record of the item */
+  uint32_t c;       /* records */
+  uint32_t g0;      /* first sorted hit */
+  int nh;           /* hits */
+  bool agg;         /* votes through the count table */
+  double a64;       /* direct items: alpha_s of hit g0 + lane (lanes < nh) */
+  uint4 rec0;       /* record min(lane, c-1) (items of <= 32 records: record min(lane/2, c-1), the one-entry-per-lane layout) */
+};
+
+#ifndef PPF_PREFETCH
+#define PPF_PREFETCH 2 /* loads issued for the NEXT work item while the current one votes: 2 = hits' alpha_s and first records, 1 = alpha_s, 0 = none */
 #endif
-    }
-  }
+__device__ __forceinline__ void vote_fetch_hits(VoteItem& it, const int lane, const MatchArgs& a) {
+  it.a64 = (!it.agg && lane < it.nh) ? a.s_a64[it.g0 + lane] : 0.0;
 }
-template <int U>
-__device__ __forceinline__ void fx_stage(const uint4* rec, const int n_valid, const uint32_t cfix_v, const int hh,
-                                         const double* __restrict__ asd_lds, const int A, const uint32_t T, const uint4* __restrict__ srcf,
-                                         const uint32_t e0, const uint32_t c, const int lane, const uint32_t (&pa)[U], const uint32_t (&pb)[U],
-                                         const uint32_t (&psa)[U], const uint32_t (&psb)[U], uint32_t (&nsa)[U], uint32_t (&nsb)[U]) {
-  const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)cfix_v, hh);
-  uint32_t guard;
-  fx_issue<U>(pa, pb, psa, psb, n_valid);
-  fx_sums<U>(rec, C, nsa, nsb, guard);
-#pragma unroll
-  for (int i = 0; i < 2 * U; i++) {
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); /* VALU */
-    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); /* DS */
-  }
-  fx_fix<U>(srcf, e0, c, lane, asd_lds + hh, A, T, guard, nsa, nsb);
+__device__ __forceinline__ void vote_fetch_records(VoteItem& it, const int lane) {
+  const uint32_t idx = (!it.agg && it.c <= 32) ? ((uint32_t)lane >> 1) : (uint32_t)lane;
+  it.rec0 = it.src[min(idx, it.c - 1)];
 }
-/* all hits of a work item against one register batch of records (rec: fixed-point records e0.. of the run) */
-template <int U>
-__device__ __forceinline__ void vote_hits_fx(unsigned char* __restrict__ acc_bytes, const uint4* rec, const int n_valid, const uint32_t cfix_v,
-                                             const int nh, const double* __restrict__ asd_lds, const int A, const uint32_t T,
-                                             const uint4* __restrict__ srcf, const uint32_t e0, const uint32_t c, const int lane) {
-  uint32_t pa[U], pb[U], sa0[U], sb0[U], sa1[U], sb1[U];
-  const uint32_t base = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes; /* LDS byte address of the guard region */
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    pa[u] = base + rec[u].x;
-    pb[u] = base + rec[u].y;
-    asm volatile("" : "+v"(pa[u]), "+v"(pb[u])); /* computed once per batch, not rematerialised per vote */
+
+__device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, int& h, const uint32_t* seg_prefix, const uint32_t* seg_off,
+                                            const uint32_t* seg_cnt, const uint32_t* seg_hit, const uint32_t* seg_m, const int lane,
+                                            const MatchArgs& a, const uint4* __restrict__ records) {
+  while (true) { /* advance h to the last position with prefix <= item */
+    const uint32_t pv = seg_prefix[min(h + 1 + lane, RUN_SEG + 63)];
+    const unsigned long long le = __ballot(pv <= item);
+    const int adv = __popcll(le);
+    h += adv;
+    if (adv < 64) break;
   }
-  {
-    uint32_t guard;
-    fx_sums<U>(rec, (uint32_t)__builtin_amdgcn_readlane((int)cfix_v, 0), sa0, sb0, guard);
-    fx_fix<U>(srcf, e0, c, lane, asd_lds, A, T, guard, sa0, sb0);
-  }
-  int hh = 1;
-  for (; hh + 1 < nh; hh += 2) {
-    fx_stage<U>(rec, n_valid, cfix_v, hh, asd_lds, A, T, srcf, e0, c, lane, pa, pb, sa0, sb0, sa1, sb1);
-    fx_stage<U>(rec, n_valid, cfix_v, hh + 1, asd_lds, A, T, srcf, e0, c, lane, pa, pb, sa1, sb1, sa0, sb0);
-  }
-  if (hh < nh) {
-    fx_stage<U>(rec, n_valid, cfix_v, hh, asd_lds, A, T, srcf, e0, c, lane, pa, pb, sa0, sb0, sa1, sb1);
-    fx_issue<U>(pa, pb, sa1, sb1, n_valid);
-  } else {
-    fx_issue<U>(pa, pb, sa0, sb0, n_valid);
-  }
-}
-/* runs of at most 32 pair records: one entry per lane (see vote_hits_single) */
-__device__ __forceinline__ void vote_hits_single_fx(unsigned char* __restrict__ acc_bytes, const uint32_t row_bytes, const uint32_t fxv,
-                                                    const uint32_t alpha_bits, const uint32_t cfix_v, const int nh,
-                                                    const double* __restrict__ asd_lds, const int A, const uint32_t T) {
-  uint32_t pr = (uint32_t)(uintptr_t)(lds_byte*)acc_bytes + row_bytes;
-  asm volatile("" : "+v"(pr));
-  uint32_t s_prev = 0;
-  for (int hh = 0; hh < nh; hh++) {
-    const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)cfix_v, hh);
-    if (hh) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(s_prev, pr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    uint32_t sv = fxv + C;
-    if (__builtin_expect(__any((sv & 0xFFFFu) < T), 0)) {
-      if ((sv & 0xFFFFu) < T) sv = (uint32_t)ppf_alpha_bin_exact(__uint_as_float(alpha_bits), asd_lds[hh], A) << 16;
-    }
-    s_prev = sv;
-  }
-  if (nh > 0) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)fx_addr(s_prev, pr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  /* the staged values are the same in every lane: move them to scalar registers so the item
+   * runs on scalar control flow and scalar base addresses */
+  const uint32_t local = item - (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_prefix[h]);
+  const uint32_t c_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_cnt[h]);
+  const uint32_t mm = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_m[h]);
+  const uint32_t m_all = mm & 0x7FFFFFFFu;
+  const uint32_t hit0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_hit[h]);
+  const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_off[h]);
+  it.agg = (mm & 0x80000000u) != 0;
+  const uint32_t chunk_sz = it.agg ? (uint32_t)AGG_CHUNK : (uint32_t)VOTE_CHUNK;
+  const uint32_t group_sz = it.agg ? (uint32_t)AGG_SUB : (uint32_t)VOTE_MAX_HITS;
+  const uint32_t nchunk = (c_all + chunk_sz - 1) / chunk_sz;
+  const uint32_t sub = local / nchunk, chunk = local - sub * nchunk;
+  it.c = min(chunk_sz, c_all - chunk * chunk_sz);
+  it.src = records + off0 + chunk * chunk_sz;
+  it.g0 = hit0 + sub * group_sz;
+  it.nh = (int)min(group_sz, m_all - sub * group_sz);
+#if PPF_PREFETCH >= 1
+  vote_fetch_hits(it, lane, a);
+#endif
+#if PPF_PREFETCH >= 2
+  vote_fetch_records(it, lane);
+#endif
 }
 
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
-  uint32_t* seg_prefix = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);          /* VOTE_SEG + 64 */
-  uint32_t* seg_off = seg_prefix + (VOTE_SEG + 64);                                /* VOTE_SEG */
-  uint32_t* seg_cnt = seg_off + VOTE_SEG;                                          /* VOTE_SEG */
-  uint32_t* seg_m = seg_cnt + VOTE_SEG;                                            /* VOTE_SEG: run length at run starts */
-  uint32_t* seg_a32 = seg_m + VOTE_SEG;                                            /* VOTE_SEG */
-  double* seg_a64 = reinterpret_cast<double*>(seg_a32 + VOTE_SEG);                 /* VOTE_SEG */
+  uint32_t* seg_prefix = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);          /* RUN_SEG + 64 */
+  uint32_t* seg_off = seg_prefix + (RUN_SEG + 64);                                 /* RUN_SEG: first record of the run in this tile */
+  uint32_t* seg_cnt = seg_off + RUN_SEG;                                           /* RUN_SEG: records */
+  uint32_t* seg_hit = seg_cnt + RUN_SEG;                                           /* RUN_SEG: first sorted hit */
+  uint32_t* seg_m = seg_hit + RUN_SEG;                                             /* RUN_SEG: hits | count-table flag << 31 */
+  unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(seg_m + RUN_SEG); /* VOTE_WAVES x AGG_SCRATCH */
   const int A = a.num_angles;
   const int P = vote_pitch(A);
   const int GW = vote_guard(A);
-  uint32_t* lds_acc = reinterpret_cast<uint32_t*>(seg_a64 + VOTE_SEG);             /* guard + cells */
+  uint32_t* lds_acc = reinterpret_cast<uint32_t*>(wave_scratch + VOTE_WAVES * AGG_SCRATCH); /* guard + cells */
   uint32_t* acc = lds_acc + GW;
-  /* table entries carry byte offsets relative to the start of the guard ((GW + local_ref*P)*4), so the
-   * vote address is entry.x + k*4 on top of a compile-time LDS offset */
-  unsigned char* acc_bytes = reinterpret_cast<unsigned char*>(lds_acc);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* scalar: the work-item loop is wave-uniform */
@@ -858,225 +939,175 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   }
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
-#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
-  const uint4* __restrict__ records = a.records_fx;
-  const uint4* __restrict__ records_f = a.records; /* float alpha_m: only read on the guard path */
-#else
   const uint4* __restrict__ records = a.records;
-#endif
-  const HitRec* __restrict__ hits = a.hits + (size_t)r * a.hit_cap;
-  const int n_hits = (int)a.hit_count[r];
   const float S = (float)((double)A / (4 * PPF_PI));
 #ifdef PPF_FORCE_EXACT
-  const float G = 1.0f;
+  const float G = 1.0f; /* test build: every direct vote takes the fp64 chain */
 #else
   const float G = PPF_GUARD_REL * (float)A;
 #endif
   const float G2 = 2.0f * G;
-  (void)G2;
   const float Og = 0.5f * (float)A + G;
-  const uint32_t tail_bytes = (uint32_t)(lane * 4); /* per-lane guard word for lanes past the end of a bucket */
+  const uint32_t tail_bytes = (uint32_t)(lane * 4 + 8); /* per-lane guard word for lanes past the end of a bucket (words 2..65: the count
+                                                          table path also touches the word below the row's bin 0) */
+  AggConsts ak;
+  ak.acc_base = (uint32_t)(uintptr_t)(lds_byte*)reinterpret_cast<unsigned char*>(lds_acc);
+  ak.ws = (uint32_t)(uintptr_t)(lds_byte*)(wave_scratch + wave * AGG_SCRATCH);
+  ak.S = S; ak.half_a = 0.5f * (float)A; ak.Og = Og; ak.G2 = G2;
+  ak.s64 = (double)A / (4 * PPF_PI); ak.half_a64 = 0.5 * (double)A;
+  ak.A = A;
+  const uint32_t acc_base = ak.acc_base;
+  const uint32_t agg_min = (a.agg_min_hits > 0 && A <= AGG_MAX_ANGLES) ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
+  unsigned long long ops = 0; /* LDS atomic lane-operations issued by this wave (wave-uniform part) */
+  uint32_t agg_votes = 0;     /* ... plus this lane's one-by-one votes on the count-table path */
 
-  const uint2* __restrict__ keys = a.keys_sorted + (size_t)r * a.hit_cap;
-  unsigned long long* start_mask = reinterpret_cast<unsigned long long*>(red + 16); /* VOTE_WAVES x u64 */
+  for (int blk = 0; blk < a.n_rounds; blk++) {
+    const uint2 rb = a.run_blocks[(size_t)r * a.n_rounds + blk];
+    for (uint32_t seg0 = 0; seg0 < rb.y; seg0 += RUN_SEG) {
+      /* Stage a segment of the run table: this tile's record range of every run and its work items, exclusive scan */
+      __syncthreads(); /* previous segment fully consumed (and the accumulator clear, first time) */
+      const uint32_t n_seg = min((uint32_t)RUN_SEG, rb.y - seg0);
+      uint32_t items = 0;
+      if (tid < RUN_SEG) {
+        uint32_t off = 0, cnt = 0, hs = 0, mm = 0;
+        if ((uint32_t)tid < n_seg) {
+          const uint4 run = a.runs[rb.x + seg0 + tid];
+          off = boff[run.x];
+          cnt = boff[run.x + 1] - off;
+          hs = run.y;
+          mm = run.z;
+          if (cnt) {
+            if (run.z >= agg_min && cnt >= PPF_AGG_MIN_RECORDS) {
+              items = ((run.z + AGG_SUB - 1) / AGG_SUB) * ((cnt + AGG_CHUNK - 1) / AGG_CHUNK);
+              mm |= 0x80000000u;
+            } else {
+              items = ((run.z + VOTE_MAX_HITS - 1) / VOTE_MAX_HITS) * ((cnt + VOTE_CHUNK - 1) / VOTE_CHUNK);
+            }
+          }
+        }
+        seg_off[tid] = off; seg_cnt[tid] = cnt; seg_hit[tid] = hs; seg_m[tid] = mm;
+      }
+      uint32_t incl = items;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (lane == 63) red[wave] = incl;
+      __syncthreads();
+      uint32_t woff = 0, total = 0;
+#pragma unroll
+      for (int kk = 0; kk < RUN_SEG / 64; kk++) {
+        const uint32_t w = red[kk];
+        if (kk < wave) woff += w;
+        total += w;
+      }
+      if (tid < RUN_SEG) seg_prefix[tid] = woff + incl - items; /* exclusive */
+      if (tid < 64) seg_prefix[RUN_SEG + tid] = total;           /* sentinel + padding for the 64-wide look-ahead */
+      if (tid == 0) red[48] = VOTE_WAVES; /* next unclaimed work item (each wave starts with item == its id) */
+      __syncthreads();
 
-  for (int seg0 = 0; seg0 < n_hits; seg0 += VOTE_SEG) {
-    /* Stage a segment of the bucket-sorted hit list: this tile's bucket range, alpha_s, run
-     * structure (a run = consecutive hits of one bucket), work items per run, exclusive scan. */
-    __syncthreads(); /* previous segment fully consumed (and the accumulator clear, first time) */
-    const int n_seg = min(VOTE_SEG, n_hits - seg0);
-    uint32_t off = 0, cnt = 0;
-    bool is_start = true; /* positions past the end terminate the last run */
-    if (tid < n_seg) {
-      const uint2 key = keys[seg0 + tid];
-      const HitRec h = hits[key.y];
-      if (key.x != 0xFFFFFFFFu) {
-        off = boff[key.x];
-        cnt = boff[key.x + 1] - off;
-      }
-#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
-      /* C = rint((A/2 - alpha_s * A/(4 pi)) * 65536) + 2 (the folded guard), fp64 */
-      seg_a32[tid] = (uint32_t)(long long)__builtin_rint((0.5 * (double)A - h.alpha_s * ((double)A / (4 * PPF_PI))) * 65536.0) + 2u;
-#else
-      seg_a32[tid] = h.alpha32;
+      /* Work items are claimed from an LDS counter as waves become free (items differ by orders of magnitude in
+       * size); a wave's items still come in increasing order, so the owning run is found with a 64-wide look-ahead
+       * from the previous one (runs with no records in this tile have 0 items and are skipped).  A wave always holds
+       * TWO items: while it votes one, the first loads of the next (its hits' alpha_s, its first records) are in
+       * flight -- most items are small (a bucket's share of one tile: median 14 records) and would otherwise spend
+       * their time waiting for those loads. */
+      int h = 0;
+      VoteItem cur, nxt;
+      uint32_t item = (uint32_t)wave;
+      bool have = item < total;
+      if (have) vote_locate(cur, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+      while (have) {
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u));
+        const bool have_next = item < total;
+        if (have_next) vote_locate(nxt, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+#if PPF_PREFETCH < 1
+        vote_fetch_hits(cur, lane, a);
 #endif
-      seg_a64[tid] = h.alpha_s;
-      is_start = (tid == 0) || (keys[seg0 + tid - 1].x != key.x);
-    }
-    const unsigned long long smask = __ballot(is_start);
-    if (lane == 0) start_mask[wave] = smask;
-    __syncthreads();
-    uint32_t items = 0, m = 0;
-    if (tid < n_seg && is_start && cnt > 0) {
-      /* run length: distance to the next run start (or to the end of the segment) */
-      int next = VOTE_SEG;
-      unsigned long long rest = (lane == 63) ? 0ull : (smask >> (lane + 1));
-      if (rest) {
-        next = tid + 1 + (__ffsll((long long)rest) - 1);
-      } else {
-        for (int w = wave + 1; w < VOTE_WAVES; w++) {
-          const unsigned long long mw = start_mask[w];
-          if (mw) { next = w * 64 + (__ffsll((long long)mw) - 1); break; }
-        }
-      }
-      m = (uint32_t)(min(next, n_seg) - tid);
-      items = ((m + VOTE_MAX_HITS - 1) / VOTE_MAX_HITS) * ((cnt + VOTE_CHUNK - 1) / VOTE_CHUNK);
-    }
-    seg_off[tid] = off;
-    seg_cnt[tid] = cnt;
-    seg_m[tid] = m;
-    uint32_t incl = items;
+#if PPF_PREFETCH < 2
+        vote_fetch_records(cur, lane);
+#endif
+        if (cur.agg) {
+          /* ---- count-table item: <= AGG_SUB hits x <= AGG_CHUNK records ---- */
+          const uint32_t c = cur.c;
+          const uint4* __restrict__ src = cur.src;
+          uint4 rec_cur = cur.rec0;
+          agg_build(ak, a.s_a64 + cur.g0, a.s_cell + cur.g0, cur.nh, lane);
+          const double* __restrict__ g_a64 = a.s_a64 + cur.g0;
+          for (uint32_t e0 = 0; e0 < c; e0 += 64) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            const uint4 rec_nxt = src[min(e + 64, c - 1)]; /* next block's records in flight under this block's votes */
+            uint4 rec = rec_cur;
+            if (e >= c) { rec.x = tail_bytes; rec.y = tail_bytes; }
+            agg_pair(ak, rec, g_a64, cur.nh, agg_votes);
+            rec_cur = rec_nxt;
+          }
+          ops += 2u * (AGG_NY + 1) * 64u * ((c + 63u) / 64u);
+        } else {
+          /* ---- direct item: <= VOTE_MAX_HITS hits x <= VOTE_CHUNK records ---- */
+          const uint32_t c = cur.c;
+          const int nh = cur.nh;
+          /* lane l holds the folded offset of hit g0+l: Ohg = A/2 + G - alpha_s*S */
+          const float ohg_v = lane < nh ? Og - (float)cur.a64 * S : 0.f;
+          const double* __restrict__ asd = a.s_a64 + cur.g0; /* exact alpha_s, read on the guard path only */
+          const uint4* __restrict__ src = cur.src;
+          constexpr uint32_t B = 64 * VOTE_UNROLL; /* records per batch */
+          const uint32_t nfull = c / B;
+          ops += 2ull * 64u * ((c + 63u) / 64u) * (uint32_t)nh;
+          /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
+           * flight while batch b is voted for every hit of the item.  The prefetch is unconditional
+           * (the last one re-reads the final batch): a conditional one would merge two control-flow
+           * paths and force the compiler into a vmcnt that also waits for the prefetch. */
+          uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
+          if (nfull) {
+            ea[0] = cur.rec0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y = __shfl_up(incl, o);
-      if (lane >= o) incl += y;
-    }
-    if (lane == 63) red[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
+            for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = src[u * 64 + lane];
+          }
+          uint32_t b = 0;
+          while (b < nfull) {
+            load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
+            vote_hits<VOTE_UNROLL>(acc_base, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+            if (++b >= nfull) break;
+            load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
+            vote_hits<VOTE_UNROLL>(acc_base, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+            ++b;
+          }
+          const uint32_t e0 = nfull * B;
+          if (c <= 32) { /* at most 64 entries: one entry per lane (rec0 was fetched for this layout) */
+            const uint32_t e = (uint32_t)lane >> 1;
+            const uint4 rr = cur.rec0;
+            const bool second = (lane & 1) != 0;
+            const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
+            vote_hits_single(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+          } else if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
+            const uint32_t e = e0 + ((uint32_t)lane >> 1);
+            const uint4 rr = src[min(e, c - 1)];
+            const bool second = (lane & 1) != 0;
+            const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
+            vote_hits_single(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+          } else if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
 #pragma unroll
-    for (int k = 0; k < VOTE_WAVES; k++) {
-      const uint32_t w = red[k];
-      if (k < wave) woff += w;
-      total += w;
-    }
-    seg_prefix[tid] = woff + incl - items; /* exclusive */
-    if (tid < 64) seg_prefix[VOTE_SEG + tid] = total; /* sentinel + padding for the 64-wide look-ahead */
-#if PPF_VOTE_DYNAMIC
-    if (tid == 0) red[48] = VOTE_WAVES; /* next unclaimed work item (each wave starts with item == its id) */
-#endif
-    __syncthreads();
-
-    /* waves take work items round-robin; the owning run start is found with a 64-wide look-ahead
-     * from the previous one (positions that start no run in this tile have 0 items and are skipped) */
-    int h = 0;
-#if PPF_VOTE_DYNAMIC
-    /* work items are claimed from an LDS counter as waves become free (items of one segment differ by
-     * orders of magnitude in size); a wave's items still come in increasing order */
-    for (uint32_t item = wave; item < total;
-         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u))) {
-#else
-    for (uint32_t item = wave; item < total; item += VOTE_WAVES) {
-#endif
-      while (true) { /* advance h to the last position with prefix <= item */
-        const uint32_t pv = seg_prefix[min(h + 1 + lane, VOTE_SEG + 63)];
-        const unsigned long long le = __ballot(pv <= item);
-        const int adv = __popcll(le);
-        h += adv;
-        if (adv < 64) break;
-      }
-      /* the staged values are the same in every lane: move them to scalar registers so the item
-       * runs on scalar control flow and scalar base addresses */
-      const uint32_t local = item - (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_prefix[h]);
-      const uint32_t c_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_cnt[h]);
-      const uint32_t m_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_m[h]);
-      const uint32_t nchunk = (c_all + VOTE_CHUNK - 1) / VOTE_CHUNK;
-      const uint32_t sub = local / nchunk, chunk = local - sub * nchunk;
-      const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_off[h]) + chunk * VOTE_CHUNK;
-#if PPF_ABL == 6 /* diagnostic: empty work items */
-      const uint32_t c = 0;
-#else
-      const uint32_t c = min((uint32_t)VOTE_CHUNK, c_all - chunk * VOTE_CHUNK);
-#endif
-      const int h0 = h + (int)(sub * VOTE_MAX_HITS);
-      const int nh = min((int)VOTE_MAX_HITS, h + (int)m_all - h0);
-      /* lane l holds the folded offset of hit h0+l: Ohg = A/2 + G - alpha_s*S */
-      float ohg_v = 0.f;
-      if (lane < nh) ohg_v = Og - __uint_as_float(seg_a32[h0 + lane]) * S;
-      const uint4* __restrict__ src = records + o;
-#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
-      const uint32_t cfix_v = lane < nh ? seg_a32[h0 + lane] : 0u; /* lane l: fixed-point offset of hit h0+l */
-      const uint4* __restrict__ srcf = records_f + o;
-#ifdef PPF_FORCE_EXACT
-      const uint32_t T = 0x10000u;
-#else
-      const uint32_t T = 4u;
-#endif
-      (void)ohg_v;
-#endif
-      constexpr uint32_t B = 64 * VOTE_UNROLL; /* records per batch */
-      const uint32_t nfull = c / B;
-      /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
-       * flight while batch b is voted for every hit of the item.  The prefetch is unconditional
-       * (the last one re-reads the final batch): a conditional one would merge two control-flow
-       * paths and force the compiler into a vmcnt that also waits for the prefetch. */
-      uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
-      if (nfull) load_records<VOTE_UNROLL>(ea, src, 0, lane);
-      uint32_t b = 0;
-      while (b < nfull) {
-        load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
-#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
-        vote_hits_fx<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, cfix_v, nh, &seg_a64[h0], A, T, srcf, b * B, c, lane);
-#elif PPF_ABL == 0 && PPF_VOTE_PIPE
-        vote_hits<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, ohg_v, nh, &seg_a64[h0], G2, A);
-#else
-        for (int hh = 0; hh < nh; hh++) {
-          const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
-          cast_votes<VOTE_UNROLL>(acc_bytes, ea, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
+            for (int u = 0; u < VOTE_UNROLL; u++) {
+              const uint32_t e = e0 + u * 64 + lane;
+              ea[u] = (u == 0 && e0 == 0) ? cur.rec0 : src[min(e, c - 1)];
+              if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
+            }
+            const int n_valid = (int)((c - e0 + 63) / 64);
+            /* most buckets are smaller than a batch: only the 64-record groups that hold data get
+             * their bin arithmetic, through an instantiation per group count */
+            static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
+            switch (n_valid) {
+              case 1: vote_hits<1>(acc_base, ea, 1, S, ohg_v, nh, asd, G2, A); break;
+              case 2: vote_hits<2>(acc_base, ea, 2, S, ohg_v, nh, asd, G2, A); break;
+              case 3: vote_hits<3>(acc_base, ea, 3, S, ohg_v, nh, asd, G2, A); break;
+              default: vote_hits<4>(acc_base, ea, 4, S, ohg_v, nh, asd, G2, A); break;
+            }
+          }
         }
-#endif
-        if (++b >= nfull) break;
-        load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
-#if PPF_ABL == 0 && PPF_VOTE_PIPE && PPF_VOTE_FIXED
-        vote_hits_fx<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, cfix_v, nh, &seg_a64[h0], A, T, srcf, b * B, c, lane);
-#elif PPF_ABL == 0 && PPF_VOTE_PIPE
-        vote_hits<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, ohg_v, nh, &seg_a64[h0], G2, A);
-#else
-        for (int hh = 0; hh < nh; hh++) {
-          const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
-          cast_votes<VOTE_UNROLL>(acc_bytes, eb, VOTE_UNROLL, S, Ohg, &seg_a64[h0 + hh], G2, A);
-        }
-#endif
-        ++b;
-      }
-      const uint32_t e0 = nfull * B;
-#if PPF_ABL == 0 && PPF_VOTE_PIPE
-      if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
-        const uint32_t e = e0 + ((uint32_t)lane >> 1);
-        const uint4 r = src[min(e, c - 1)];
-        const bool second = (lane & 1) != 0;
-        const uint32_t row_bytes = e < c ? (second ? r.y : r.x) : tail_bytes;
-#if PPF_VOTE_FIXED
-        const uint4 rf = srcf[min(e, c - 1)];
-        vote_hits_single_fx(acc_bytes, row_bytes, second ? r.w : r.z, second ? rf.w : rf.z, cfix_v, nh, &seg_a64[h0], A, T);
-#else
-        vote_hits_single(acc_bytes, row_bytes, second ? r.w : r.z, S, ohg_v, nh, &seg_a64[h0], G2, A);
-#endif
-      } else
-#endif
-      if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
-#pragma unroll
-        for (int u = 0; u < VOTE_UNROLL; u++) {
-          const uint32_t e = e0 + u * 64 + lane;
-          ea[u] = src[min(e, c - 1)];
-          if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
-        }
-        const int n_valid = (int)((c - e0 + 63) / 64);
-#if PPF_ABL == 0 && PPF_VOTE_PIPE
-        /* most buckets are smaller than a batch (median 18 records): only the 64-record groups that hold data get
-         * their bin arithmetic, through an instantiation per group count */
-        static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
-#if PPF_VOTE_FIXED
-        switch (n_valid) {
-          case 1: vote_hits_fx<1>(acc_bytes, ea, 1, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
-          case 2: vote_hits_fx<2>(acc_bytes, ea, 2, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
-          case 3: vote_hits_fx<3>(acc_bytes, ea, 3, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
-          default: vote_hits_fx<4>(acc_bytes, ea, 4, cfix_v, nh, &seg_a64[h0], A, T, srcf, e0, c, lane); break;
-        }
-#else
-        switch (n_valid) {
-          case 1: vote_hits<1>(acc_bytes, ea, 1, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
-          case 2: vote_hits<2>(acc_bytes, ea, 2, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
-          case 3: vote_hits<3>(acc_bytes, ea, 3, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
-          default: vote_hits<4>(acc_bytes, ea, 4, S, ohg_v, nh, &seg_a64[h0], G2, A); break;
-        }
-#endif
-#else
-        for (int hh = 0; hh < nh; hh++) {
-          const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
-          cast_votes<VOTE_UNROLL>(acc_bytes, ea, n_valid, S, Ohg, &seg_a64[h0 + hh], G2, A);
-        }
-#endif
+        cur = nxt;
+        have = have_next;
       }
     }
   }
@@ -1100,12 +1131,15 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       if (v > bv) { bv = v; bi = (uint32_t)(ref * A + bin); }
     }
   }
+  unsigned long long wops = (unsigned long long)agg_votes; /* summed over the lanes below; the uniform part is added once */
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t v2 = __shfl_down(bv, o), i2 = __shfl_down(bi, o);
     sum += __shfl_down(sum, o);
+    wops += __shfl_down(wops, o);
     if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
   }
+  wops += ops;
   uint32_t* red_v = seg_prefix; /* staging arrays are free now */
   uint32_t* red_i = seg_prefix + VOTE_WAVES;
   __syncthreads();
@@ -1122,9 +1156,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     if (lane == 0) a.partial[(size_t)rg * a.n_tiles + tile] = make_uint2(v, ix);
   }
   if (lane == 0 && sum) atomicAdd(&a.cellsum[(size_t)rg * a.n_tiles + tile], sum);
+  if (lane == 0 && wops) atomicAdd(&a.tally[0], wops);
 }
 
-/* fixed LDS of k_vote: header + hit staging (the guard and the cells are sized per model) */
-constexpr size_t VOTE_LDS_FIXED = LDS_HEADER + (size_t)(VOTE_SEG + 64) * 4 + (size_t)VOTE_SEG * 4 * 4 + (size_t)VOTE_SEG * 8;
+/* fixed LDS of k_vote: header + run staging + per-wave count tables (the guard and the cells are sized per model) */
+constexpr size_t VOTE_LDS_FIXED = LDS_HEADER + (size_t)(RUN_SEG + 64) * 4 + (size_t)RUN_SEG * 4 * 4 + (size_t)VOTE_WAVES * AGG_SCRATCH;
 
 #endif /* PPF_MATCH_KERNELS_H */

@@ -356,14 +356,13 @@ ppf_status ppf_match_clouds(const ppf_model* m, const ppf_cloud* scene, const pp
   if (!n_out) return fail(PPF_ERR_INVALID, "ppf_match_clouds: n_out is NULL");
   *n_out = 0;
   if (!scene) return fail(PPF_ERR_INVALID, "ppf_match_clouds: scene is NULL");
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_clouds: no HIP device (this engine has no CPU fallback)");
   ppf_status s = check_match_args(m, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params);
   if (s != PPF_OK) return s;
-  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_clouds: no HIP device (this engine has no CPU fallback)");
   ppf_workspace ws;
   s = ppf_match_device(m, &ws, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params, nullptr);
   if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
-  for (auto& e : ws.ev)
-    if (e) (void)hipEventDestroy(e);
   return s;
 }
 

@@ -174,7 +174,8 @@ class PPF3DDetector:
         if self._model is None:
             raise PPFError(_capi.PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training")
 
-    def _params(self, step, dist, presampled, ref_offset=0, ref_stride=1, skip_clustering=False) -> MatchParams:
+    def _params(self, step, dist, presampled, ref_offset=0, ref_stride=1, skip_clustering=False,
+                vote_mode: int = 0) -> MatchParams:
         mp = MatchParams()
         lib().ppf_default_match_params(C.byref(mp))
         mp.relative_scene_sample_step = float(step)
@@ -185,6 +186,7 @@ class PPF3DDetector:
         mp.presampled = int(presampled)
         mp.ref_offset, mp.ref_stride = int(ref_offset), int(ref_stride)
         mp.skip_clustering = int(skip_clustering)
+        mp.vote_mode = int(vote_mode)  # 0: count tables for runs of many hits, 1: one atomic per (entry, hit)
         return mp
 
     def match(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
@@ -212,13 +214,15 @@ class PPF3DDetector:
 
     def raw_votes(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
                   relativeSceneDistance: float = 0.03, *, presampled: bool = False,
-                  edge: Optional[np.ndarray] = None, ref_offset: int = 0, ref_stride: int = 1) -> dict:
+                  edge: Optional[np.ndarray] = None, ref_offset: int = 0, ref_stride: int = 1,
+                  vote_mode: int = 0) -> dict:
         """Per-reference-point argmax triples {refIndMax, alphaIndMax, maxVotes} + raw poses +
         exact counters: the bit-exact parity surface."""
         self._require_trained()
         sc = _cloud(scene, "scene")
         ed = _cloud(edge, "edge") if edge is not None else None
-        mp = self._params(relativeSceneSampleStep, relativeSceneDistance, presampled, ref_offset, ref_stride, True)
+        mp = self._params(relativeSceneSampleStep, relativeSceneDistance, presampled, ref_offset, ref_stride, True,
+                          vote_mode)
         cap = sc.shape[0] + 8
         votes = (Vote * cap)()
         poses = (Pose * cap)()
@@ -236,12 +240,12 @@ class PPF3DDetector:
                 "stats": self.last_stats}
 
     def accumulators(self, scene: np.ndarray, relativeSceneSampleStep: float, *, edge: Optional[np.ndarray] = None,
-                     ref_offset: int = 0, ref_stride: int = 1) -> np.ndarray:
+                     ref_offset: int = 0, ref_stride: int = 1, vote_mode: int = 0) -> np.ndarray:
         """Full Hough accumulators (n_ref, N_m, numAngles) of presampled clouds (debug / parity)."""
         self._require_trained()
         sc = _cloud(scene, "scene")
         ed = _cloud(edge, "edge") if edge is not None else None
-        mp = self._params(relativeSceneSampleStep, 0.05, True, ref_offset, ref_stride, True)
+        mp = self._params(relativeSceneSampleStep, 0.05, True, ref_offset, ref_stride, True, vote_mode)
         mi = self.info()
         step = int(1.0 / relativeSceneSampleStep)
         n_tot = (sc.shape[0] + step - 1) // step

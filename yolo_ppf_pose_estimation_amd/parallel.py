@@ -66,6 +66,34 @@ def gather_poses(local: np.ndarray, device=None):
     return out.cpu().numpy().reshape((world,) + tuple(t.shape))
 
 
+def gather_device(block, dist=None):
+    """all_gather of a device tensor block (rows = pose records as float64 words) without leaving HBM: every rank
+    contributes the same shape; returns (world * rows, words) on the device (RCCL under backend "nccl").  With the
+    gloo rehearsal backend the block travels through the host."""
+    import torch
+    import torch.distributed as tdist
+
+    d = dist or tdist
+    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+        return block
+    world = d.get_world_size()
+    if d.get_backend() != "nccl":
+        host = block.cpu()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        d.all_gather_into_tensor(out, host)
+        return out.to(block.device)
+    out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    d.all_gather_into_tensor(out, block)
+    return out
+
+
+def merge_reference_shards_device(gathered, world: int, n_total: int):
+    """Device twin of merge_reference_shards: `gathered` is (world * per_rank, words) from gather_device, rank r's block
+    holding reference points r, r + world, ...; returns the first n_total rows in reference-point order, contiguous."""
+    per = gathered.shape[0] // world
+    return gathered.view(world, per, gathered.shape[1]).transpose(0, 1).reshape(per * world, gathered.shape[1])[:n_total].contiguous()
+
+
 def merge_reference_shards(shards: Sequence[np.ndarray]) -> np.ndarray:
     """Interleave per-rank blocks of per-reference records (rank r holds reference points r, r+world, ...)
     back into reference-point order."""
