@@ -79,6 +79,13 @@ class DevPool {
     static DevPool* p = new DevPool(); /* never destroyed: no hipFree after the runtime is gone */
     return *p;
   }
+  /* size classes: 8 per octave (1, 1.125, ... 1.875 x 2^k), so a block wastes at most 12.5 % of what was asked for */
+  static size_t class_size(int cls) { return ((size_t)8 + (size_t)(cls & 7)) << (cls >> 3); }
+  static int class_of(size_t bytes) {
+    int cls = 5 * 8; /* 256 B */
+    while (class_size(cls) < bytes) cls++;
+    return cls;
+  }
   hipError_t acquire(size_t bytes, void** out, size_t* granted, int* device) {
     *out = nullptr;
     const size_t want = std::max<size_t>(bytes, 256);
@@ -87,14 +94,13 @@ class DevPool {
     if (e != hipSuccess) return e;
     *device = dev; /* a block goes back to the list of the device it was allocated on, whatever is current then */
     if (off_) { *granted = want; return hipMalloc(out, want); }
-    int cls = 8;
-    while (((size_t)1 << cls) < want) cls++;
+    const int cls = class_of(want);
     {
       std::lock_guard<std::mutex> g(mu_);
       auto& lst = free_[key(dev, cls)];
-      if (!lst.empty()) { *out = lst.back(); lst.pop_back(); *granted = (size_t)1 << cls; return hipSuccess; }
+      if (!lst.empty()) { *out = lst.back(); lst.pop_back(); *granted = class_size(cls); return hipSuccess; }
     }
-    *granted = (size_t)1 << cls;
+    *granted = class_size(cls);
     e = hipMalloc(out, *granted);
     if (e != hipSuccess) { /* out of memory: drop the cache and retry once */
       trim();
@@ -105,8 +111,7 @@ class DevPool {
   void release(void* p, size_t granted, int dev) {
     if (!p) return;
     if (off_) { (void)hipFree(p); return; }
-    int cls = 8;
-    while (((size_t)1 << cls) < granted) cls++;
+    const int cls = class_of(granted);
     std::lock_guard<std::mutex> g(mu_);
     free_[key(dev, cls)].push_back(p);
   }
@@ -120,7 +125,7 @@ class DevPool {
 
  private:
   DevPool() : off_(getenv("PPF_NO_POOL") != nullptr) {}
-  static int key(int dev, int cls) { return dev * 64 + cls; }
+  static int key(int dev, int cls) { return dev * 1024 + cls; }
   std::mutex mu_;
   std::map<int, std::vector<void*>> free_;
   bool off_;
@@ -149,7 +154,16 @@ struct DevBuf {
     if (e == hipSuccess) { p = static_cast<T*>(q); cap = n; }
     return e;
   }
-  size_t bytes() const { return cap * sizeof(T); }
+  /* like reserve, but a block more than twice as big as needed (and above 16 MiB) is traded for a fitting one: the hit
+   * pools of a workspace shrink again after an unusually dense scene */
+  hipError_t fit(size_t n) {
+    if (p && granted > ((size_t)16 << 20) && granted > 2 * std::max<size_t>(n, 1) * sizeof(T)) {
+      sync_device_of_block(device);
+      DevPool::get().release(p, granted, device); p = nullptr; cap = 0; granted = 0;
+    }
+    return reserve(n);
+  }
+  size_t bytes() const { return granted; }
 };
 
 void sync_device(int dev);
@@ -1145,7 +1159,7 @@ struct ppf_workspace {
   DevBuf<unsigned long long> work;
   DevBuf<uint32_t> perm;
   DevBuf<uint32_t> perm_group;
-  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[2] */
+  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[4] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
   DevBuf<ppf_pose> d_final;
@@ -1169,7 +1183,9 @@ struct ppf_workspace {
   bool has_edge = false;
   double hit_frac = 0.25;                /* expected hits per scene pair: sizes the hit pools, learned from every call */
   bool frac_known = false;               /* false: the next call first COUNTS its hits (one extra pair pass and one wait) */
-  std::vector<std::pair<const ppf_model*, double>> frac_by_model; /* hit_frac remembered per model (batches alternate models) */
+  double run_frac = 0.4;                 /* expected runs (distinct buckets hit by a reference point) per hit, learned likewise */
+  struct Learned { const ppf_model* model; double hit, run; };
+  std::vector<Learned> frac_by_model;    /* the two fractions remembered per model (batches alternate models) */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
   bool cluster_serial = false;           /* force the serial greedy assignment (otherwise only used above 11,520 poses) */
   int device = -1;
@@ -1649,9 +1665,9 @@ ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* 
 static void workspace_remember_frac(ppf_workspace* ws) {
   if (!ws->model || !ws->frac_known) return;
   for (auto& fm : ws->frac_by_model)
-    if (fm.first == ws->model) { fm.second = ws->hit_frac; return; }
+    if (fm.model == ws->model) { fm.hit = ws->hit_frac; fm.run = ws->run_frac; return; }
   if (ws->frac_by_model.size() >= 16) ws->frac_by_model.erase(ws->frac_by_model.begin());
-  ws->frac_by_model.emplace_back(ws->model, ws->hit_frac);
+  ws->frac_by_model.push_back({ws->model, ws->hit_frac, ws->run_frac});
 }
 
 /* the workspace keeps the model alive until its next call (or its destruction): results are fetched later */
@@ -1686,7 +1702,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     workspace_remember_frac(ws);
     bool found = false;
     for (auto& fm : ws->frac_by_model)
-      if (fm.first == m) { ws->hit_frac = fm.second; found = true; }
+      if (fm.model == m) { ws->hit_frac = fm.hit; ws->run_frac = fm.run; found = true; }
     if (found) ws->frac_known = true;
     else if (!ws->frac_by_model.empty()) ws->frac_known = false; /* a model this workspace has not met: count first */
   }
@@ -1716,7 +1732,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
 
   const int T = m->info.n_tiles;
   HIPCHK(ws->partial.reserve((size_t)n_ref * T));
-  const size_t n_cnt = (size_t)n_ref * T + n_ref + 4;
+  const size_t n_cnt = (size_t)n_ref * T + n_ref + 6; /* cellsum | pairs | totals[2] | tally[4]: LDS operations, hits, runs, - */
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
   HIPCHK(ws->raw_poses.reserve(n_ref));
@@ -1792,14 +1808,14 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   const uint32_t stripe_cap = worst_case ? (uint32_t)std::min<double>(4.0e9 / n_stripes, (double)batch * va.pair_chunks * wg_hits)
                                          : (uint32_t)(est / n_stripes * 1.04) + 2 * wg_hits;
   const uint32_t sorted_cap = (uint32_t)std::min(4.0e9, est + 4096.0);
-  const uint32_t run_cap = worst_case ? sorted_cap : (uint32_t)std::min<double>((double)sorted_cap, std::max(est / 6.0, 64.0 * batch) + 1024.0);
+  const uint32_t run_cap = worst_case ? sorted_cap : (uint32_t)std::min<double>((double)sorted_cap, std::max(est * std::min(1.0, ws->run_frac), 64.0 * batch) + 1024.0);
   HIPCHK(ws->frames.reserve((size_t)batch * 12));
-  HIPCHK(ws->raw.reserve((size_t)stripe_cap * n_stripes));
+  HIPCHK(ws->raw.fit((size_t)stripe_cap * n_stripes));
   HIPCHK(ws->chunk_desc.reserve((size_t)batch * va.pair_chunks));
   HIPCHK(ws->hit_count.reserve(batch));
-  HIPCHK(ws->s_a64.reserve(sorted_cap));
-  HIPCHK(ws->s_cell.reserve(sorted_cap));
-  HIPCHK(ws->runs.reserve(run_cap));
+  HIPCHK(ws->s_a64.fit(sorted_cap));
+  HIPCHK(ws->s_cell.fit(sorted_cap));
+  HIPCHK(ws->runs.fit(run_cap));
   HIPCHK(ws->run_blocks.reserve((size_t)batch * va.n_rounds));
   HIPCHK(ws->work.reserve(batch));
   HIPCHK(ws->perm.reserve(batch));
@@ -1896,7 +1912,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
   if (ws->checked || ws->n_ref == 0) { ws->checked = true; return PPF_OK; }
   for (;;) {
     const int T = ws->model->info.n_tiles;
-    unsigned long long tot[4];
+    unsigned long long tot[5];
     uint32_t ovf = 0;
     HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
@@ -1906,6 +1922,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->stats.n_lds_atomics = tot[2];
       ws->stats.n_hits = tot[3];
       if (tot[1]) ws->hit_frac = std::min(1.0, std::max(1e-3, 1.06 * (double)tot[3] / (double)tot[1]));
+      if (tot[3]) ws->run_frac = std::min(1.0, std::max(0.02, 1.10 * (double)tot[4] / (double)tot[3]));
       ws->frac_known = true;
       if (ws->clustered) {
         uint32_t nf = 0;
@@ -1928,7 +1945,8 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       return PPF_OK;
     }
     if (ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
-    ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0);
+    if (ovf & 3u) ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0); /* raw or sorted hit pool */
+    if (ovf & 4u) ws->run_frac = std::min(1.0, ws->run_frac * 2.0); /* run table */
     ws->stats.n_retries++;
     const ppf_match_params p = ws->params;
     ppf_model* m = ws->model;
@@ -2055,7 +2073,7 @@ __global__ __launch_bounds__(256) void k_pose_block(const ppf_pose* __restrict__
     reinterpret_cast<unsigned long long*>(dst)[i] = row < n ? s64[i] : 0ull;
   }
   if (i == 0 && meta_out) { meta_out[0] = (uint32_t)n; meta_out[1] = flag_in ? *flag_in : 0u; }
-  if (i < 4 && tot_out && tot_in) tot_out[i] = tot_in[i];
+  if (i < 5 && tot_out && tot_in) tot_out[i] = tot_in[i]; /* votes, pairs, LDS operations, hits, runs */
 }
 
 ppf_status ppf_workspace_copy_top_poses(ppf_workspace* ws, void* d_dst, int k, void* stream) {
@@ -2242,7 +2260,7 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
   const size_t n_match = (size_t)n_scenes * n_models;
   HIPCHK(b->d_out.reserve(n_match * cap));
   HIPCHK(b->d_meta.reserve(n_match * 2));
-  HIPCHK(b->d_tot.reserve(n_match * 4));
+  HIPCHK(b->d_tot.reserve(n_match * 8));
   b->last_records = (int)(n_match * cap);
   const int words = cap * (int)(sizeof(ppf_pose) / 8);
 
@@ -2256,13 +2274,13 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
     if (ws->n_ref == 0) {
       HIPCHK(hipMemsetAsync(b->d_out.p + idx * cap, 0, (size_t)cap * sizeof(ppf_pose), st));
       HIPCHK(hipMemsetAsync(b->d_meta.p + idx * 2, 0, 2 * sizeof(uint32_t), st));
-      HIPCHK(hipMemsetAsync(b->d_tot.p + idx * 4, 0, 4 * sizeof(unsigned long long), st));
+      HIPCHK(hipMemsetAsync(b->d_tot.p + idx * 8, 0, 8 * sizeof(unsigned long long), st));
       return PPF_OK;
     }
     const unsigned long long* tot = ws->counters.p + (size_t)ws->n_ref * models[k]->info.n_tiles + ws->n_ref;
     k_pose_block<<<dim3((words + 255) / 256), dim3(256), 0, st>>>(ws->d_final.p, ws->cl_u32.p, 0, b->d_out.p + idx * cap, cap,
                                                                    b->d_meta.p + idx * 2, ws->cursors.p + CUR_OVERFLOW,
-                                                                   b->d_tot.p + idx * 4, tot);
+                                                                   b->d_tot.p + idx * 8, tot);
     HIPCHK(hipGetLastError());
     return PPF_OK;
   };
@@ -2301,7 +2319,7 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
   }
   for (int l = 0; l < b->lanes; l++) HIPCHK(hipStreamSynchronize(b->streams[l]));
   std::vector<uint32_t> meta(n_match * 2);
-  std::vector<unsigned long long> tot(n_match * 4);
+  std::vector<unsigned long long> tot(n_match * 8);
   HIPCHK(hipMemcpy(meta.data(), b->d_meta.p, meta.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(tot.data(), b->d_tot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   /* learn the hit fraction per lane; repeat the matches whose pools overflowed, one at a time, with doubled pools */
@@ -2312,51 +2330,53 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
     bool staged = false;
     for (int k = 0; k < n_models; k++) {
       const size_t idx = (size_t)c * n_models + k;
-      bool at_full = false;
+      bool at_full = false; /* the match that raised the flag already ran with worst-case pools */
       while (meta[idx * 2 + 1]) {
         if (at_full) return fail(PPF_ERR_CAPACITY, "ppf_batch_run: hit pools overflowed at worst-case size");
         retries++;
         ppf_status s = PPF_OK;
         if (!staged) { s = stage_crop(lane, c, uses[lane]++); staged = true; }
         if (s != PPF_OK) return s;
-        /* pools twice what this (crop, model) match had: match_prepared looks the model's fraction up itself */
+        /* bigger pools than this (crop, model) match had (the flag says which one was short): match_prepared looks the
+         * model's fractions up itself */
         workspace_hold_model(ws, nullptr);
-        double f = 0.25;
-        for (auto& fm : ws->frac_by_model)
-          if (fm.first == models[k]) f = fm.second;
-        f = std::min(1.0, 2.0 * f);
-        at_full = f >= 1.0;
-        bool found = false;
-        for (auto& fm : ws->frac_by_model)
-          if (fm.first == models[k]) { fm.second = f; found = true; }
-        if (!found) ws->frac_by_model.emplace_back(models[k], f);
+        ppf_workspace::Learned* fm = nullptr;
+        for (auto& e : ws->frac_by_model)
+          if (e.model == models[k]) fm = &e;
+        if (!fm) { ws->frac_by_model.push_back({models[k], 0.25, 0.4}); fm = &ws->frac_by_model.back(); }
+        const uint32_t flags = meta[idx * 2 + 1];
+        at_full = fm->hit >= 1.0;
+        if (flags & 3u) fm->hit = std::min(1.0, 2.0 * fm->hit);
+        if (flags & 4u) fm->run = std::min(1.0, 2.0 * fm->run);
         s = enqueue_pair(lane, c, k);
         if (s != PPF_OK) return s;
         HIPCHK(hipStreamSynchronize(b->streams[lane]));
         HIPCHK(hipMemcpy(&meta[idx * 2], b->d_meta.p + idx * 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&tot[idx * 4], b->d_tot.p + idx * 4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&tot[idx * 8], b->d_tot.p + idx * 8, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       }
     }
   }
   /* what every lane remembers per model: the densest crop it saw */
-  std::vector<double> lane_frac((size_t)b->lanes * n_models, 0.0);
+  std::vector<double> lane_hit((size_t)b->lanes * n_models, 0.0), lane_run((size_t)b->lanes * n_models, 0.0);
   ppf_batch_stats st{};
   for (size_t idx = 0; idx < n_match; idx++) {
-    st.n_votes += tot[idx * 4 + 0]; st.n_pairs += tot[idx * 4 + 1]; st.n_lds_atomics += tot[idx * 4 + 2]; st.n_hits += tot[idx * 4 + 3];
+    const unsigned long long* t = &tot[idx * 8];
+    st.n_votes += t[0]; st.n_pairs += t[1]; st.n_lds_atomics += t[2]; st.n_hits += t[3];
     const size_t slot = (size_t)((idx / n_models) % b->lanes) * n_models + idx % n_models;
-    if (tot[idx * 4 + 1]) lane_frac[slot] = std::max(lane_frac[slot], (double)tot[idx * 4 + 3] / (double)tot[idx * 4 + 1]);
+    if (t[1]) lane_hit[slot] = std::max(lane_hit[slot], (double)t[3] / (double)t[1]);
+    if (t[3]) lane_run[slot] = std::max(lane_run[slot], (double)t[4] / (double)t[3]);
   }
   for (int l = 0; l < b->lanes; l++) {
     ppf_workspace* ws = b->ws[l];
     workspace_hold_model(ws, nullptr); /* the next call looks its model up */
     for (int k = 0; k < n_models; k++) {
-      const double f = lane_frac[(size_t)l * n_models + k];
-      if (!(f > 0)) continue;
-      const double learned = std::min(1.0, std::max(1e-3, 1.06 * f));
+      const double fh = lane_hit[(size_t)l * n_models + k], fr = lane_run[(size_t)l * n_models + k];
+      if (!(fh > 0)) continue;
+      const double hit = std::min(1.0, std::max(1e-3, 1.06 * fh)), run = std::min(1.0, std::max(0.02, 1.10 * fr));
       bool found = false;
       for (auto& fm : ws->frac_by_model)
-        if (fm.first == models[k]) { fm.second = learned; found = true; }
-      if (!found) ws->frac_by_model.emplace_back(models[k], learned);
+        if (fm.model == models[k]) { fm.hit = hit; fm.run = run; found = true; }
+      if (!found) ws->frac_by_model.push_back({models[k], hit, run});
     }
   }
   if (out) HIPCHK(hipMemcpy(out, b->d_out.p, n_match * cap * sizeof(ppf_pose), hipMemcpyDeviceToHost));

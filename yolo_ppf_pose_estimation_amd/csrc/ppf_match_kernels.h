@@ -208,7 +208,7 @@ struct MatchArgs {
   uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
-  unsigned long long* tally;    /* [2] LDS atomic lane-operations issued by k_vote, hits grouped by k_group */
+  unsigned long long* tally;    /* [3] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group */
   uint32_t* acc_dump;           /* optional [n_ref_all][n_model*num_angles] full accumulators (debug/tests) */
 };
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const uint32_t n_list = ok ? n_raw : 0u;
   const uint32_t n_cache = (uint32_t)a.group_cache;
   unsigned long long w = 0;
-  uint32_t placed = 0;
+  uint32_t placed = 0, runs_written = 0;
   for (int round = 0; round < a.n_rounds; round++) {
     const uint32_t b0 = (uint32_t)round * (uint32_t)a.round_buckets;
     const uint32_t nb = min((uint32_t)a.round_buckets, (uint32_t)a.n_buckets - b0);
@@ -507,6 +507,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
       }
     }
     placed += nh;
+    runs_written += nH + nL;
     __syncthreads();
   }
 #pragma unroll
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     for (int k = 0; k < GROUP_BLOCK / 64; k++) t += wsum[k];
     a.work[r] = t;
     atomicAdd(&a.tally[1], (unsigned long long)placed);
+    atomicAdd(&a.tally[2], (unsigned long long)runs_written);
   }
 }
 
