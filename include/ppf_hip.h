@@ -81,8 +81,12 @@ typedef struct ppf_train_params {
   int32_t distance_from_distance_step; /* 0 (default): distance step = diameter*relative_sampling_step,
                                           as the reference's library computes it; 1: use relative_distance_step */
   int32_t max_tile_refs;          /* 0 = auto: model reference points per LDS accumulator tile */
-  int32_t reserved;
+  int32_t key_equality;           /* PPF_KEY_BUCKET (0, the reference's library): a scene pair votes for every model pair
+                                     in its hash bucket, colliding keys included; PPF_KEY_EXACT (1, PCL PPFHashMapSearch):
+                                     only for model pairs with the same quantised key */
 } ppf_train_params;
+#define PPF_KEY_BUCKET 0
+#define PPF_KEY_EXACT 1
 
 typedef struct ppf_match_params {
   double relative_scene_sample_step; /* match() arg 3: every (int)(1/x)-th sampled scene point is a reference */
@@ -96,6 +100,12 @@ typedef struct ppf_match_params {
   int32_t skip_clustering;           /* 1: stop after per-reference poses */
   int32_t vote_mode;                 /* PPF_VOTE_AUTO (0): runs of many hits vote through per-run count tables;
                                         PPF_VOTE_DIRECT (1): every (entry, hit) pair casts its own atomic.  Same results. */
+  /* PCL-semantics policy switches (pcl::PPFRegistration; zero = what the reference's library does) */
+  double pair_radius;                /* > 0: a reference point is only paired with points at most this far away (PCL searches
+                                        model_diameter / 2 around it); <= 0: with every point */
+  int32_t rot_metric_relative;       /* 1: poses cluster when the angle of their RELATIVE rotation is below
+                                        rotation_threshold (PCL); 0: when their rotation angles differ by less (OpenCV) */
+  int32_t reserved;
 } ppf_match_params;
 #define PPF_VOTE_AUTO 0
 #define PPF_VOTE_DIRECT 1

@@ -27,8 +27,10 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -59,6 +61,18 @@ inline void check(ppf_status st) {
   ppf_last_error(buf, (int)sizeof(buf));
   throw Error(st, buf);
 }
+
+namespace detail {
+/* row pitch in floats: cols for the facade's own Mat; step1() (and a CV_32FC1 check) for cv::Mat, so that a
+ * non-continuous view (a column range, a row stride) is read correctly and a double Mat is refused */
+template <class M> inline int stride_of(const M& m) { return m.cols; }
+#ifdef PPF_MATCH_3D_HAVE_OPENCV
+inline int stride_of(const cv::Mat& m) {
+  if (m.depth() != CV_32F || m.channels() != 1) throw Error(PPF_ERR_INVALID, "expected a CV_32FC1 cloud (N x 6 float32)");
+  return (int)m.step1();
+}
+#endif
+}  // namespace detail
 
 /* Minimal float32 matrix with the accessors the reference uses on cv::Mat for point clouds. */
 class Mat {
@@ -182,11 +196,52 @@ class PPF3DDetector {
     ppf_model_info info;
     check(ppf_model_get_info(model_, &info));
   }
+#ifdef PPF_MATCH_3D_HAVE_OPENCV
+  /* The reference's own calls (CloudProcessing.h:111-113, 249-251):
+   *     cv::FileStorage fsOut(file, cv::FileStorage::WRITE); detector.write(fsOut); fsOut.release();
+   *     cv::FileStorage fsLoad(file, cv::FileStorage::READ); cv::FileNode fn = fsLoad.root(); detector.read(fn);
+   * The table travels inside the storage as one CV_8U row under the key "ppf_hip_model" (the bytes of the binary table
+   * file); read() validates them like any other model file. */
+  void write(cv::FileStorage& fs) const {
+    require_trained();
+    const std::string tmp = temp_name();
+    check(ppf_model_save(model_, tmp.c_str()));
+    std::ifstream in(tmp.c_str(), std::ios::binary);
+    std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    in.close();
+    std::remove(tmp.c_str());
+    if (bytes.empty()) throw Error(PPF_ERR_IO, "write(FileStorage): could not serialise the model");
+    cv::Mat blob(1, (int)bytes.size(), CV_8U, bytes.data());
+    fs << "ppf_hip_model" << blob;
+  }
+  void read(const cv::FileNode& fn) {
+    cv::Mat blob;
+    fn["ppf_hip_model"] >> blob;
+    if (blob.empty() || blob.depth() != CV_8U) throw Error(PPF_ERR_IO, "read(FileNode): no ppf_hip_model entry in this storage");
+    const std::string tmp = temp_name();
+    {
+      std::ofstream out(tmp.c_str(), std::ios::binary);
+      for (int r = 0; r < blob.rows; r++) out.write(reinterpret_cast<const char*>(blob.ptr<unsigned char>(r)), (std::streamsize)blob.cols);
+    }
+    try {
+      read(tmp);
+    } catch (...) {
+      std::remove(tmp.c_str());
+      throw;
+    }
+    std::remove(tmp.c_str());
+  }
+#endif
   ppf_model_info info() const { require_trained(); ppf_model_info i; check(ppf_model_get_info(model_, &i)); return i; }
   const ppf_model* handle() const { return model_; }
 
  private:
-  template <class M> static int stride_of(const M& m) { return m.cols; }
+  static std::string temp_name() {
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "/tmp/ppf_hip_model_%p_%ld.bin", (void*)&buf, (long)std::rand());
+    return buf;
+  }
+  template <class M> static int stride_of(const M& m) { return detail::stride_of(m); }
   template <class M> static void require_cloud(const M& m, const char* who) {
     if (m.rows <= 0 || m.cols < 6) throw Error(PPF_ERR_INVALID, std::string(who) + ": expected an N x 6 float32 cloud (x y z nx ny nz)");
   }
@@ -235,7 +290,7 @@ class ICP {
   /* one registration from the identity: returns 0, fills residual and the 4x4 src -> dst */
   template <class M> int registerModelToScene(const M& srcPC, const M& dstPC, double& residual, Matx44d& pose) {
     require_cloud(srcPC); require_cloud(dstPC);
-    check(ppf_icp_register(srcPC.template ptr<float>(0), srcPC.rows, srcPC.cols, dstPC.template ptr<float>(0), dstPC.rows, dstPC.cols,
+    check(ppf_icp_register(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC),
                            &prm_, pose.data(), &residual, nullptr));
     return 0;
   }
@@ -251,7 +306,7 @@ class ICP {
       std::memcpy(r.t, p.t, sizeof(r.t));
       r.angle = p.angle; r.alpha = p.alpha; r.residual = p.residual; r.model_index = p.modelIndex; r.num_votes = p.numVotes;
     }
-    check(ppf_icp_refine(srcPC.template ptr<float>(0), srcPC.rows, srcPC.cols, dstPC.template ptr<float>(0), dstPC.rows, dstPC.cols, &prm_,
+    check(ppf_icp_refine(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC), &prm_,
                          recs.data(), (int)recs.size(), nullptr));
     for (size_t i = 0; i < poses.size(); i++) *poses[i] = Pose3D(recs[i]);
     return 0;

@@ -15,11 +15,13 @@
  *     reg.setSearchMethod(search); reg.setInputSource(model); reg.setInputTarget(scene);
  *     reg.align(output);  reg.getFinalTransformation();
  *
- * SEMANTICS (stated, not hidden): the engine underneath implements the voting scheme of the library the reference
- * really uses (Drost et al. as in OpenCV's surface_matching).  It differs from PCL's ppf_registration in details
- * that change individual vote counts but not the method: buckets are addressed by hash slot without key
- * equality, alpha differences are binned over 4*pi, every scene point is paired with every reference point (no
- * kd-tree radius), clusters compare absolute rotation angles.  Point types only need members
+ * SEMANTICS (stated, not hidden): these classes switch the engine's PCL policy flags on -- the model table is keyed
+ * on the exact quantised feature (ppf_train_params.key_equality = PPF_KEY_EXACT, PPFHashMapSearch's hash map with
+ * key equality), a reference point is paired with the scene points within model_diameter / 2
+ * (ppf_match_params.pair_radius, PPFRegistration's kd-tree radius search), and poses cluster on the angle of their
+ * relative rotation (rot_metric_relative).  What remains of the library the reference really uses (OpenCV's
+ * surface_matching): the three acos angles as pair feature instead of PCL's Darboux-frame angles, and alpha
+ * differences binned over 4*pi.  Both change individual vote counts, not the method.  Point types only need members
  * x, y, z, normal_x, normal_y, normal_z (pcl::PointNormal qualifies); clouds only need `.points` or to be a
  * std::vector of such points.  Compiles without PCL and without Eigen.
  */
@@ -111,6 +113,7 @@ class PPFHashMapSearch {
     ppf_train_params tp;
     ppf_default_train_params(&tp);
     tp.presampled = 1;
+    tp.key_equality = PPF_KEY_EXACT; /* nearestNeighborSearch() returns the model pairs with the SAME quantised feature */
     tp.distance_from_distance_step = 1;
     tp.relative_distance_step = dist_step_ / diameter_;
     tp.relative_sampling_step = tp.relative_distance_step; /* only feeds the default clustering threshold */
@@ -154,6 +157,8 @@ class PPFRegistration {
     mp.relative_scene_sample_step = 1.0 / (double)rate_;
     mp.position_threshold = pos_thr_;
     mp.rotation_threshold = rot_thr_;
+    mp.pair_radius = 0.5 * (double)search_->getModelDiameter(); /* the radius search of computeTransformation() */
+    mp.rot_metric_relative = 1;                                 /* posesWithinErrorBounds(): angle of the relative rotation */
     const int n = (int)(scene_rows_.size() / 6);
     std::vector<ppf_pose> out((size_t)n / rate_ + 8);
     int n_out = 0;

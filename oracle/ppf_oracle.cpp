@@ -282,6 +282,17 @@ struct Model {
   std::vector<HashNode> list_nodes;
   bool trained = false;
   int mode = 0;
+  /* PCL-semantics policy switches (closing paragraph; off = the OpenCV behaviour the reference uses):
+   *   key_exact     PPFHashMapSearch::nearestNeighborSearch compares the quantised key, the OpenCV table walks a whole
+   *                 hash bucket
+   *   pair_radius   PPFRegistration pairs a reference point only with scene points within a radius (kd-tree search of
+   *                 model_diameter / 2); <= 0: every point
+   *   rot_relative  PPFRegistration::posesWithinErrorBounds tests the angle of the RELATIVE rotation of two poses,
+   *                 OpenCV the difference of their rotation angles */
+  bool key_exact = false;
+  double pair_radius = 0.0;
+  bool rot_relative = false;
+  std::vector<int32_t> pair_key; /* N^2 x 4: quantised key of every model pair */
 };
 
 /* upstream PPF3DDetector ctor + setSearchParams() defaults. */
@@ -319,6 +330,7 @@ void trainModel(Model& m, const float* pc, int n, int stride, int flags) {
   m.bucket_head.assign(m.slots, -1);
   m.ppf.assign(NN * 5, 0.f);
   m.hash_nodes.assign(NN, THash{0, 0, 0});
+  m.pair_key.assign(NN * 4, 0);
   m.list_nodes.clear();
   m.list_nodes.reserve(NN);
   const float* S = m.sampled_pc.data();
@@ -329,9 +341,9 @@ void trainModel(Model& m, const float* pc, int n, int stride, int flags) {
       const V3 p2 = v3(S + (size_t)j * 6), n2 = v3(S + (size_t)j * 6 + 3);
       double f[4] = {0, 0, 0, 0};
       computePPFFeatures<M>(p1, n1, p2, n2, f);
-      uint32_t hashValue = hashPPF(f, m.angle_step_radians, distanceStep);
-      double alpha = computeAlpha<M>(p1, n1, p2);
       int ppfInd = i * N + j;
+      uint32_t hashValue = hashPPF(f, m.angle_step_radians, distanceStep, &m.pair_key[(size_t)ppfInd * 4]);
+      double alpha = computeAlpha<M>(p1, n1, p2);
       m.hash_nodes[ppfInd] = THash{hashValue, i, ppfInd};
       /* hashtableInsertHashed: prepend to bucket hash % size */
       uint32_t b = hashValue % m.slots;
@@ -449,7 +461,9 @@ VoteResult voteOneRef(const Model& m, const float* surf, int /*nSurf*/, const fl
     const V3 p2 = v3(paired + (size_t)j * 6), n2 = v3(paired + (size_t)j * 6 + 3);
     double f[4] = {0, 0, 0, 0};
     computePPFFeatures<M>(p1, n1, p2, n2, f);
-    uint32_t hashValue = hashPPF(f, m.angle_step, distanceStep);
+    if (m.pair_radius > 0 && f[3] > m.pair_radius) continue; /* policy: neighbours within a radius only */
+    int32_t sceneKey[4];
+    uint32_t hashValue = hashPPF(f, m.angle_step, distanceStep, sceneKey);
     V3 rp = mulMV(Rsg, p2);
     V3 p2t{tsg.x + rp.x, tsg.y + rp.y, tsg.z + rp.z};
     double alpha_scene;
@@ -459,6 +473,7 @@ VoteResult voteOneRef(const Model& m, const float* surf, int /*nSurf*/, const fl
     while (node >= 0) {
       const HashNode& ln = m.list_nodes[node];
       const THash& tData = m.hash_nodes[ln.data];
+      if (m.key_exact && memcmp(&m.pair_key[(size_t)tData.ppfInd * 4], sceneKey, 16) != 0) { node = ln.next; continue; }
       int corrI = tData.i;
       const float* ppfCorrScene = &m.ppf[(size_t)tData.ppfInd * 5];
       double alpha_model = (double)ppfCorrScene[4];
@@ -530,8 +545,15 @@ void clusterPoses(const Model& m, std::vector<Pose>& poseList, int numPoses, std
       const Pose& c = poseList[clusters[j].members[0]];
       double dvx = c.t[0] - pose.t[0], dvy = c.t[1] - pose.t[1], dvz = c.t[2] - pose.t[2];
       double dNorm = std::sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
-      double phi = std::fabs(pose.angle - c.angle);
-      if (phi < m.rotation_threshold && dNorm < m.position_threshold) {
+      bool rotOk;
+      if (m.rot_relative) {
+        /* angle of Ra^T Rb = 2 acos(|qa . qb|) < threshold  <=>  |qa . qb| > cos(threshold / 2)  (threshold in [0, 2 pi]) */
+        const double d = std::fabs(c.q[0] * pose.q[0] + c.q[1] * pose.q[1] + c.q[2] * pose.q[2] + c.q[3] * pose.q[3]);
+        rotOk = d > M::cos_(0.5 * m.rotation_threshold);
+      } else {
+        rotOk = std::fabs(pose.angle - c.angle) < m.rotation_threshold;
+      }
+      if (rotOk && dNorm < m.position_threshold) {
         clusters[j].members.push_back(order[i]);
         clusters[j].numVotes += pose.numVotes;
         assigned = true;
@@ -688,6 +710,13 @@ void oracle_set_search_params(void* h, double positionThreshold, double rotation
   m->position_threshold = positionThreshold < 0 ? m->sampling_step_relative : positionThreshold;
   m->rotation_threshold = rotationThreshold < 0 ? ((360 / m->angle_step) / 180.0 * M_PI) : rotationThreshold;
   m->use_weighted_avg = useWeighted != 0;
+}
+
+void oracle_set_policy(void* h, int keyExact, double pairRadius, int rotRelative) {
+  Model* m = (Model*)h;
+  m->key_exact = keyExact != 0;
+  m->pair_radius = pairRadius;
+  m->rot_relative = rotRelative != 0;
 }
 
 void oracle_model_info(void* h, int* nRef, uint32_t* slots, double* angleStep, double* distanceStep, int* numAngles) {

@@ -132,3 +132,76 @@ def test_stage_wrapper_runs_the_drivers_sequence_on_the_real_frame(tmp_path, bot
     ICP(100, 0.005, 2.5, 8).registerModelToScene(ply.load_ply_simple(m), obj_mat, poses)
     assert int(res["votes"]) == poses[0].numVotes
     assert float(res["residual"]) == poses[0].residual
+
+
+OPENCV_OVERLOADS = r'''
+// The reference's own calls on cv::FileStorage / cv::FileNode (CloudProcessing.h:111-113, 249-251) and a cv::Mat view
+// whose row step is larger than its column count, through the OpenCV overloads of the facade.
+#include <cstdio>
+#include "ppf_match_3d.hpp"
+using namespace ppfhip::ppf_match_3d;
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  try {
+    ppfhip::ppf_match_3d::Mat model = loadPLYSimple(argv[1], 1), scene = loadPLYSimple(argv[2], 1);
+    // a 9-column CV_32F buffer whose first 6 columns are the cloud: step1() == 9, cols == 6
+    cv::Mat wide(scene.rows, 9, CV_32F);
+    for (int i = 0; i < scene.rows; i++) {
+      for (int k = 0; k < 6; k++) wide.ptr<float>(i)[k] = scene.ptr<float>(i)[k];
+      for (int k = 6; k < 9; k++) wide.ptr<float>(i)[k] = 1e9f;
+    }
+    cv::Mat view = wide.colRange(0, 6);
+    cv::Mat cvmodel(model.rows, 6, CV_32F, model.ptr<float>(0));
+    PPF3DDetector detector(0.05, 0.05);
+    detector.trainModel(cvmodel);
+    std::vector<Pose3DPtr> a, b, c;
+    detector.match(scene, a, 0.05, 0.05);
+    detector.match(view, b, 0.05, 0.05);
+    {
+      cv::FileStorage fsOut(argv[3], cv::FileStorage::WRITE);
+      detector.write(fsOut);
+      fsOut.release();
+    }
+    PPF3DDetector loaded(0.05, 0.05);
+    cv::FileStorage fsLoad(argv[3], cv::FileStorage::READ);
+    cv::FileNode fnLoad = fsLoad.root();
+    loaded.read(fnLoad);
+    loaded.match(view, c, 0.05, 0.05);
+    bool same = a.size() == b.size() && a.size() == c.size() && !a.empty();
+    for (size_t i = 0; same && i < a.size(); i++)
+      same = a[i]->numVotes == b[i]->numVotes && a[i]->numVotes == c[i]->numVotes && a[i]->pose == b[i]->pose && a[i]->pose == c[i]->pose;
+    bool refused = false;
+    try { cv::Mat dbl(10, 6, CV_64F); detector.match(dbl, b, 0.05, 0.05); } catch (const Error& e) { refused = e.status == PPF_ERR_INVALID; }
+    std::printf("RESULT poses=%zu same=%d refused_double=%d\n", a.size(), (int)same, (int)refused);
+    return same && refused ? 0 : 1;
+  } catch (const Error& e) {
+    std::fprintf(stderr, "ppf error %d: %s\n", (int)e.status, e.what());
+    return 10 + (int)e.status;
+  }
+}
+'''
+
+
+def _build_opencv_overloads(tmp_path):
+    src = tmp_path / "opencv_overloads.cpp"
+    src.write_text(OPENCV_OVERLOADS)
+    exe = str(tmp_path / "opencv_overloads")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I",
+                    os.path.join(ROOT, "tests", "mock_opencv"), str(src), "-L", CSRC, "-lppf_hip", f"-Wl,-rpath,{CSRC}",
+                    "-o", exe], check=True)
+    return exe
+
+
+def test_opencv_overloads_compile_against_a_stand_in_header(tmp_path):
+    """cv::FileStorage / cv::FileNode read/write and the step1()-based stride compile (a minimal stand-in for
+    <opencv2/core.hpp> lives under tests/mock_opencv; OpenCV itself is not installed here)."""
+    _build_opencv_overloads(tmp_path)
+
+
+@pytest.mark.gpu
+def test_opencv_overloads_round_trip_and_strided_views(tmp_path, bottle):
+    exe = _build_opencv_overloads(tmp_path)
+    m, s = _inputs(tmp_path, bottle)
+    r = subprocess.run([exe, m, s, str(tmp_path / "detector_bottle.xml")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "same=1 refused_double=1" in r.stdout

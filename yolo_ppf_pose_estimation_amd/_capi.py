@@ -28,14 +28,15 @@ class PPFError(RuntimeError):
 class TrainParams(C.Structure):
     _fields_ = [("relative_sampling_step", C.c_double), ("relative_distance_step", C.c_double),
                 ("num_angles", C.c_double), ("presampled", C.c_int32), ("distance_from_distance_step", C.c_int32),
-                ("max_tile_refs", C.c_int32), ("reserved", C.c_int32)]
+                ("max_tile_refs", C.c_int32), ("key_equality", C.c_int32)]
 
 
 class MatchParams(C.Structure):
     _fields_ = [("relative_scene_sample_step", C.c_double), ("relative_scene_distance", C.c_double),
                 ("position_threshold", C.c_double), ("rotation_threshold", C.c_double),
                 ("use_weighted_avg", C.c_int32), ("presampled", C.c_int32), ("ref_offset", C.c_int32),
-                ("ref_stride", C.c_int32), ("skip_clustering", C.c_int32), ("vote_mode", C.c_int32)]
+                ("ref_stride", C.c_int32), ("skip_clustering", C.c_int32), ("vote_mode", C.c_int32),
+                ("pair_radius", C.c_double), ("rot_metric_relative", C.c_int32), ("reserved", C.c_int32)]
 
 
 class IcpParams(C.Structure):

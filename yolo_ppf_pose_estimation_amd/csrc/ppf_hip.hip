@@ -216,8 +216,8 @@ __device__ __forceinline__ ppf_vec3 ld3(const float* a, const float* b, const fl
 
 /* ---- training: one workgroup per model reference point i, threads sweep j (row A5-train) ---- */
 __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_step, double dist_step,
-                                                     uint32_t slot_mask, uint32_t* __restrict__ pair_slot,
-                                                     float* __restrict__ pair_alpha,
+                                                     uint32_t slot_mask, int key_exact, int lut_na, int lut_nd,
+                                                     uint32_t* __restrict__ pair_slot, float* __restrict__ pair_alpha,
                                                      unsigned long long* __restrict__ slot_bits) {
   __shared__ double frame[12];
   const int i = blockIdx.x;
@@ -237,8 +237,17 @@ __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_st
     const ppf_vec3 p2 = ld3(m.x, m.y, m.z, j), n2 = ld3(m.nx, m.ny, m.nz, j);
     double f[4] = {0, 0, 0, 0};
     ppf_pair_feature(p1, n1, p2, n2, f);
-    const uint32_t h = ppf_hash_feature(f, angle_step, dist_step);
-    const uint32_t slot = h & slot_mask; /* hash % slots, slots a power of two */
+    uint32_t slot;
+    if (key_exact) { /* PPF_KEY_EXACT: the "slot" is the quantised key itself (its index in the key table) */
+      const int32_t k0 = ppf_d2i(f[0] / angle_step), k1 = ppf_d2i(f[1] / angle_step), k2 = ppf_d2i(f[2] / angle_step),
+                    k3 = ppf_d2i(f[3] / dist_step);
+      const bool in = ((uint32_t)k0 < (uint32_t)lut_na) & ((uint32_t)k1 < (uint32_t)lut_na) & ((uint32_t)k2 < (uint32_t)lut_na) &
+                      ((uint32_t)k3 < (uint32_t)lut_nd);
+      if (!in) { pair_slot[idx] = 0xFFFFFFFFu; pair_alpha[idx] = 0.f; continue; } /* cannot happen: ppf_model_train checks the range */
+      slot = (uint32_t)(((k0 * lut_na + k1) * lut_na + k2) * lut_nd + k3);
+    } else {
+      slot = ppf_hash_feature(f, angle_step, dist_step) & slot_mask; /* hash % slots, slots a power of two */
+    }
     pair_slot[idx] = slot;
     pair_alpha[idx] = (float)ppf_model_alpha(R, t, p2);
     atomicOr(&slot_bits[slot >> 6], 1ull << (slot & 63));
@@ -280,7 +289,7 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
 }
 
 /* key_lut[((k0*na + k1)*na + k2)*nd + k3] = dense bucket of hash(k0..k3) % slots, or -1 */
-__global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int na, int nd,
+__global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int key_exact, int na, int nd,
                                                        int32_t* __restrict__ lut) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)na * na * na * nd;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
   const int k2 = (int)(t % na); t /= na;
   const int k1 = (int)(t % na);
   const int k0 = (int)(t / na);
-  lut[idx] = slot_to_bucket(slotmap, ppf_murmur_key16(k0, k1, k2, k3) & slot_mask);
+  lut[idx] = slot_to_bucket(slotmap, key_exact ? (uint32_t)idx : (ppf_murmur_key16(k0, k1, k2, k3) & slot_mask));
 }
 
 /* phase 0: count entries per (tile, bucket); phase 1: scatter through cursors */
@@ -605,6 +614,8 @@ struct ClusterArgs {
   int n, num_poses;
   double pos_thr, rot_thr;
   int weighted;
+  int rot_relative;      /* rotation test on the relative rotation of two poses (PCL) instead of their angle difference */
+  double cos_half_rot;   /* cos(rot_thr / 2): |qa . qb| above it <=> relative angle below rot_thr */
   /* global scratch */
   const uint32_t* order; /* [n] rank -> pose (k_rank on the vote keys) */
   uint32_t* assign;   /* [n] rank position -> cluster */
@@ -758,7 +769,19 @@ __global__ __launch_bounds__(1024) void k_cluster_assign(ClusterArgs a) {
 constexpr int CLM_MAX_WORDS = 180;  /* 64 staged rows must fit the LDS window: up to 11,520 poses */
 constexpr int CLM_LDS_BYTES = 96 * 1024;
 
-/* poses in rank order as SoA (x, y, z, angle) in g_heads; cluster counters cleared */
+/* relative-rotation variant of matchPose() (PCL's posesWithinErrorBounds): the angle of Ra^T Rb is 2 acos(|qa . qb|) */
+__device__ __forceinline__ bool pose_matches_rel(double hx, double hy, double hz, const double* hq, double tx, double ty, double tz,
+                                                 const double* q, double pos_thr, double pos_thr2, double cos_half_rot) {
+  const double dx = hx - tx, dy = hy - ty, dz = hz - tz;
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  const double d = ppf_fabs(hq[0] * q[0] + hq[1] * q[1] + hq[2] * q[2] + hq[3] * q[3]);
+  if (!(d > cos_half_rot)) return false;
+  if (d2 < pos_thr2 * (1.0 - 1e-12)) return true;
+  if (d2 > pos_thr2 * (1.0 + 1e-12)) return false;
+  return ppf_sqrt(d2) < pos_thr;
+}
+
+/* poses in rank order as SoA (x, y, z, angle, q0..q3) in g_heads; cluster counters cleared */
 __global__ __launch_bounds__(256) void k_clm_gather(ClusterArgs a) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n;
@@ -768,6 +791,8 @@ __global__ __launch_bounds__(256) void k_clm_gather(ClusterArgs a) {
   if (s >= min(a.num_poses, n)) return;
   const ppf_pose& p = a.in[a.order[s]];
   a.g_heads[s] = p.t[0]; a.g_heads[(size_t)n + s] = p.t[1]; a.g_heads[2 * (size_t)n + s] = p.t[2]; a.g_heads[3 * (size_t)n + s] = p.angle;
+  if (a.rot_relative)
+    for (int k = 0; k < 4; k++) a.g_heads[(size_t)(4 + k) * n + s] = p.q[k];
 }
 /* bits[i*words + w] bit b = pose 64w+b (< i) matches pose i; one workgroup per pose i, one wave per word */
 __global__ __launch_bounds__(256) void k_clm_matrix(ClusterArgs a, unsigned long long* __restrict__ bits, int words) {
@@ -776,9 +801,21 @@ __global__ __launch_bounds__(256) void k_clm_matrix(ClusterArgs a, unsigned long
   const double* px = a.g_heads; const double* py = px + n; const double* pz = py + n; const double* pa = pz + n;
   const double tx = px[i], ty = py[i], tz = pz[i], ang = pa[i];
   const double pos_thr2 = a.pos_thr * a.pos_thr;
+  const double* pq = pa + n; /* q0[n] q1[n] q2[n] q3[n], relative metric only */
+  double qi[4] = {0, 0, 0, 0};
+  if (a.rot_relative)
+    for (int k = 0; k < 4; k++) qi[k] = pq[(size_t)k * n + i];
   for (int w = wave; w <= (i >> 6); w += 4) {
     const int j = (w << 6) + lane;
-    const bool hit = j < i && pose_matches(px[j], py[j], pz[j], pa[j], tx, ty, tz, ang, a.pos_thr, pos_thr2, a.rot_thr);
+    bool hit = false;
+    if (j < i) {
+      if (a.rot_relative) {
+        const double qj[4] = {pq[j], pq[(size_t)n + j], pq[2 * (size_t)n + j], pq[3 * (size_t)n + j]};
+        hit = pose_matches_rel(px[j], py[j], pz[j], qj, tx, ty, tz, qi, a.pos_thr, pos_thr2, a.cos_half_rot);
+      } else {
+        hit = pose_matches(px[j], py[j], pz[j], pa[j], tx, ty, tz, ang, a.pos_thr, pos_thr2, a.rot_thr);
+      }
+    }
     const unsigned long long m = __ballot(hit);
     if (lane == 0) bits[(size_t)i * words + w] = m;
   }
@@ -1196,7 +1233,7 @@ struct ppf_workspace {
 namespace {
 
 ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int num_poses, double pos, double rot,
-                           bool weighted, hipStream_t st);
+                           bool weighted, hipStream_t st, bool rot_relative = false);
 
 void resolve_thresholds(const ppf_model* m, const ppf_match_params* p, double* pos, double* rot) {
   *pos = p->position_threshold < 0 ? m->info.position_threshold_default : p->position_threshold;
@@ -1204,14 +1241,16 @@ void resolve_thresholds(const ppf_model* m, const ppf_match_params* p, double* p
 }
 
 ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int num_poses, double pos, double rot,
-                           bool weighted, hipStream_t st) {
+                           bool weighted, hipStream_t st, bool rot_relative) {
   const size_t nn = (size_t)std::max(n, 1);
   HIPCHK(ws->d_final.reserve(nn));
   HIPCHK(ws->cl_u32.reserve(8 * nn + 4)); /* n_out | order | assign | rin | head | crank | gvotes | sizes | coff[n+1] */
   HIPCHK(ws->cl_votes.reserve(2 * nn));   /* cluster votes | pose vote keys */
-  HIPCHK(ws->cl_soa.reserve(11 * nn));    /* member q,t 7n | heads 4n */
+  HIPCHK(ws->cl_soa.reserve(15 * nn));    /* member q,t 7n | heads 4n (+ 4n quaternions for the relative rotation metric) */
   ClusterArgs ca;
   ca.in = d_in; ca.n = n; ca.num_poses = num_poses; ca.pos_thr = pos; ca.rot_thr = rot; ca.weighted = weighted ? 1 : 0;
+  ca.rot_relative = rot_relative ? 1 : 0;
+  ca.cos_half_rot = ppf_cos(0.5 * rot);
   uint32_t* u = ws->cl_u32.p;
   ca.n_out = u; u += 1;
   uint32_t* order = u; u += n;
@@ -1235,7 +1274,9 @@ ppf_status enqueue_cluster(ppf_workspace* ws, const ppf_pose* d_in, int n, int n
     const int np = std::min(num_poses, n);
     const int words = (np + 63) / 64;
     const size_t matrix_words = (size_t)np * words;
-    if (np > 0 && words <= CLM_MAX_WORDS && !ws->cluster_serial) {
+    if (rot_relative && np > 0 && words > CLM_MAX_WORDS)
+      return fail(PPF_ERR_INVALID, "clustering: the relative rotation metric handles up to %d poses", CLM_MAX_WORDS * 64);
+    if (np > 0 && words <= CLM_MAX_WORDS && (!ws->cluster_serial || rot_relative)) {
       /* match matrix + one wave walking the rows (see k_clm_heads) */
       static std::once_flag once_h;
       static hipError_t attr_h = hipSuccess;
@@ -1314,16 +1355,26 @@ static int max_tile_rows(int num_angles) {
 
 /* tabulate hash -> bucket for every key with angle bins 0..floor(pi/angle_step)+1 and distance bins 0..1023 (pairs up
  * to ~1000 distance steps apart: tens of model diameters); everything else keeps the hash path in k_pairs */
-static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
+static void key_lut_dims(ppf_model* m) {
   m->lut_na = (int)std::floor(PPF_PI / m->info.angle_step) + 2;
   m->lut_nd = 1024;
   const size_t total = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
   if (total > ((size_t)1 << 26)) { /* very fine angle steps: shrink the distance range to keep the table at 256 MiB */
     m->lut_nd = (int)std::max<size_t>(1, ((size_t)1 << 26) / ((size_t)m->lut_na * m->lut_na * m->lut_na));
   }
+}
+/* hash slots of the table: next_pow2(N^2) like the reference's library, or (PPF_KEY_EXACT) one slot per quantised key */
+static uint32_t table_slots(const ppf_model* m) {
+  if (m->params.key_equality == PPF_KEY_EXACT)
+    return next_pow2(std::max<uint32_t>((uint32_t)((size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd), 16u));
+  return next_pow2(std::max<uint32_t>((uint32_t)((size_t)m->info.n_ref * m->info.n_ref), 16u));
+}
+static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
+  key_lut_dims(m);
   const size_t n = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
   HIPCHK(m->key_lut.reserve(n));
-  k_build_key_lut<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(m->slotmap.p, m->info.slots - 1, m->lut_na, m->lut_nd, m->key_lut.p);
+  k_build_key_lut<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(m->slotmap.p, m->info.slots - 1, m->params.key_equality == PPF_KEY_EXACT,
+                                                                           m->lut_na, m->lut_nd, m->key_lut.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   return PPF_OK;
@@ -1342,7 +1393,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(bits.reserve(words));
   HIPCHK(hipMemsetAsync(bits.p, 0, words * sizeof(unsigned long long), st));
   k_train_pairs<<<dim3(N), dim3(256), 0, st>>>(m->cloud.view(), m->info.angle_step, m->info.distance_step, slots - 1,
-                                               pair_slot.p, pair_alpha.p, bits.p);
+                                               m->params.key_equality == PPF_KEY_EXACT, m->lut_na, m->lut_nd, pair_slot.p, pair_alpha.p, bits.p);
   HIPCHK(hipGetLastError());
   HIPCHK(word_cnt.reserve(words + 1));
   HIPCHK(word_rank.reserve(words + 1));
@@ -1497,7 +1548,12 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   m->info.angle_step = angle_step;
   m->info.distance_step = dist_step;
   m->info.diameter = diameter;
-  m->info.slots = next_pow2(std::max<uint32_t>((uint32_t)((size_t)N * N), 16u));
+  key_lut_dims(m);
+  if (params->key_equality != PPF_KEY_BUCKET && params->key_equality != PPF_KEY_EXACT)
+    return fail(PPF_ERR_INVALID, "ppf_model_train: key_equality must be PPF_KEY_BUCKET or PPF_KEY_EXACT");
+  if (params->key_equality == PPF_KEY_EXACT && (double)diameter / (double)dist_step + 2.0 > (double)m->lut_nd)
+    return fail(PPF_ERR_INVALID, "ppf_model_train: PPF_KEY_EXACT needs diameter / distance step (%g) below %d", (double)diameter / dist_step, m->lut_nd);
+  m->info.slots = table_slots(m);
   m->info.position_threshold_default = params->relative_sampling_step;
   m->info.rotation_threshold_default = ((360 / angle_step) / 180.0 * PPF_PI);
   const int A = m->info.num_angles;
@@ -1757,6 +1813,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.tally = ws->counters.p + (size_t)n_ref * T + n_ref + 2;
   va.acc_dump = ws->acc_dump;
   va.bucket_total = m->bucket_total.p;
+  va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
+  va.pair_radius = params->pair_radius;
   va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
   const int n_paired = va.paired.n;
   va.pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
@@ -1895,7 +1953,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     /* the reference clusters sampled.rows / sceneSamplingStep poses (integer division: the lowest-voted
      * pose is dropped when the stride does not divide the row count); a shard clusters its own share */
     const int num = (params->ref_stride == 1 && params->ref_offset == 0) ? rows / scene_step : n_ref;
-    s = enqueue_cluster(ws, ws->raw_poses.p, n_ref, num, pos, rot, params->use_weighted_avg != 0, st);
+    s = enqueue_cluster(ws, ws->raw_poses.p, n_ref, num, pos, rot, params->use_weighted_avg != 0, st, params->rot_metric_relative != 0);
     if (s != PPF_OK) return s;
     ws->clustered = true;
   }
@@ -2120,7 +2178,8 @@ ppf_status ppf_cluster_poses_device(const ppf_model* m, ppf_workspace* ws, const
   if (n == 0) return PPF_OK;
   double pos, rot;
   resolve_thresholds(m, params, &pos, &rot);
-  ppf_status s = enqueue_cluster(ws, (const ppf_pose*)d_in, n, num_poses, pos, rot, params->use_weighted_avg != 0, (hipStream_t)stream);
+  ppf_status s = enqueue_cluster(ws, (const ppf_pose*)d_in, n, num_poses, pos, rot, params->use_weighted_avg != 0, (hipStream_t)stream,
+                                 params->rot_metric_relative != 0);
   if (s != PPF_OK) return s;
   ws->clustered = true;
   ws->n_ref = n; /* d_final / cl_u32 hold the clusters; results come back through ppf_workspace_results(poses) / _copy_top_poses */
@@ -2141,7 +2200,7 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
   HIPCHK(hipMemcpy(d_in.p, in, (size_t)n * sizeof(ppf_pose), hipMemcpyHostToDevice));
   double pos, rot;
   resolve_thresholds(m, params, &pos, &rot);
-  ppf_status s = enqueue_cluster(&ws, d_in.p, n, num_poses, pos, rot, params->use_weighted_avg != 0, nullptr);
+  ppf_status s = enqueue_cluster(&ws, d_in.p, n, num_poses, pos, rot, params->use_weighted_avg != 0, nullptr, params->rot_metric_relative != 0);
   if (s != PPF_OK) return s;
   HIPCHK(hipStreamSynchronize(nullptr));
   uint32_t nf = 0;
@@ -2480,8 +2539,10 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
   const ppf_model_info& I = m->info;
   const uint64_t N = (uint64_t)(I.n_ref > 0 ? I.n_ref : 0);
   if (I.n_ref < 2 || N * N > 0x7FFFFFFFull) return bad("n_ref");
-  if (I.slots != next_pow2(std::max<uint32_t>((uint32_t)(N * N), 16u))) return bad("slots");
-  if (!(I.num_angles >= 1 && I.num_angles <= 4096) || !(I.angle_step > 0) || !(I.distance_step > 0) || !std::isfinite(I.diameter)) return bad("steps");
+  if (!(I.num_angles >= 1 && I.num_angles <= 4096) || !(I.angle_step > 1e-4) || !(I.distance_step > 0) || !std::isfinite(I.diameter)) return bad("steps");
+  if (m->params.key_equality != PPF_KEY_BUCKET && m->params.key_equality != PPF_KEY_EXACT) return bad("key_equality");
+  key_lut_dims(m);
+  if (I.slots != table_slots(m)) return bad("slots");
   if (I.num_angles != (int)std::floor(2 * PPF_PI / I.angle_step)) return bad("num_angles");
   const int A = I.num_angles, P = vote_pitch(A), GW = vote_guard(A);
   if (I.n_tiles < 1 || I.tile_refs < 1 || (uint64_t)I.n_tiles * I.tile_refs < N || (uint64_t)(I.n_tiles - 1) * I.tile_refs >= N)

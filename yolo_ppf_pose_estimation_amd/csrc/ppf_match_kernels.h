@@ -202,6 +202,8 @@ struct MatchArgs {
   uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
   const uint32_t* perm_group;   /* [n_ref] reference points ordered by hit count, for k_group */
   int agg_min_hits;             /* 0: every run votes directly */
+  int key_exact;                /* PPF_KEY_EXACT table: keys outside the key table match nothing */
+  double pair_radius;           /* > 0: pairs farther apart than this are skipped (not counted) */
   int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
   int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
@@ -274,13 +276,20 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
        * comparing the doubles compares the float bits (no NaN/-0 cases in finite clouds). */
       const bool self_pair = !a.same_cloud && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x &&
                              n2.y == n1.y && n2.z == n1.z;
-      if (!self_pair) {
+      bool skip = self_pair;
+      if (a.pair_radius > 0.0) { /* PCL policy: neighbours within a radius only; the same fp64 distance the pair feature uses */
+        const double dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+        skip |= ppf_sqrt(dx * dx + dy * dy + dz * dz) > a.pair_radius;
+      }
+      if (!skip) {
         int32_t key[4];
         pair_key(p1, n1, p2, n2, a.angle_step, a.dist_step, fk, key);
         int b;
         if (((uint32_t)key[0] < (uint32_t)a.lut_na) & ((uint32_t)key[1] < (uint32_t)a.lut_na) & ((uint32_t)key[2] < (uint32_t)a.lut_na) &
             ((uint32_t)key[3] < (uint32_t)a.lut_nd)) {
           b = a.key_lut[(size_t)((key[0] * a.lut_na + key[1]) * a.lut_na + key[2]) * a.lut_nd + key[3]];
+        } else if (a.key_exact) { /* no model pair has a key outside the table */
+          b = -1;
         } else { /* NaN features (INT_MIN bins) or pairs farther apart than the table covers */
           b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
         }

@@ -86,12 +86,15 @@ class _ModelHandle:
 
 class PPF3DDetector:
     def __init__(self, relativeSamplingStep: float = 0.05, relativeDistanceStep: float = 0.05, numAngles: float = 30,
-                 *, distance_from_distance_step: bool = False, max_tile_refs: int = 0):
+                 *, distance_from_distance_step: bool = False, max_tile_refs: int = 0, key_equality: int = 0):
         self.sampling_step_relative = float(relativeSamplingStep)
         self.distance_step_relative = float(relativeDistanceStep)
         self.angle_step_relative = float(numAngles)
         self._dist_flag = bool(distance_from_distance_step)
         self._max_tile_refs = int(max_tile_refs)
+        self._key_equality = int(key_equality)  # 0: whole hash bucket votes (OpenCV); 1: exact quantised key (PCL)
+        self._pair_radius = 0.0                 # > 0: scene pairs within this distance only (PCL)
+        self._rot_metric_relative = False       # cluster on the relative rotation angle (PCL)
         self._position_threshold = -1.0
         self._rotation_threshold = -1.0
         self._use_weighted_avg = False
@@ -101,7 +104,9 @@ class PPF3DDetector:
     # -- copy semantics: share the trained table ------------------------------------------------
     def __copy__(self):
         d = PPF3DDetector(self.sampling_step_relative, self.distance_step_relative, self.angle_step_relative,
-                          distance_from_distance_step=self._dist_flag, max_tile_refs=self._max_tile_refs)
+                          distance_from_distance_step=self._dist_flag, max_tile_refs=self._max_tile_refs,
+                          key_equality=self._key_equality)
+        d._pair_radius, d._rot_metric_relative = self._pair_radius, self._rot_metric_relative
         d._position_threshold, d._rotation_threshold = self._position_threshold, self._rotation_threshold
         d._use_weighted_avg = self._use_weighted_avg
         d._model = self._model
@@ -117,6 +122,13 @@ class PPF3DDetector:
         self._rotation_threshold = float(rotationThreshold)
         self._use_weighted_avg = bool(useWeightedClustering)
 
+    def setPolicy(self, pair_radius: float = 0.0, rot_metric_relative: bool = False):
+        """PCL-semantics switches of the match (ppf_match_params.pair_radius / rot_metric_relative); the key policy is a
+        constructor argument because it shapes the trained table."""
+        self._pair_radius = float(pair_radius)
+        self._rot_metric_relative = bool(rot_metric_relative)
+        return self
+
     # -- training ---------------------------------------------------------------------------------
     def trainModel(self, model: np.ndarray, presampled: bool = False):
         pc = _cloud(model, "model")
@@ -128,6 +140,7 @@ class PPF3DDetector:
         tp.presampled = int(presampled)
         tp.distance_from_distance_step = int(self._dist_flag)
         tp.max_tile_refs = self._max_tile_refs
+        tp.key_equality = self._key_equality
         out = C.c_void_p()
         check(lib().ppf_model_train(pc.ctypes.data, pc.shape[0], pc.shape[1], C.byref(tp), C.byref(out)))
         self._model = _ModelHandle(out.value)
@@ -187,6 +200,8 @@ class PPF3DDetector:
         mp.ref_offset, mp.ref_stride = int(ref_offset), int(ref_stride)
         mp.skip_clustering = int(skip_clustering)
         mp.vote_mode = int(vote_mode)  # 0: count tables for runs of many hits, 1: one atomic per (entry, hit)
+        mp.pair_radius = self._pair_radius
+        mp.rot_metric_relative = int(self._rot_metric_relative)
         return mp
 
     def match(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
