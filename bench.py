@@ -84,7 +84,8 @@ def launch_ranks(args, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    for ln in out.decode().splitlines():  # the contract is ONE JSON line on stdout; library chatter goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -115,19 +116,19 @@ def algorithmic_bytes(n_ref, n_model, num_angles, n_pairs, n_votes):
     return n_ref * (24 + 2 * 4 * n_model * num_angles + 12) + n_pairs * 32 + n_votes * 16
 
 
-def measured_traffic(n_votes):
-    """HBM/fabric bytes per k_vote launch from the committed PMC passes (profiles/*_pmc_traffic.json) taken on this
-    exact workload (same vote count per launch), newest file first; None when there is none.  bench.py cannot collect
-    PMC counters on itself."""
+def committed_counters(n_votes_per_step):
+    """The committed PMC summary (profiles/*_pmc_*.json, tools/pmc_summary.py) taken on this exact workload (same
+    vote count per step), newest file first; None when there is none.  bench.py cannot collect PMC counters on itself."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*.json")), reverse=True):
         try:
             t = json.load(open(f))
-            if t.get("n_votes_per_launch") == n_votes:
-                return t["hbm_bytes_per_launch_k_vote"]["gfx950_corrected_2xFETCH"], os.path.basename(f)
+            if t.get("n_votes_per_step", t.get("n_votes_per_launch")) == n_votes_per_step:
+                t["file"] = os.path.basename(f)
+                return t
         except Exception:
             pass
-    return None, None
+    return None
 
 
 def cpu_baseline(model_step, bottle, scene, n_ref_total, seconds_per_rep, reps=5):
@@ -401,7 +402,9 @@ def main(argv=None):
             line["kernel_ms"] = {"k_pairs": float(np.mean(pair_ms)), "k_group": float(np.mean(group_ms)),
                                  "k_vote": float(np.mean(vote_ms)), "device_total": float(np.mean(dev_ms))}
             abytes = algorithmic_bytes(st["n_ref"], info["n_ref"], info["num_angles"], st["n_pairs"], st["n_votes"])
-            traffic, src = measured_traffic(st["n_votes"]) if world == 1 else (None, None)
+            pmc = committed_counters(st["n_votes"]) if world == 1 else None
+            traffic = (pmc.get("hbm_bytes_per_step_k_vote") or pmc.get("hbm_bytes_per_launch_k_vote", {}).get("gfx950_corrected_2xFETCH")) if pmc else None
+            src = pmc["file"] if pmc else None
             achieved = traffic / avg_vote_s / 1e9 if traffic else None
             line["roofline"] = {
                 "bound": "hbm", "kernel": "k_vote",
@@ -410,10 +413,23 @@ def main(argv=None):
                 "traffic": traffic, "traffic_source": src,
                 "avg_kernel_ms": avg_vote_s * 1e3,
                 "algorithmic_bytes_per_launch": abytes,
-                "note": "achieved = measured fabric bytes of one k_vote launch (2 x TCC read requests + writes, committed "
-                        "PMC pass) / its HIP-event time.  The section 8d figure (16 B per vote) is kept as "
+                "note": "achieved = measured fabric bytes of k_vote per step (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC "
+                        "pass) / its HIP-event time of this run.  The section 8d figure (16 B per vote) is kept as "
                         "algorithmic_bytes_per_launch only: the accumulator lives in LDS and a model entry is read once "
-                        "per run of hits, so the kernel is LDS-bound, see lds_roofline",
+                        "per run of hits.  What bounds the kernel is instruction issue, see issue_roofline / lds_roofline",
+            }
+            # instruction issue: what the kernel is actually bound by (SQ counters of the committed pass)
+            issue = (pmc or {}).get("k_vote_issue")
+            line["issue_roofline"] = None if not issue else {
+                "kernel": "k_vote", "source": src,
+                "valu_busy_frac_of_simd_time": issue["valu_busy_frac_of_simd_time"],
+                "any_inst_busy_frac_of_simd_time": issue["any_inst_busy_frac_of_simd_time"],
+                "lds_busy_frac_of_simd_time": issue["lds_busy_frac_of_simd_time"],
+                "valu_wave_instr_per_s": issue["valu_wave_instructions_sampled"] / avg_vote_s,
+                "valu_wave_instr_peak_per_s": 1024 * 2.4e9 / 4.45,
+                "frac_of_valu_issue_peak": issue["valu_wave_instructions_sampled"] / avg_vote_s / (1024 * 2.4e9 / 4.45),
+                "note": "SQ_INSTS_VALU of one step / k_vote time against 1024 SIMDs x 2.4 GHz / 4.45 cycles per wave-instruction "
+                        "(profiles/r01_ubench_valu_lds.txt); busy fractions = SQ_ACTIVE_INST_* / (SQ_WAVE_CYCLES / 4 waves per SIMD)",
             }
             atom = tally["atomics"] / args.steps if tally["atomics"] else None
             line["lds_roofline"] = {

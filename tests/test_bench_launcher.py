@@ -29,9 +29,16 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
 
 
+def _free_port() -> str:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def test_under_torch_distributed_run_each_process_is_a_rank():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                        "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
                        capture_output=True, text=True, env=_env(), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = sorted((json.loads(l)["rank"], json.loads(l)["world"]) for l in r.stdout.splitlines() if l.startswith("{"))

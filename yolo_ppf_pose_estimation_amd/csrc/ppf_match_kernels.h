@@ -837,7 +837,8 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   if (qa == AGG_Q) { ca.x = 0u; ca.y = (uint32_t)ms; }
   if (qb == AGG_Q) { cb.x = 0u; cb.y = (uint32_t)ms; }
   const uint32_t pa = k.acc_base + rec.x, pb = k.acc_base + rec.y;
-  const uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
+  uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
+  asm volatile("" : "+v"(va), "+v"(vb)); /* keep these as the bases: every atomic below is base + immediate offset */
   const uint32_t wa[5] = {a01.x, a01.y, a23.x, a23.y, a45.x}, wb[5] = {b01.x, b01.y, b23.x, b23.y, b45.x};
 #pragma unroll
   for (int j = 0; j <= AGG_NY; j++) {
@@ -845,21 +846,26 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
     lds_add(vb + (uint32_t)((AGG_NY - j) * 4), (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu);
   }
   votes += (ca.y - ca.x) + (cb.y - cb.x);
-  uint32_t ia = ca.x, ib = cb.x;
-  while (__any((ia < ca.y) | (ib < cb.y))) {
-    const bool da = ia < ca.y, db = ib < cb.y;
-    const float oa = __uint_as_float(lds_ld(k.ws + AGG_OFF_A32 + min(ia, (uint32_t)(AGG_SUB - 1)) * 4));
-    const float ob = __uint_as_float(lds_ld(k.ws + AGG_OFF_A32 + min(ib, (uint32_t)(AGG_SUB - 1)) * 4));
+  /* byte addresses into the cell-sorted offsets; reads past a lane's own range stay inside the workgroup's LDS and
+   * are never used */
+  const uint32_t base32 = k.ws + AGG_OFF_A32;
+  uint32_t ia = base32 + ca.x * 4, ib = base32 + cb.x * 4;
+  const uint32_t ea = base32 + ca.y * 4, eb = base32 + cb.y * 4;
+  while (__any((ia < ea) | (ib < eb))) {
+    const bool da = ia < ea, db = ib < eb;
+    const float oa = __uint_as_float(lds_ld(ia)), ob = __uint_as_float(lds_ld(ib));
     const float xa = __builtin_fmaf(am_a, k.S, oa), xb = __builtin_fmaf(am_b, k.S, ob);
     int ba = (int)xa, bb = (int)xb;
-    const bool ga = da & (__builtin_amdgcn_fractf(xa) < k.G2), gb = db & (__builtin_amdgcn_fractf(xb) < k.G2);
-    if (__builtin_expect(__any(ga | gb), 0)) { /* inside the guard band of a bin edge: the exact fp64 chain */
-      if (ga) ba = ppf_alpha_bin_exact(am_a, g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ia)], k.A);
-      if (gb) bb = ppf_alpha_bin_exact(am_b, g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ib)], k.A);
+    const float fa = __builtin_amdgcn_fractf(xa), fb = __builtin_amdgcn_fractf(xb);
+    if (__builtin_expect(__any(__builtin_fminf(fa, fb) < k.G2), 0)) { /* some lane may sit in the guard band of a bin edge */
+      uint32_t za = rec.z, zb = rec.w;
+      asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the loop */
+      if (da && fa < k.G2) ba = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ((ia - base32) >> 2))], k.A);
+      if (db && fb < k.G2) bb = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ((ib - base32) >> 2))], k.A);
     }
     if (da) lds_add(pa + ((uint32_t)ba << 2), 1u);
     if (db) lds_add(pb + ((uint32_t)bb << 2), 1u);
-    ia++; ib++;
+    ia += 4; ib += 4;
   }
 }
 
