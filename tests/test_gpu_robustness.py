@@ -167,6 +167,34 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
 
 
+def test_serial_and_matrix_clustering_agree(det, crop):
+    """PPF_OPT_CLUSTER_SERIAL forces the serial greedy assignment (otherwise only used above 11,520 poses): same clusters."""
+    a = _device_run(det, crop)
+    ws = Workspace()
+    ws.set_option(_capi.PPF_OPT_CLUSTER_SERIAL, 1)
+    b = _device_run(det, crop, ws)
+    assert len(a["poses"]) == len(b["poses"]) > 10
+    for p, q in zip(a["poses"], b["poses"]):
+        assert p.numVotes == q.numVotes
+        np.testing.assert_array_equal(p.pose, q.pose)
+
+
+def test_icp_schedules_agree(det, bottle, crop):
+    """ppf_icp_params.flags: coarse levels kernel by kernel instead of in one workgroup, all poses on one stream: the
+    refined poses, residuals and iteration counts do not change."""
+    from yolo_ppf_pose_estimation_amd.detector import ICP
+    poses = det.match(crop, 1.0 / 10.0, 0.05, presampled=True)[:3]
+    ref = ICP(100, 0.005, 2.5, 8)
+    want = ref.registerModelToScene(bottle, crop, [p.clone() for p in poses])
+    for flags in (_capi.PPF_ICP_NO_SMALL_LEVELS, _capi.PPF_ICP_ONE_STREAM, _capi.PPF_ICP_NO_SMALL_LEVELS | _capi.PPF_ICP_ONE_STREAM):
+        icp = ICP(100, 0.005, 2.5, 8, flags=flags)
+        got = icp.registerModelToScene(bottle, crop, [p.clone() for p in poses])
+        assert icp.last_iterations == ref.last_iterations
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g.pose, w.pose)
+            assert g.residual == w.residual
+
+
 def test_a_model_on_another_device_is_refused(det, crop):
     """check_match_args: the model's device must be the calling thread's current device (one GPU here: the positive case)."""
     assert lib().ppf_device_count() >= 1

@@ -57,6 +57,15 @@ WORKER = textwrap.dedent("""
     g = parallel.gather_poses(padded)
     merged = parallel.merge_reference_shards([g[r][g[r][:, 0] >= 0] for r in range(world)])
     assert list(merged[:, 0]) == list(range(7))
+    # the tensor-block forms bench.py uses (device tensors over RCCL on the GPU box; CPU tensors over gloo here)
+    import torch
+    blk = torch.zeros((4, parallel.POSE_WORDS), dtype=torch.float64)
+    blk[: per_ref.shape[0], 0] = torch.from_numpy(per_ref[:, 0])
+    blk[per_ref.shape[0]:, 0] = -1.0
+    allb = parallel.gather_device(blk)
+    assert tuple(allb.shape) == (world * 4, parallel.POSE_WORDS)
+    merged_t = parallel.merge_reference_shards_device(allb, world, 7)
+    assert merged_t[:, 0].tolist() == [float(k) for k in range(7)] and merged_t.is_contiguous()
     dist.barrier()
     if rank == 0:
         print("GLOO_OK", world, mine)

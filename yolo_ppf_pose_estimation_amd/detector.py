@@ -333,9 +333,11 @@ class ICP:
     /root/reference/include/CloudProcessing.h:465-470, :518-523): multi-level point-to-plane ICP with picky
     correspondences and median+MAD rejection, on the device (ppf_icp_refine / ppf_icp_register)."""
 
-    def __init__(self, iterations: int = 100, tolerance: float = 0.005, rejectionScale: float = 2.5, numLevels: int = 8):
+    def __init__(self, iterations: int = 100, tolerance: float = 0.005, rejectionScale: float = 2.5, numLevels: int = 8,
+                 *, flags: int = 0):
         self._prm = IcpParams()
         lib().ppf_default_icp_params(C.byref(self._prm))
+        self._prm.flags = int(flags)  # _capi.PPF_ICP_NO_SMALL_LEVELS | PPF_ICP_ONE_STREAM: other schedules, same results
         self._prm.iterations, self._prm.tolerance = int(iterations), float(tolerance)
         self._prm.rejection_scale, self._prm.num_levels = float(rejectionScale), int(numLevels)
         self.last_iterations: List[int] = []
