@@ -41,5 +41,6 @@ def test_under_torch_distributed_run_each_process_is_a_rank():
                         "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
                        capture_output=True, text=True, env=_env(), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    got = sorted((json.loads(l)["rank"], json.loads(l)["world"]) for l in r.stdout.splitlines() if l.startswith("{"))
-    assert got == [(0, 2), (1, 2)]
+    import re
+    objs = [json.loads(m) for m in re.findall(r"\{[^{}]*\}", r.stdout)]  # the two ranks share one pipe: lines may interleave
+    assert sorted((o["rank"], o["world"]) for o in objs) == [(0, 2), (1, 2)], r.stdout + r.stderr[-500:]

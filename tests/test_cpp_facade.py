@@ -73,7 +73,8 @@ def test_pcl_shaped_facade_compiles_and_fails_loudly_without_gpu(tmp_path, bottl
 @pytest.mark.gpu
 def test_pcl_shaped_facade_runs(tmp_path, bottle):
     """PPFEstimation -> PPFHashMapSearch -> PPFRegistration: the same engine call as the Python binding with the
-    equivalent parameters (model rows as given, absolute distance step, sampling rate 20)."""
+    equivalent parameters (model rows as given, absolute distance step, sampling rate 20) and the PCL policy switches the
+    PCL-named classes turn on (exact key equality, pair radius model_diameter / 2, relative rotation metric)."""
     from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
     exe = _build(tmp_path, "pcl_pipeline_demo")
     m, s = _inputs(tmp_path, bottle)
@@ -84,9 +85,11 @@ def test_pcl_shaped_facade_runs(tmp_path, bottle):
     model, scene = ply.load_ply_simple(m), ply.load_ply_simple(s)
     diameter = float(np.linalg.norm((model[:, :3].max(0) - model[:, :3].min(0)).astype(np.float32)))
     rel = float(np.float32(0.012)) / float(np.float32(diameter))
-    det = PPF3DDetector(rel, rel, 2.0 * np.pi / float(np.float32(12.0 / 180.0 * 3.14159265)), distance_from_distance_step=True)
+    det = PPF3DDetector(rel, rel, 2.0 * np.pi / float(np.float32(12.0 / 180.0 * 3.14159265)), distance_from_distance_step=True,
+                        key_equality=1)
     det.trainModel(model, presampled=True)
     det.setSearchParams(float(np.float32(0.05)), float(np.float32(30.0 / 180.0 * 3.14159265)))
+    det.setPolicy(pair_radius=0.5 * float(np.float32(diameter)), rot_metric_relative=True)
     poses = det.match(scene, 1.0 / 20.0, 0.05, presampled=True)
     assert votes == poses[0].numVotes
 
