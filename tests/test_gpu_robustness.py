@@ -167,6 +167,19 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
 
 
+def test_fine_alpha_resolution_votes_directly(bottle):
+    """numAngles > 31: no count tables (their Y range needs numAngles <= 31), every vote its own atomic, several tiles."""
+    det = PPF3DDetector(0.1, 0.05, 180).trainModel(bottle)
+    assert det.info()["num_angles"] == 180 and det.info()["n_tiles"] >= 2
+    scene = synth.make_scene(bottle, n_points=3000, seed=8)[0]
+    got = det.raw_votes(scene, 1.0 / 10.0, 0.05, presampled=True)
+    ora = O.OracleDetector(0.1, 0.05, 180).train_model(bottle)
+    want = ora.match(scene, relative_scene_sample_step=1.0 / 10.0, presampled=True, cluster=False)
+    np.testing.assert_array_equal(got["triples"], want["triples"])
+    assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+    assert got["stats"]["n_lds_atomics"] >= got["stats"]["n_votes"]
+
+
 def test_serial_and_matrix_clustering_agree(det, crop):
     """PPF_OPT_CLUSTER_SERIAL forces the serial greedy assignment (otherwise only used above 11,520 poses): same clusters."""
     a = _device_run(det, crop)
