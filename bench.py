@@ -416,20 +416,29 @@ def main(argv=None):
                 "note": "achieved = measured fabric bytes of k_vote per step (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC "
                         "pass) / its HIP-event time of this run.  The section 8d figure (16 B per vote) is kept as "
                         "algorithmic_bytes_per_launch only: the accumulator lives in LDS and a model entry is read once "
-                        "per run of hits.  What bounds the kernel is instruction issue, see issue_roofline / lds_roofline",
+                        "per run of hits.  What bounds the kernel is the LDS instruction rate, see issue_roofline / lds_roofline",
             }
             # instruction issue: what the kernel is actually bound by (SQ counters of the committed pass)
             issue = (pmc or {}).get("k_vote_issue")
+            lds_instr_peak = 256 * 2.4e9 / 4.38  # ds_add_u32: one 64-lane wave-instruction per 4.38 cycles per CU (r01 ubench)
             line["issue_roofline"] = None if not issue else {
                 "kernel": "k_vote", "source": src,
                 "valu_busy_frac_of_simd_time": issue["valu_busy_frac_of_simd_time"],
                 "any_inst_busy_frac_of_simd_time": issue["any_inst_busy_frac_of_simd_time"],
                 "lds_busy_frac_of_simd_time": issue["lds_busy_frac_of_simd_time"],
+                "lds_wave_instr_per_s": issue["lds_wave_instructions_sampled"] / avg_vote_s,
+                "lds_wave_instr_peak_per_s": lds_instr_peak,
+                "frac_of_lds_instr_peak": issue["lds_wave_instructions_sampled"] / avg_vote_s / lds_instr_peak,
+                "lds_bank_conflict_frac_of_lds_cycles": issue["lds_bank_conflict_frac_of_lds_cycles"],
+                "frac_of_lds_instr_peak_conflicts_counted": issue["lds_wave_instructions_sampled"] / avg_vote_s / lds_instr_peak
+                                                            / max(1e-9, 1.0 - issue["lds_bank_conflict_frac_of_lds_cycles"]),
                 "valu_wave_instr_per_s": issue["valu_wave_instructions_sampled"] / avg_vote_s,
                 "valu_wave_instr_peak_per_s": 1024 * 2.4e9 / 4.45,
                 "frac_of_valu_issue_peak": issue["valu_wave_instructions_sampled"] / avg_vote_s / (1024 * 2.4e9 / 4.45),
-                "note": "SQ_INSTS_VALU of one step / k_vote time against 1024 SIMDs x 2.4 GHz / 4.45 cycles per wave-instruction "
-                        "(profiles/r01_ubench_valu_lds.txt); busy fractions = SQ_ACTIVE_INST_* / (SQ_WAVE_CYCLES / 4 waves per SIMD)",
+                "note": "k_vote is bound by the LDS pipe: SQ_INSTS_LDS of one step / k_vote time against one 64-lane LDS "
+                        "wave-instruction per 4.38 cycles per CU (the ds_add_u32 rate of profiles/r01_ubench_valu_lds.txt); the "
+                        "second fraction divides by the share of LDS cycles that are not bank conflicts.  VALU: SQ_INSTS_VALU "
+                        "against 1024 SIMDs x 2.4 GHz / 4.45 cycles; busy fractions = SQ_ACTIVE_INST_* / (SQ_WAVE_CYCLES / 4)",
             }
             atom = tally["atomics"] / args.steps if tally["atomics"] else None
             line["lds_roofline"] = {
