@@ -264,6 +264,9 @@ ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref
 ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
                                   int estride, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
                                   int* n_ref);
+/* Size of the cached device block a request of `bytes` is served from (host only, no device needed): classes of 1/8
+ * octave, so at most 12.5 % more than asked for.  Test surface of the block cache's keying. */
+size_t ppf_debug_block_size(size_t bytes);
 /* Evaluate include/ppf_detmath.h on the device: fn 0 acos(x), 1 sin(x), 2 cos(x), 3 atan2(x, y), 4 sqrt(x),
  * 5 x / y.  The bit patterns must equal the host's (tests/test_gpu_detmath.py). */
 ppf_status ppf_debug_device_math(int fn, const double* x, const double* y, double* out, int n);

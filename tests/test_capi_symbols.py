@@ -120,3 +120,23 @@ def test_model_file_validation_is_host_side_and_loud(tmp_path):
     if lib().ppf_device_count() == 0:
         out = C.c_void_p()
         assert lib().ppf_model_load(str(p).encode(), C.byref(out)) == _capi.PPF_ERR_HIP
+
+
+def test_block_cache_size_classes():
+    """DevPool keying (host logic): a request is served from the smallest class that holds it, classes are 1/8 octave
+    apart (at most 12.5 % waste above 2 KiB), and a block's own size maps back to its class, so a released block is found
+    again by the next request of that size."""
+    f = lib().ppf_debug_block_size
+    assert f(0) == f(1) == f(256) == 256
+    prev = 0
+    rng = np.random.default_rng(0)
+    sizes = sorted(set([257, 1000, 4096, 4097, 1 << 20, (1 << 20) + 1, 454_000_000, 4_269_982_720] +
+                       [int(x) for x in rng.integers(300, 1 << 33, size=2000)]))
+    for n in sizes:
+        g = f(n)
+        assert g >= n and f(g) == g, (n, g)
+        if n >= 2048:
+            assert g <= n * 1.125 + 1, (n, g)
+        assert g >= prev
+        prev = g
+    assert len({f(n) for n in range(256, 4096)}) <= 8 * 4 + 1  # four octaves, eight classes each

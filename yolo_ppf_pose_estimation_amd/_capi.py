@@ -117,6 +117,7 @@ _SIGNATURES = {
     "ppf_workspace_ref_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_debug_accumulators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(MatchParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ppf_debug_block_size": (C.c_size_t, [C.c_size_t]),
     "ppf_debug_device_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_workspace_device_poses": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "ppf_workspace_copy_top_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

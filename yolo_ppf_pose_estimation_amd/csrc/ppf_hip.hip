@@ -2093,6 +2093,11 @@ ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns
   return PPF_OK;
 }
 
+/* the block cache's size class for a request (host only): what DevBuf is granted for `bytes` */
+size_t ppf_debug_block_size(size_t bytes) {
+  return DevPool::class_size(DevPool::class_of(std::max<size_t>(bytes, 256)));
+}
+
 ppf_status ppf_debug_device_math(int fn, const double* x, const double* y, double* out, int n) {
   if (!x || !out || n <= 0 || fn < 0 || fn > 5) return fail(PPF_ERR_INVALID, "ppf_debug_device_math: bad argument");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_debug_device_math: no HIP device");

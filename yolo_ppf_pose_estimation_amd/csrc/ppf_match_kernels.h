@@ -943,7 +943,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* scalar: the work-item loop is wave-uniform */
-  const int slot = blockIdx.x / a.n_tiles, tile = blockIdx.x - slot * a.n_tiles;
+  /* tile-major launch order: the workgroups in flight work on the same accumulator tile, i.e. the same slice of the
+   * model table (a 10k-point model: 80 MB of 800 MB), which then stays in L2 / Infinity Cache while the reference
+   * points go by (C4: 483 -> 471 ms; C2, whose table fits the cache anyway: no change) */
+  const int tile = blockIdx.x / a.n_ref, slot = blockIdx.x - tile * a.n_ref;
   const int r = (int)a.perm[slot]; /* heaviest reference points first */
   const int rg = a.ref_base + r;
   const int tile_base = tile * a.tile_refs;
