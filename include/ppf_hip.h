@@ -105,7 +105,8 @@ typedef struct ppf_match_params {
                                         model_diameter / 2 around it); <= 0: with every point */
   int32_t rot_metric_relative;       /* 1: poses cluster when the angle of their RELATIVE rotation is below
                                         rotation_threshold (PCL); 0: when their rotation angles differ by less (OpenCV) */
-  int32_t reserved;
+  int32_t alpha_range_2pi;           /* 1: alpha_m - alpha_s is wrapped into [-pi, pi] and binned over 2 pi, numAngles bins of
+                                        2 pi / numAngles (PCL); 0: the unwrapped difference over 4 pi (OpenCV) */
 } ppf_match_params;
 #define PPF_VOTE_AUTO 0
 #define PPF_VOTE_DIRECT 1

@@ -18,10 +18,11 @@
  * SEMANTICS (stated, not hidden): these classes switch the engine's PCL policy flags on -- the model table is keyed
  * on the exact quantised feature (ppf_train_params.key_equality = PPF_KEY_EXACT, PPFHashMapSearch's hash map with
  * key equality), a reference point is paired with the scene points within model_diameter / 2
- * (ppf_match_params.pair_radius, PPFRegistration's kd-tree radius search), and poses cluster on the angle of their
- * relative rotation (rot_metric_relative).  What remains of the library the reference really uses (OpenCV's
- * surface_matching): the three acos angles as pair feature instead of PCL's Darboux-frame angles, and alpha
- * differences binned over 4*pi.  Both change individual vote counts, not the method.  Point types only need members
+ * (ppf_match_params.pair_radius, PPFRegistration's kd-tree radius search), alpha differences are wrapped into
+ * [-pi, pi] and binned over 2*pi (alpha_range_2pi), and poses cluster on the angle of their relative rotation
+ * (rot_metric_relative).  What remains of the library the reference really uses (OpenCV's surface_matching): the three
+ * acos angles as pair feature instead of PCL's Darboux-frame values, and fp64 arithmetic where PCL computes in float.
+ * Both change individual vote counts, not the method.  Point types only need members
  * x, y, z, normal_x, normal_y, normal_z (pcl::PointNormal qualifies); clouds only need `.points` or to be a
  * std::vector of such points.  Compiles without PCL and without Eigen.
  */
@@ -159,6 +160,7 @@ class PPFRegistration {
     mp.rotation_threshold = rot_thr_;
     mp.pair_radius = 0.5 * (double)search_->getModelDiameter(); /* the radius search of computeTransformation() */
     mp.rot_metric_relative = 1;                                 /* posesWithinErrorBounds(): angle of the relative rotation */
+    mp.alpha_range_2pi = 1;                                     /* alpha wrapped into [-pi, pi], bins of the angle discretisation step */
     const int n = (int)(scene_rows_.size() / 6);
     std::vector<ppf_pose> out((size_t)n / rate_ + 8);
     int n_out = 0;

@@ -292,6 +292,9 @@ struct Model {
   bool key_exact = false;
   double pair_radius = 0.0;
   bool rot_relative = false;
+  /*   alpha_2pi     PPFRegistration wraps alpha_m - alpha_s into [-pi, pi] and bins it over 2 pi (numAngles bins of
+   *                 2 pi / numAngles); OpenCV bins the unwrapped difference over 4 pi */
+  bool alpha_2pi = false;
   std::vector<int32_t> pair_key; /* N^2 x 4: quantised key of every model pair */
 };
 
@@ -478,7 +481,14 @@ VoteResult voteOneRef(const Model& m, const float* surf, int /*nSurf*/, const fl
       const float* ppfCorrScene = &m.ppf[(size_t)tData.ppfInd * 5];
       double alpha_model = (double)ppfCorrScene[4];
       double alpha = alpha_model - alpha_scene;
-      int alpha_index = d2i(numAngles * (alpha + 2 * M_PI) / (4 * M_PI));
+      int alpha_index;
+      if (m.alpha_2pi) {
+        if (alpha < -M_PI) alpha += 2 * M_PI; else if (alpha > M_PI) alpha -= 2 * M_PI;
+        alpha_index = d2i(numAngles * (alpha + M_PI) / (2 * M_PI));
+        if (alpha_index >= numAngles) alpha_index = numAngles - 1; /* alpha == +pi exactly */
+      } else {
+        alpha_index = d2i(numAngles * (alpha + 2 * M_PI) / (4 * M_PI));
+      }
       size_t accIndex = (size_t)((int64_t)corrI * numAngles + alpha_index);
       /* alpha_index == numAngles happens (alpha_model is a float: (float)pi > pi) and upstream then
        * increments the next reference point's bin 0, or writes past the buffer for the last one.
@@ -516,7 +526,7 @@ void assemblePose(const Model& m, const float* surf, int i, const VoteResult& v,
   computeTransformRT<M>(v3(pm), v3(pm + 3), Rmg, tmg);
   rtToPose(Rmg, tmg, Tmg);
   int alpha_index = (int)v.alphaIndMax;
-  double alpha = (alpha_index * (4 * M_PI)) / numAngles - 2 * M_PI;
+  double alpha = m.alpha_2pi ? (alpha_index * (2 * M_PI)) / numAngles - M_PI : (alpha_index * (4 * M_PI)) / numAngles - 2 * M_PI;
   const double sx = M::sin_(alpha), cx = M::cos_(alpha);
   M33 Rx{{{1, 0, 0}, {0, cx, -sx}, {0, sx, cx}}};
   rtToPose(Rx, V3{0, 0, 0}, Talpha);
@@ -712,11 +722,12 @@ void oracle_set_search_params(void* h, double positionThreshold, double rotation
   m->use_weighted_avg = useWeighted != 0;
 }
 
-void oracle_set_policy(void* h, int keyExact, double pairRadius, int rotRelative) {
+void oracle_set_policy(void* h, int keyExact, double pairRadius, int rotRelative, int alpha2pi) {
   Model* m = (Model*)h;
   m->key_exact = keyExact != 0;
   m->pair_radius = pairRadius;
   m->rot_relative = rotRelative != 0;
+  m->alpha_2pi = alpha2pi != 0;
 }
 
 void oracle_model_info(void* h, int* nRef, uint32_t* slots, double* angleStep, double* distanceStep, int* numAngles) {

@@ -91,7 +91,7 @@ def lib():
         L.oracle_train.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         L.oracle_free.argtypes = [C.c_void_p]
         L.oracle_set_search_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
-        L.oracle_set_policy.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+        L.oracle_set_policy.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int]
         L.oracle_model_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.oracle_model_sampled.argtypes = [C.c_void_p, fp]
@@ -195,9 +195,9 @@ class OracleDetector:
     def set_search_params(self, position_threshold=-1.0, rotation_threshold=-1.0, use_weighted=False):
         lib().oracle_set_search_params(self.h, position_threshold, rotation_threshold, int(use_weighted))
 
-    def set_policy(self, key_exact=False, pair_radius=0.0, rot_relative=False):
-        """PCL-semantics switches (oracle/ppf_oracle.cpp: Model::key_exact / pair_radius / rot_relative)."""
-        lib().oracle_set_policy(self.h, int(key_exact), float(pair_radius), int(rot_relative))
+    def set_policy(self, key_exact=False, pair_radius=0.0, rot_relative=False, alpha_2pi=False):
+        """PCL-semantics switches (oracle/ppf_oracle.cpp: Model::key_exact / pair_radius / rot_relative / alpha_2pi)."""
+        lib().oracle_set_policy(self.h, int(key_exact), float(pair_radius), int(rot_relative), int(alpha_2pi))
         return self
 
     def info(self) -> dict:

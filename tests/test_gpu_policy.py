@@ -1,5 +1,5 @@
 """PCL-semantics policy switches (closing paragraph): exact key equality, pair radius, relative
-rotation metric.  Each is checked against the oracle run with the same switch; all off is the reference's (OpenCV)
+rotation metric, 2 pi alpha range.  Each is checked against the oracle run with the same switch; all off is the reference's (OpenCV)
 behaviour every other test covers.  "parity unpinned": PCL's ppf_registration is not in the container either."""
 import numpy as np
 import pytest
@@ -72,11 +72,24 @@ def test_relative_rotation_metric(bottle, crop):
     assert len(plain.match(crop, STEP, 0.05, presampled=True)) != want["n_final"]
 
 
-def test_all_three_together(bottle, crop):
+def test_alpha_range_2pi(bottle, crop):
+    """alpha_m - alpha_s wrapped into [-pi, pi] and binned over 2 pi (12-degree bins at numAngles = 30) instead of the
+    unwrapped difference over 4 pi (24-degree bins): other triples, same exactness; also with 20 and 45 bins."""
+    for num_angles in (30, 20, 45):
+        det = PPF3DDetector(0.05, 0.05, num_angles).trainModel(bottle).setPolicy(alpha_range_2pi=True)
+        ora = O.OracleDetector(0.05, 0.05, num_angles).train_model(bottle).set_policy(alpha_2pi=True)
+        got, _ = _compare(det, ora, crop)
+        plain = PPF3DDetector(0.05, 0.05, num_angles).trainModel(bottle).raw_votes(crop, STEP, 0.05, presampled=True)
+        assert plain["stats"]["n_votes"] == got["stats"]["n_votes"]           # the same pairs vote ...
+        assert not np.array_equal(plain["triples"], got["triples"])           # ... into other bins
+
+
+def test_all_four_together(bottle, crop):
     det = PPF3DDetector(0.05, 0.05, key_equality=1).trainModel(bottle)
     radius = 0.5 * det.info()["diameter"]
     det.setSearchParams(0.02, 0.35)
-    det.setPolicy(pair_radius=radius, rot_metric_relative=True)
-    ora = O.OracleDetector(0.05, 0.05).train_model(bottle).set_policy(key_exact=True, pair_radius=radius, rot_relative=True)
+    det.setPolicy(pair_radius=radius, rot_metric_relative=True, alpha_range_2pi=True)
+    ora = O.OracleDetector(0.05, 0.05).train_model(bottle).set_policy(key_exact=True, pair_radius=radius, rot_relative=True,
+                                                                      alpha_2pi=True)
     ora.set_search_params(0.02, 0.35)
     _compare(det, ora, crop)

@@ -36,7 +36,7 @@ class MatchParams(C.Structure):
                 ("position_threshold", C.c_double), ("rotation_threshold", C.c_double),
                 ("use_weighted_avg", C.c_int32), ("presampled", C.c_int32), ("ref_offset", C.c_int32),
                 ("ref_stride", C.c_int32), ("skip_clustering", C.c_int32), ("vote_mode", C.c_int32),
-                ("pair_radius", C.c_double), ("rot_metric_relative", C.c_int32), ("reserved", C.c_int32)]
+                ("pair_radius", C.c_double), ("rot_metric_relative", C.c_int32), ("alpha_range_2pi", C.c_int32)]
 
 
 class IcpParams(C.Structure):

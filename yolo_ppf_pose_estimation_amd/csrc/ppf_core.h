@@ -126,6 +126,15 @@ PPF_HD int32_t ppf_alpha_bin_exact(float alpha_m, double alpha_s, int num_angles
   return ppf_d2i(num_angles * (alpha + 2 * PPF_PI) / (4 * PPF_PI));
 }
 
+/* PCL's binning (policy switch alpha_range_2pi): the difference wrapped into [-pi, pi], numAngles bins of 2pi/numAngles */
+PPF_HD int32_t ppf_alpha_bin_exact_2pi(float alpha_m, double alpha_s, int num_angles) {
+  double alpha = (double)alpha_m - alpha_s;
+  if (alpha < -PPF_PI) alpha += 2 * PPF_PI;
+  else if (alpha > PPF_PI) alpha -= 2 * PPF_PI;
+  const int32_t k = ppf_d2i(num_angles * (alpha + PPF_PI) / (2 * PPF_PI));
+  return k >= num_angles ? num_angles - 1 : k; /* alpha == +pi exactly */
+}
+
 /* ---- pose algebra (row A8) ------------------------------------------------------------------ */
 PPF_HD void ppf_mat44_mul(const double* A, const double* B, double* C) {
   for (int i = 0; i < 4; i++)

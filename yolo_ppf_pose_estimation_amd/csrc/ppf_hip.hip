@@ -506,6 +506,7 @@ struct FinalArgs {
   CloudSoA surf, model;
   int scene_step, ref_offset, ref_stride, n_ref;
   int n_tiles, tile_refs, num_angles;
+  int alpha_2pi; /* PCL's alpha binning: the winning bin stands for idx * 2pi/A - pi */
   const uint2* partial;
   const unsigned long long* cellsum;
   const unsigned long long* pairs;
@@ -544,7 +545,8 @@ __global__ void k_finalize(FinalArgs a) {
   double TsgInv[16], Tmg[16], Talpha[16], tmp[16], raw[16];
   ppf_rt_to_pose(RInv, tInv, TsgInv);
   ppf_rt_to_pose(Rmg, tmg, Tmg);
-  const double alpha = ((int)alphaIndMax * (4 * PPF_PI)) / a.num_angles - 2 * PPF_PI;
+  const double alpha = a.alpha_2pi ? ((int)alphaIndMax * (2 * PPF_PI)) / a.num_angles - PPF_PI
+                                   : ((int)alphaIndMax * (4 * PPF_PI)) / a.num_angles - 2 * PPF_PI;
   const double sx = ppf_sin(alpha), cx = ppf_cos(alpha);
   const double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
   const double t0[3] = {0, 0, 0};
@@ -1815,7 +1817,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.bucket_total = m->bucket_total.p;
   va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
   va.pair_radius = params->pair_radius;
-  va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
+  va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || params->alpha_range_2pi || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
   const int n_paired = va.paired.n;
   va.pair_chunks = (n_paired + PAIR_BLOCK * PAIRS_PER_THREAD - 1) / (PAIR_BLOCK * PAIRS_PER_THREAD);
   const uint32_t round_cap = ws->round_buckets_cap > 0 ? (uint32_t)std::min(ws->round_buckets_cap, GROUP_MAX_BUCKETS) : (uint32_t)GROUP_MAX_BUCKETS;
@@ -1898,7 +1900,9 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr_err == hipSuccess)
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES - 1024);
   });
@@ -1933,7 +1937,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 2], st));
-    k_vote<<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
+    if (params->alpha_range_2pi) k_vote<true><<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
+    else k_vote<false><<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 3], st));
   }
@@ -1942,6 +1947,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   fa.surf = ws->surf.view(); fa.model = m->cloud.view();
   fa.scene_step = scene_step; fa.ref_offset = params->ref_offset; fa.ref_stride = params->ref_stride; fa.n_ref = n_ref;
   fa.n_tiles = T; fa.tile_refs = m->info.tile_refs; fa.num_angles = m->info.num_angles;
+  fa.alpha_2pi = params->alpha_range_2pi != 0;
   fa.partial = ws->partial.p; fa.cellsum = va.cellsum; fa.pairs = va.pairs;
   fa.votes = ws->votes.p; fa.poses = ws->raw_poses.p;
   fa.totals = ws->counters.p + (size_t)n_ref * T + n_ref;

@@ -573,6 +573,24 @@ __device__ __forceinline__ uint32_t lds_ld8(const uint32_t addr) { return *(vola
 /* order the LDS phases of one wave (LDS executes a wave's operations in order; this keeps the compiler from moving them) */
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
+/* WRAP (policy alpha_range_2pi): q' = (alpha_m - alpha_s)*A/(2pi) + 3A/2 + G lies in (A/2, 5A/2); the bin of the wrapped
+ * difference is trunc(q') - A reduced into [0, A).  The wrap thresholds sit on integers of q' - G, i.e. on bin edges: the
+ * guard band that sends near-edge votes to the fp64 chain covers them as well. */
+template <bool WRAP>
+__device__ __forceinline__ int vote_wrap(int t, const int A) {
+  if constexpr (WRAP) {
+    t -= A;
+    t = t < 0 ? t + A : t;
+    t = t >= A ? t - A : t;
+  }
+  return t;
+}
+template <bool WRAP>
+__device__ __forceinline__ int vote_bin_exact(const float am, const double as, const int A) {
+  if constexpr (WRAP) return ppf_alpha_bin_exact_2pi(am, as, A);
+  else return ppf_alpha_bin_exact(am, as, A);
+}
+
 template <int U>
 __device__ __forceinline__ void load_records(uint4* rec, const uint4* __restrict__ src, const uint32_t e0, const int lane) {
 #pragma unroll
@@ -580,16 +598,16 @@ __device__ __forceinline__ void load_records(uint4* rec, const uint4* __restrict
 }
 
 /* the bins of 2U votes against one hit; frmin = smallest fractional part (guard-band check) */
-template <int U>
-__device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const float Ohg, int (&ka)[U], int (&kb)[U], float& frmin_out) {
+template <int U, bool WRAP>
+__device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const float Ohg, const int A, int (&ka)[U], int (&kb)[U], float& frmin_out) {
   float fa[U], fb[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
     /* two scalar v_fma_f32: measured faster than one v_pk_fma_f32 on gfx950 */
     const float qa = __builtin_fmaf(__uint_as_float(rec[u].z), S, Ohg);
     const float qb = __builtin_fmaf(__uint_as_float(rec[u].w), S, Ohg);
-    ka[u] = (int)qa;
-    kb[u] = (int)qb;
+    ka[u] = vote_wrap<WRAP>((int)qa, A);
+    kb[u] = vote_wrap<WRAP>((int)qb, A);
     fa[u] = __builtin_amdgcn_fractf(qa);
     fb[u] = __builtin_amdgcn_fractf(qb);
   }
@@ -605,7 +623,7 @@ __device__ __forceinline__ void vote_bins(const uint4* rec, const float S, const
   frmin_out = frmin;
 }
 /* rare path: votes within the guard band of a bin edge get the exact fp64 bin */
-template <int U>
+template <int U, bool WRAP>
 __device__ __forceinline__ void vote_fix(const uint4* rec, const float S, const float Ohg, const double* __restrict__ asd,
                                          const float G2, const int A, const float frmin, int (&ka)[U], int (&kb)[U]) {
   if (__builtin_expect(__any(frmin < G2), 0)) {
@@ -615,8 +633,8 @@ __device__ __forceinline__ void vote_fix(const uint4* rec, const float S, const 
       uint32_t za = rec[u].z, zb = rec[u].w;
       asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the hot loop */
       const float aa = __uint_as_float(za), ab = __uint_as_float(zb);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = ppf_alpha_bin_exact(aa, as, A);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = ppf_alpha_bin_exact(ab, as, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(aa, S, Ohg)) < G2) ka[u] = vote_bin_exact<WRAP>(aa, as, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(ab, S, Ohg)) < G2) kb[u] = vote_bin_exact<WRAP>(ab, as, A);
     }
   }
 }
@@ -633,24 +651,24 @@ __device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32
   }
 }
 /* one pipeline stage: the atomics of the previous hit (bins pka/pkb) under the bin arithmetic of hit hh (-> nka/nkb) */
-template <int U>
+template <int U, bool WRAP>
 __device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, const float S, const float ohg_v, const int hh,
                                            const double* __restrict__ asd, const float G2, const int A, const uint32_t (&pa)[U],
                                            const uint32_t (&pb)[U], const int (&pka)[U], const int (&pkb)[U], int (&nka)[U], int (&nkb)[U]) {
   float frmin;
   const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
   vote_issue<U>(pa, pb, pka, pkb, n_valid);
-  vote_bins<U>(rec, S, Ohg, nka, nkb, frmin);
+  vote_bins<U, WRAP>(rec, S, Ohg, A, nka, nkb, frmin);
 #pragma unroll
   for (int i = 0; i < 2 * U; i++) {
     __builtin_amdgcn_sched_group_barrier(0x002, PPF_PIPE_VALU, 0); /* VALU */
     __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); /* DS */
   }
-  vote_fix<U>(rec, S, Ohg, asd + hh, G2, A, frmin, nka, nkb);
+  vote_fix<U, WRAP>(rec, S, Ohg, asd + hh, G2, A, frmin, nka, nkb);
 }
 /* all hits of a direct work item against one register batch of records; two sets of bins alternate so that a set is only
  * overwritten a full stage after the atomics that used it were issued */
-template <int U>
+template <int U, bool WRAP>
 __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* rec, const int n_valid, const float S,
                                           const float ohg_v, const int nh, const double* __restrict__ asd, const float G2,
                                           const int A) {
@@ -665,16 +683,16 @@ __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* 
   {
     float frmin;
     const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), 0));
-    vote_bins<U>(rec, S, Ohg, ka0, kb0, frmin);
-    vote_fix<U>(rec, S, Ohg, asd, G2, A, frmin, ka0, kb0);
+    vote_bins<U, WRAP>(rec, S, Ohg, A, ka0, kb0, frmin);
+    vote_fix<U, WRAP>(rec, S, Ohg, asd, G2, A, frmin, ka0, kb0);
   }
   int hh = 1;
   for (; hh + 1 < nh; hh += 2) {
-    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
-    vote_stage<U>(rec, n_valid, S, ohg_v, hh + 1, asd, G2, A, pa, pb, ka1, kb1, ka0, kb0);
+    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
+    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh + 1, asd, G2, A, pa, pb, ka1, kb1, ka0, kb0);
   }
   if (hh < nh) {
-    vote_stage<U>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
+    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
     vote_issue<U>(pa, pb, ka1, kb1, n_valid);
   } else {
     vote_issue<U>(pa, pb, ka0, kb0, n_valid);
@@ -684,6 +702,7 @@ __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* 
 /* Runs of at most 32 pair records in this tile (64 entries: more than half of all (tile, bucket) runs): one ENTRY per
  * lane instead of one pair record per lane, so the 64 lanes of the single group are filled twice as well and a hit costs
  * one fma/cvt/fract/lshl_add/ds_add instead of two of each.  Same bins, same guard band, same exact fallback. */
+template <bool WRAP>
 __device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const uint32_t row_bytes, const uint32_t alpha_bits,
                                                  const float S, const float ohg_v, const int nh, const double* __restrict__ asd,
                                                  const float G2, const int A) {
@@ -695,13 +714,13 @@ __device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const 
     const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
     if (hh) lds_add(adr_prev, 1u);
     const float q = __builtin_fmaf(am, S, Ohg);
-    int k = (int)q;
+    int k = vote_wrap<WRAP>((int)q, A);
     if (__builtin_expect(__any(__builtin_amdgcn_fractf(q) < G2), 0)) {
       const double as = asd[hh];
       uint32_t z = alpha_bits;
       asm volatile("" : "+v"(z));
       const float az = __uint_as_float(z);
-      if (__builtin_amdgcn_fractf(__builtin_fmaf(az, S, Ohg)) < G2) k = ppf_alpha_bin_exact(az, as, A);
+      if (__builtin_amdgcn_fractf(__builtin_fmaf(az, S, Ohg)) < G2) k = vote_bin_exact<WRAP>(az, as, A);
     }
     adr_prev = pr + ((uint32_t)k << 2);
   }
@@ -926,6 +945,8 @@ __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, i
 #endif
 }
 
+/* WRAP: PCL's alpha binning (2 pi range with wrap-around, policy switch alpha_range_2pi): direct votes only */
+template <bool WRAP>
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
@@ -960,24 +981,27 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
   const uint4* __restrict__ records = a.records;
-  const float S = (float)((double)A / (4 * PPF_PI));
+  const double s64 = WRAP ? (double)A / (2 * PPF_PI) : (double)A / (4 * PPF_PI);
+  const float S = (float)s64;
 #ifdef PPF_FORCE_EXACT
   const float G = 1.0f; /* test build: every direct vote takes the fp64 chain */
 #else
-  const float G = PPF_GUARD_REL * (float)A;
+  /* guard band: the fp32 error bound is 1.1e-7*A; with the 2 pi range q' reaches 2.5 A and its
+   * rounding steps are four times coarser (bound 3.7e-7*A) */
+  const float G = (WRAP ? 1.6e-6f : PPF_GUARD_REL) * (float)A;
 #endif
   const float G2 = 2.0f * G;
-  const float Og = 0.5f * (float)A + G;
+  const double og64 = (WRAP ? 1.5 : 0.5) * (double)A + (double)G; /* folded offsets are formed in fp64 and rounded once */
   const uint32_t tail_bytes = (uint32_t)(lane * 4 + 8); /* per-lane guard word for lanes past the end of a bucket (words 2..65: the count
                                                           table path also touches the word below the row's bin 0) */
   AggConsts ak;
   ak.acc_base = (uint32_t)(uintptr_t)(lds_byte*)reinterpret_cast<unsigned char*>(lds_acc);
   ak.ws = (uint32_t)(uintptr_t)(lds_byte*)(wave_scratch + wave * AGG_SCRATCH);
-  ak.S = S; ak.half_a = 0.5f * (float)A; ak.Og = Og; ak.G2 = G2;
-  ak.s64 = (double)A / (4 * PPF_PI); ak.half_a64 = 0.5 * (double)A;
+  ak.S = S; ak.half_a = 0.5f * (float)A; ak.Og = (float)og64; ak.G2 = G2;
+  ak.s64 = s64; ak.half_a64 = 0.5 * (double)A;
   ak.A = A;
   const uint32_t acc_base = ak.acc_base;
-  const uint32_t agg_min = (a.agg_min_hits > 0 && A <= AGG_MAX_ANGLES) ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
+  const uint32_t agg_min = (!WRAP && a.agg_min_hits > 0 && A <= AGG_MAX_ANGLES) ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
   unsigned long long ops = 0; /* LDS atomic lane-operations issued by this wave (wave-uniform part) */
   uint32_t agg_votes = 0;     /* ... plus this lane's one-by-one votes on the count-table path */
 
@@ -1069,7 +1093,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint32_t c = cur.c;
           const int nh = cur.nh;
           /* lane l holds the folded offset of hit g0+l: Ohg = A/2 + G - alpha_s*S */
-          const float ohg_v = lane < nh ? Og - (float)cur.a64 * S : 0.f;
+          const float ohg_v = lane < nh ? (WRAP ? (float)(og64 - cur.a64 * s64) : (float)og64 - (float)cur.a64 * S) : 0.f;
           const double* __restrict__ asd = a.s_a64 + cur.g0; /* exact alpha_s, read on the guard path only */
           const uint4* __restrict__ src = cur.src;
           constexpr uint32_t B = 64 * VOTE_UNROLL; /* records per batch */
@@ -1088,10 +1112,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           uint32_t b = 0;
           while (b < nfull) {
             load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
-            vote_hits<VOTE_UNROLL>(acc_base, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+            vote_hits<VOTE_UNROLL, WRAP>(acc_base, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
             if (++b >= nfull) break;
             load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
-            vote_hits<VOTE_UNROLL>(acc_base, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+            vote_hits<VOTE_UNROLL, WRAP>(acc_base, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
             ++b;
           }
           const uint32_t e0 = nfull * B;
@@ -1100,13 +1124,13 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             const uint4 rr = cur.rec0;
             const bool second = (lane & 1) != 0;
             const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            vote_hits_single(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            vote_hits_single<WRAP>(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
           } else if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
             const uint32_t e = e0 + ((uint32_t)lane >> 1);
             const uint4 rr = src[min(e, c - 1)];
             const bool second = (lane & 1) != 0;
             const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            vote_hits_single(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            vote_hits_single<WRAP>(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
           } else if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
 #pragma unroll
             for (int u = 0; u < VOTE_UNROLL; u++) {
@@ -1119,10 +1143,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
              * their bin arithmetic, through an instantiation per group count */
             static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
             switch (n_valid) {
-              case 1: vote_hits<1>(acc_base, ea, 1, S, ohg_v, nh, asd, G2, A); break;
-              case 2: vote_hits<2>(acc_base, ea, 2, S, ohg_v, nh, asd, G2, A); break;
-              case 3: vote_hits<3>(acc_base, ea, 3, S, ohg_v, nh, asd, G2, A); break;
-              default: vote_hits<4>(acc_base, ea, 4, S, ohg_v, nh, asd, G2, A); break;
+              case 1: vote_hits<1, WRAP>(acc_base, ea, 1, S, ohg_v, nh, asd, G2, A); break;
+              case 2: vote_hits<2, WRAP>(acc_base, ea, 2, S, ohg_v, nh, asd, G2, A); break;
+              case 3: vote_hits<3, WRAP>(acc_base, ea, 3, S, ohg_v, nh, asd, G2, A); break;
+              default: vote_hits<4, WRAP>(acc_base, ea, 4, S, ohg_v, nh, asd, G2, A); break;
             }
           }
         }

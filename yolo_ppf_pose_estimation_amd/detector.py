@@ -95,6 +95,7 @@ class PPF3DDetector:
         self._key_equality = int(key_equality)  # 0: whole hash bucket votes (OpenCV); 1: exact quantised key (PCL)
         self._pair_radius = 0.0                 # > 0: scene pairs within this distance only (PCL)
         self._rot_metric_relative = False       # cluster on the relative rotation angle (PCL)
+        self._alpha_range_2pi = False           # alpha differences wrapped into [-pi, pi], binned over 2 pi (PCL)
         self._position_threshold = -1.0
         self._rotation_threshold = -1.0
         self._use_weighted_avg = False
@@ -107,6 +108,7 @@ class PPF3DDetector:
                           distance_from_distance_step=self._dist_flag, max_tile_refs=self._max_tile_refs,
                           key_equality=self._key_equality)
         d._pair_radius, d._rot_metric_relative = self._pair_radius, self._rot_metric_relative
+        d._alpha_range_2pi = self._alpha_range_2pi
         d._position_threshold, d._rotation_threshold = self._position_threshold, self._rotation_threshold
         d._use_weighted_avg = self._use_weighted_avg
         d._model = self._model
@@ -122,11 +124,12 @@ class PPF3DDetector:
         self._rotation_threshold = float(rotationThreshold)
         self._use_weighted_avg = bool(useWeightedClustering)
 
-    def setPolicy(self, pair_radius: float = 0.0, rot_metric_relative: bool = False):
+    def setPolicy(self, pair_radius: float = 0.0, rot_metric_relative: bool = False, alpha_range_2pi: bool = False):
         """PCL-semantics switches of the match (ppf_match_params.pair_radius / rot_metric_relative); the key policy is a
         constructor argument because it shapes the trained table."""
         self._pair_radius = float(pair_radius)
         self._rot_metric_relative = bool(rot_metric_relative)
+        self._alpha_range_2pi = bool(alpha_range_2pi)
         return self
 
     # -- training ---------------------------------------------------------------------------------
@@ -202,6 +205,7 @@ class PPF3DDetector:
         mp.vote_mode = int(vote_mode)  # 0: count tables for runs of many hits, 1: one atomic per (entry, hit)
         mp.pair_radius = self._pair_radius
         mp.rot_metric_relative = int(self._rot_metric_relative)
+        mp.alpha_range_2pi = int(self._alpha_range_2pi)
         return mp
 
     def match(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
