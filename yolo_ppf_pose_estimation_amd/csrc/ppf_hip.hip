@@ -1893,7 +1893,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)m->info.tile_refs * vote_pitch(m->info.num_angles)) * 4;
   if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
   /* k_group's dynamic LDS: counters, chunk prefix, and as many cached alpha_s as the rest holds */
-  const size_t group_fixed = (size_t)va.round_buckets * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
+  const size_t group_fixed = (size_t)((va.round_buckets + 1) & ~1) * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
   if (group_fixed + 2048 > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: %d paired points are more than one call can group", n_paired);
   va.group_cache = (int)std::min<size_t>((size_t)n_paired, ((size_t)LDS_BYTES - 1024 - group_fixed) / sizeof(double));
   const size_t group_lds = group_fixed + (size_t)va.group_cache * sizeof(double);

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   __shared__ uint32_t sh[4];
   const int r = a.perm_group ? (int)a.perm_group[blockIdx.x] : (int)blockIdx.x; /* most hits first: no long block at the tail */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t* cpre = gcnt + a.round_buckets;                                  /* pair_chunks + 1 */
+  uint32_t* cpre = gcnt + ((a.round_buckets + 1) & ~1);                     /* pair_chunks + 1 (even offsets: the doubles behind stay 8-byte aligned) */
   double* acache = reinterpret_cast<double*>(cpre + ((a.pair_chunks + 2) & ~1)); /* group_cache */
   const uint32_t n_raw = (uint32_t)a.hit_count[r];
   const uint2* __restrict__ desc = a.chunk_desc + (size_t)r * a.pair_chunks;
