@@ -11,7 +11,7 @@ import sys
 def load(path, kern):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
-        if row["Kernel_Name"].startswith(kern):
+        if row["Kernel_Name"].replace("void ", "").split("<")[0].split("(")[0].strip() == kern:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 

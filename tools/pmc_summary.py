@@ -16,7 +16,7 @@ import sys
 def load(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"].split("(")[0]
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()  # "void k_vote<false>(MatchArgs)" -> k_vote
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
