@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define PPF_ABI_VERSION 2
+#define PPF_ABI_VERSION 3
 
 typedef enum ppf_status {
   PPF_OK = 0,
@@ -84,9 +84,16 @@ typedef struct ppf_train_params {
   int32_t key_equality;           /* PPF_KEY_BUCKET (0, the reference's library): a scene pair votes for every model pair
                                      in its hash bucket, colliding keys included; PPF_KEY_EXACT (1, PCL PPFHashMapSearch):
                                      only for model pairs with the same quantised key */
+  int32_t feature;                /* PPF_FEATURE_PPF (0, the reference's library): three acos angles + distance, truncated;
+                                     PPF_FEATURE_DARBOUX (1, PCL PPFEstimation / pcl::computePairFeatures): atan2 angle and
+                                     two cosines of the Darboux frame + distance, keys floor(f / step).  A property of the
+                                     trained table; matching follows the model. */
+  int32_t reserved;               /* 0 */
 } ppf_train_params;
 #define PPF_KEY_BUCKET 0
 #define PPF_KEY_EXACT 1
+#define PPF_FEATURE_PPF 0
+#define PPF_FEATURE_DARBOUX 1
 
 typedef struct ppf_match_params {
   double relative_scene_sample_step; /* match() arg 3: every (int)(1/x)-th sampled scene point is a reference */

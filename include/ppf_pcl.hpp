@@ -15,14 +15,15 @@
  *     reg.setSearchMethod(search); reg.setInputSource(model); reg.setInputTarget(scene);
  *     reg.align(output);  reg.getFinalTransformation();
  *
- * SEMANTICS (stated, not hidden): these classes switch the engine's PCL policy flags on -- the model table is keyed
- * on the exact quantised feature (ppf_train_params.key_equality = PPF_KEY_EXACT, PPFHashMapSearch's hash map with
- * key equality), a reference point is paired with the scene points within model_diameter / 2
+ * SEMANTICS (stated, not hidden): these classes switch the engine's PCL policy flags on -- the pair feature is
+ * pcl::computePairFeatures' (ppf_train_params.feature = PPF_FEATURE_DARBOUX, keys floor(f / step)), the model table is
+ * keyed on the exact quantised feature (key_equality = PPF_KEY_EXACT, PPFHashMapSearch's hash map with key equality),
+ * a reference point is paired with the scene points within model_diameter / 2
  * (ppf_match_params.pair_radius, PPFRegistration's kd-tree radius search), alpha differences are wrapped into
  * [-pi, pi] and binned over 2*pi (alpha_range_2pi), and poses cluster on the angle of their relative rotation
- * (rot_metric_relative).  What remains of the library the reference really uses (OpenCV's surface_matching): the three
- * acos angles as pair feature instead of PCL's Darboux-frame values, and fp64 arithmetic where PCL computes in float.
- * Both change individual vote counts, not the method.  Point types only need members
+ * (rot_metric_relative).  What remains different from PCL proper: fp64 arithmetic where PCL computes in float (pairs within
+ * rounding of a bin edge can land in the neighbouring bin), and the engine's reference frame / alpha convention (the
+ * reference's library's, applied to model and scene alike, so alpha differences agree).  Point types only need members
  * x, y, z, normal_x, normal_y, normal_z (pcl::PointNormal qualifies); clouds only need `.points` or to be a
  * std::vector of such points.  Compiles without PCL and without Eigen.
  */
@@ -114,6 +115,7 @@ class PPFHashMapSearch {
     ppf_train_params tp;
     ppf_default_train_params(&tp);
     tp.presampled = 1;
+    tp.feature = PPF_FEATURE_DARBOUX; /* PPFEstimation's four values */
     tp.key_equality = PPF_KEY_EXACT; /* nearestNeighborSearch() returns the model pairs with the SAME quantised feature */
     tp.distance_from_distance_step = 1;
     tp.relative_distance_step = dist_step_ / diameter_;

@@ -155,6 +155,42 @@ void computePPFFeatures(const V3& p1, const V3& n1, const V3& p2, const V3& n2, 
   f[2] = M::acos_(dot(n1, n2));
 }
 
+/* PCL's pair feature (policy switch; pcl::computePairFeatures as PPFEstimation / PPFRegistration call it), in fp64 where
+ * PCL computes in float: returns false for degenerate pairs, which PCL leaves out of table and vote alike. */
+template <class M>
+bool computePairFeaturesDarboux(const V3& p1, const V3& n1, const V3& p2, const V3& n2, double f[4]) {
+  V3 d{p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
+  const double f4 = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+  if (!(f4 > 0.0)) return false;
+  const double a1 = dot(n1, d) / f4, a2 = dot(n2, d) / f4;
+  V3 u = n1, n = n2;
+  double f3 = a1;
+  if (std::fabs(a1) < std::fabs(a2)) { /* PCL: acos(|a1|) > acos(|a2|): the other point becomes the source */
+    u = n2; n = n1;
+    d = V3{-d.x, -d.y, -d.z};
+    f3 = -a2;
+  }
+  V3 v{d.y * u.z - d.z * u.y, d.z * u.x - d.x * u.z, d.x * u.y - d.y * u.x};
+  const double vn = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+  if (!(vn > 0.0)) return false;
+  v = V3{v.x / vn, v.y / vn, v.z / vn};
+  const V3 w{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+  f[0] = M::atan2_(dot(w, n), dot(u, n));
+  f[1] = dot(v, n);
+  f[2] = f3;
+  f[3] = f4;
+  return true;
+}
+/* PPFHashMapSearch: keys are floor(f / step), the two cosines divided by the ANGLE step like the angle (PCL's own quirk) */
+uint32_t hashDarboux(const double f[4], double angleStep, double distStep, int32_t keyOut[4]) {
+  int32_t key[4] = {d2i(std::floor(f[0] / angleStep)), d2i(std::floor(f[1] / angleStep)), d2i(std::floor(f[2] / angleStep)),
+                    d2i(std::floor(f[3] / distStep))};
+  if (keyOut) memcpy(keyOut, key, 16);
+  uint64_t h[2];
+  murmur3_x64_128(key, 16, 42, h);
+  return (uint32_t)h[0];
+}
+
 /* upstream aaToR(): Rodrigues rotation from axis/angle. */
 template <class M>
 void aaToR(const V3& axis, double angle, M33& R) {
@@ -295,6 +331,8 @@ struct Model {
   /*   alpha_2pi     PPFRegistration wraps alpha_m - alpha_s into [-pi, pi] and bins it over 2 pi (numAngles bins of
    *                 2 pi / numAngles); OpenCV bins the unwrapped difference over 4 pi */
   bool alpha_2pi = false;
+  /*   darboux       PPFEstimation's pair feature (pcl::computePairFeatures) instead of the three acos angles; fixed at training */
+  bool darboux = false;
   std::vector<int32_t> pair_key; /* N^2 x 4: quantised key of every model pair */
 };
 
@@ -320,6 +358,7 @@ void trainModel(Model& m, const float* pc, int n, int stride, int flags) {
   float diameter = std::sqrt(dx * dx + dy * dy + dz * dz);
   /* upstream: float distanceStep = (float)(diameter * sampling_step_relative);  (NOT the distance step) */
   float distanceStep = (float)(diameter * ((flags & 4) ? m.distance_step_relative : m.sampling_step_relative));
+  m.darboux = (flags & 8) != 0; /* policy: PCL's pair feature, a property of the trained table */
   if (flags & 1) {
     m.sampled_pc.resize((size_t)n * 6);
     for (int i = 0; i < n; i++) memcpy(&m.sampled_pc[(size_t)i * 6], pc + (size_t)i * stride, 24);
@@ -343,9 +382,15 @@ void trainModel(Model& m, const float* pc, int n, int stride, int flags) {
       if (i == j) continue;
       const V3 p2 = v3(S + (size_t)j * 6), n2 = v3(S + (size_t)j * 6 + 3);
       double f[4] = {0, 0, 0, 0};
-      computePPFFeatures<M>(p1, n1, p2, n2, f);
       int ppfInd = i * N + j;
-      uint32_t hashValue = hashPPF(f, m.angle_step_radians, distanceStep, &m.pair_key[(size_t)ppfInd * 4]);
+      uint32_t hashValue;
+      if (m.darboux) {
+        if (!computePairFeaturesDarboux<M>(p1, n1, p2, n2, f)) continue; /* PCL leaves degenerate pairs out */
+        hashValue = hashDarboux(f, m.angle_step_radians, distanceStep, &m.pair_key[(size_t)ppfInd * 4]);
+      } else {
+        computePPFFeatures<M>(p1, n1, p2, n2, f);
+        hashValue = hashPPF(f, m.angle_step_radians, distanceStep, &m.pair_key[(size_t)ppfInd * 4]);
+      }
       double alpha = computeAlpha<M>(p1, n1, p2);
       m.hash_nodes[ppfInd] = THash{hashValue, i, ppfInd};
       /* hashtableInsertHashed: prepend to bucket hash % size */
@@ -463,10 +508,17 @@ VoteResult voteOneRef(const Model& m, const float* surf, int /*nSurf*/, const fl
     if (!sameCloud && memcmp(surf + (size_t)i * 6, paired + (size_t)j * 6, 24) == 0) continue;
     const V3 p2 = v3(paired + (size_t)j * 6), n2 = v3(paired + (size_t)j * 6 + 3);
     double f[4] = {0, 0, 0, 0};
-    computePPFFeatures<M>(p1, n1, p2, n2, f);
-    if (m.pair_radius > 0 && f[3] > m.pair_radius) continue; /* policy: neighbours within a radius only */
     int32_t sceneKey[4];
-    uint32_t hashValue = hashPPF(f, m.angle_step, distanceStep, sceneKey);
+    uint32_t hashValue;
+    if (m.darboux) {
+      if (!computePairFeaturesDarboux<M>(p1, n1, p2, n2, f)) continue;
+      if (m.pair_radius > 0 && f[3] > m.pair_radius) continue;
+      hashValue = hashDarboux(f, m.angle_step, distanceStep, sceneKey);
+    } else {
+      computePPFFeatures<M>(p1, n1, p2, n2, f);
+      if (m.pair_radius > 0 && f[3] > m.pair_radius) continue; /* policy: neighbours within a radius only */
+      hashValue = hashPPF(f, m.angle_step, distanceStep, sceneKey);
+    }
     V3 rp = mulMV(Rsg, p2);
     V3 p2t{tsg.x + rp.x, tsg.y + rp.y, tsg.z + rp.z};
     double alpha_scene;
@@ -858,6 +910,18 @@ uint32_t oracle_pair_feature(const float* p1, const float* n1, const float* p2, 
   else computePPFFeatures<MathDet>(v3(p1), v3(n1), v3(p2), v3(n2), f);
   if (f4) memcpy(f4, f, sizeof(f));
   return hashPPF(f, angleStep, distStep, key4);
+}
+/* the same for PCL's feature; returns 0 for a degenerate pair (f, key untouched), 1 otherwise with *hash set */
+int oracle_pair_feature_darboux(const float* p1, const float* n1, const float* p2, const float* n2, double angleStep,
+                                double distStep, int mode, double* f4, int32_t* key4, uint32_t* hash) {
+  double f[4] = {0, 0, 0, 0};
+  const bool ok = mode == 1 ? computePairFeaturesDarboux<MathLibm>(v3(p1), v3(n1), v3(p2), v3(n2), f)
+                            : computePairFeaturesDarboux<MathDet>(v3(p1), v3(n1), v3(p2), v3(n2), f);
+  if (!ok) return 0;
+  if (f4) memcpy(f4, f, sizeof(f));
+  const uint32_t h = hashDarboux(f, angleStep, distStep, key4);
+  if (hash) *hash = h;
+  return 1;
 }
 void oracle_transform_rt(const float* p, const float* n, int mode, double* R9, double* t3) {
   M33 R; V3 t;

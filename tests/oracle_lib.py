@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "libppf_oracle.so")
 
 FLAG_PRESAMPLED = 1
 FLAG_DIST_FROM_DISTANCE_STEP = 4
+FLAG_FEATURE_DARBOUX = 8
 MODE_DET, MODE_LIBM = 0, 1
 
 
@@ -110,6 +111,9 @@ def lib():
         L.oracle_cluster.restype = C.c_int
         L.oracle_cluster.argtypes = [C.c_void_p, C.POINTER(OraclePose), C.c_int, C.c_int, C.POINTER(OraclePose), C.c_int]
         L.oracle_murmur3_x64_128.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.oracle_pair_feature_darboux.restype = C.c_int
+        L.oracle_pair_feature_darboux.argtypes = [fp, fp, fp, fp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
         L.oracle_pair_feature.restype = C.c_uint32
         L.oracle_pair_feature.argtypes = [fp, fp, fp, fp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_int32)]
@@ -180,10 +184,10 @@ class OracleDetector:
         except Exception:
             pass
 
-    def train_model(self, pc: np.ndarray, presampled: bool = False):
+    def train_model(self, pc: np.ndarray, presampled: bool = False, darboux: bool = False):
         pc, p = _f32(pc)
         assert pc.ndim == 2 and pc.shape[1] >= 6
-        flags = (FLAG_PRESAMPLED if presampled else 0) | self.dist_flag
+        flags = (FLAG_PRESAMPLED if presampled else 0) | self.dist_flag | (FLAG_FEATURE_DARBOUX if darboux else 0)
         if self.h:
             lib().oracle_free(self.h)
         self.h = lib().oracle_train(p, pc.shape[0], pc.shape[1], self.rel_sampling, self.rel_distance,
@@ -308,6 +312,17 @@ def pair_feature(p1, n1, p2, n2, angle_step, dist_step, mode=MODE_DET):
     h = lib().oracle_pair_feature(a[0][1], a[1][1], a[2][1], a[3][1], angle_step, dist_step, mode, _f64p(f),
                                   key.ctypes.data_as(C.POINTER(C.c_int32)))
     return f, key, int(h)
+
+
+def pair_feature_darboux(p1, n1, p2, n2, angle_step, dist_step, mode=MODE_DET):
+    """(f, key, hash) of PCL's pair feature, or None for a degenerate pair."""
+    a = [_f32(v) for v in (p1, n1, p2, n2)]
+    f = np.zeros(4, dtype=np.float64)
+    key = np.zeros(4, dtype=np.int32)
+    h = C.c_uint32()
+    ok = lib().oracle_pair_feature_darboux(a[0][1], a[1][1], a[2][1], a[3][1], angle_step, dist_step, mode, _f64p(f),
+                                           key.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h))
+    return (f, key, int(h.value)) if ok else None
 
 
 def transform_rt(p, n, mode=MODE_DET):

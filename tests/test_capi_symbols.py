@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"libppf_hip.so lacks {n}"
     assert sorted(_capi._SIGNATURES) == names, "python binding table and header disagree"
-    assert lib().ppf_abi_version() == 2
+    assert lib().ppf_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(tmp_path):
@@ -98,7 +98,7 @@ def _write_model_file(path, n_ref=2, junk=b""):
     info.n_entries, info.n_tiles, info.tile_refs = n_ref * (n_ref - 1), 1, n_ref
     info.angle_step, info.distance_step, info.diameter = 2 * np.pi / 30, 0.01, 0.2
     with open(path, "wb") as f:
-        f.write(b"PPFHIP02" + bytes(tp) + bytes(info) + struct.pack("<Q", 1) + junk)
+        f.write(b"PPFHIP03" + bytes(tp) + bytes(info) + struct.pack("<Q", 1) + junk)
 
 
 def test_model_file_validation_is_host_side_and_loud(tmp_path):

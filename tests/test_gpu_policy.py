@@ -1,5 +1,5 @@
 """PCL-semantics policy switches (closing paragraph): exact key equality, pair radius, relative
-rotation metric, 2 pi alpha range.  Each is checked against the oracle run with the same switch; all off is the reference's (OpenCV)
+rotation metric, 2 pi alpha range, Darboux-frame pair feature.  Each is checked against the oracle run with the same switch; all off is the reference's (OpenCV)
 behaviour every other test covers.  "parity unpinned": PCL's ppf_registration is not in the container either."""
 import numpy as np
 import pytest
@@ -82,6 +82,56 @@ def test_alpha_range_2pi(bottle, crop):
         plain = PPF3DDetector(0.05, 0.05, num_angles).trainModel(bottle).raw_votes(crop, STEP, 0.05, presampled=True)
         assert plain["stats"]["n_votes"] == got["stats"]["n_votes"]           # the same pairs vote ...
         assert not np.array_equal(plain["triples"], got["triples"])           # ... into other bins
+
+
+def test_darboux_feature(bottle, crop):
+    """pcl::computePairFeatures' four values with floor() keys (signed): other table, other hits, same exactness -- with the
+    bucket-walking table and with exact keys, and through a file round trip (the feature is a property of the model)."""
+    plain = PPF3DDetector(0.05, 0.05).trainModel(bottle).raw_votes(crop, STEP, 0.05, presampled=True)
+    for exact in (False, True):
+        det = PPF3DDetector(0.05, 0.05, key_equality=int(exact), feature=1).trainModel(bottle)
+        ora = O.OracleDetector(0.05, 0.05).train_model(bottle, darboux=True).set_policy(key_exact=exact)
+        got, _ = _compare(det, ora, crop)
+        assert got["stats"]["n_pairs"] == plain["stats"]["n_pairs"]      # no degenerate pairs in this cloud
+        assert not np.array_equal(plain["triples"], got["triples"])
+
+
+def test_darboux_model_survives_a_file_round_trip(bottle, crop, tmp_path):
+    det = PPF3DDetector(0.05, 0.05, feature=1).trainModel(bottle)
+    f = str(tmp_path / "darboux.ppf")
+    det.write(f)
+    back = PPF3DDetector(0.05, 0.05).read(f)
+    np.testing.assert_array_equal(back.raw_votes(crop, STEP, 0.05, presampled=True)["triples"],
+                                  det.raw_votes(crop, STEP, 0.05, presampled=True)["triples"])
+
+
+def test_darboux_leaves_degenerate_pairs_out(bottle):
+    """d parallel to the source normal (d x u = 0) and coincident points give no feature: PCL leaves such pairs out of the
+    table and the vote, and so do engine and oracle (pairs counted = pairs hashed)."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-0.1, 0.1, size=(400, 3)).astype(np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (400, 1))
+    pts[100:200, :2] = pts[0, :2]          # a column of points straight above point 0, all normals along the column
+    pts[399] = pts[398]                    # and one duplicate
+    cloud = np.hstack([pts, nrm])
+    det = PPF3DDetector(0.05, 0.05, feature=1).trainModel(cloud, presampled=True)
+    ora = O.OracleDetector(0.05, 0.05).train_model(cloud, presampled=True, darboux=True)
+    got = det.raw_votes(cloud, 1.0, 0.05, presampled=True)
+    want = ora.match(cloud, relative_scene_sample_step=1.0, presampled=True)
+    np.testing.assert_array_equal(got["triples"], want["triples"])
+    assert got["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum()) < 400 * 399
+    assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+
+
+def test_all_five_together(bottle, crop):
+    det = PPF3DDetector(0.05, 0.05, key_equality=1, feature=1).trainModel(bottle)
+    radius = 0.5 * det.info()["diameter"]
+    det.setSearchParams(0.02, 0.35)
+    det.setPolicy(pair_radius=radius, rot_metric_relative=True, alpha_range_2pi=True)
+    ora = O.OracleDetector(0.05, 0.05).train_model(bottle, darboux=True).set_policy(key_exact=True, pair_radius=radius,
+                                                                                    rot_relative=True, alpha_2pi=True)
+    ora.set_search_params(0.02, 0.35)
+    _compare(det, ora, crop)
 
 
 def test_all_four_together(bottle, crop):

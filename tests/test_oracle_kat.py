@@ -59,6 +59,78 @@ def test_pair_feature_invariant_under_rigid_motion():
         np.testing.assert_allclose(f0, f1, atol=2e-5)  # float32 clouds: invariance up to input rounding
 
 
+# ---- PCL's pair feature (policy switch) -------------------------------------------------------------
+def _pcl_pair_features(p1, n1, p2, n2):
+    """pcl::computePairFeatures as published (features/src/pfh.cpp), restated in numpy fp64 for the known-answer check."""
+    p1, n1, p2, n2 = (np.asarray(v, np.float64) for v in (p1, n1, p2, n2))
+    dp = p2 - p1
+    f4 = np.linalg.norm(dp)
+    if f4 == 0:
+        return None
+    a1, a2 = n1 @ dp / f4, n2 @ dp / f4
+    if np.arccos(abs(a1)) > np.arccos(abs(a2)):
+        n1, n2, dp, f3 = n2, n1, -dp, -a2
+    else:
+        f3 = a1
+    v = np.cross(dp, n1)
+    if np.linalg.norm(v) == 0:
+        return None
+    v /= np.linalg.norm(v)
+    w = np.cross(n1, v)
+    return np.array([np.arctan2(w @ n2, n1 @ n2), v @ n2, f3, f4])
+
+
+def test_darboux_feature_definition():
+    step = np.deg2rad(12)
+    # source normal +z, target 0.5 away in the x-z plane, target normal +x: u = n1, v = d x u / |.| = -y, w = u x v = +x
+    f, key, h = O.pair_feature_darboux([0, 0, 0], [0, 0, 1], [0.3, 0, 0.4], [1, 0, 0], step, 0.05, mode=O.MODE_LIBM)
+    np.testing.assert_allclose(f, [np.pi / 2, 0.0, 0.8, 0.5], atol=1e-12)
+    assert list(key) == [7, 0, 3, 10]                      # floor(90/12), floor(0), floor(0.8/0.2094), floor(0.5/0.05)
+    h1, _ = O.murmur3_x64_128(key.astype("<i4").tobytes(), 42)
+    assert h == (h1 & 0xFFFFFFFF)
+    # the point whose normal is closer to the connecting line becomes the source: swapping the arguments gives the same feature
+    g, gkey, _ = O.pair_feature_darboux([0.3, 0, 0.4], [1, 0, 0], [0, 0, 0], [0, 0, 1], step, 0.05, mode=O.MODE_LIBM)
+    np.testing.assert_allclose(g, f, atol=1e-12)
+    # negative values floor downwards (PCL's std::floor), they do not truncate towards zero
+    f, key, _ = O.pair_feature_darboux([0, 0, 0], [0, 0, 1], [0.3, 0, 0.4], [-0.6, 0.8, 0], step, 0.05, mode=O.MODE_LIBM)
+    assert f[0] < 0 and f[1] < 0 and key[0] == np.floor(f[0] / step) and key[1] == np.floor(f[1] / step) == -4
+
+
+def test_darboux_feature_against_the_published_formula_and_rigid_motion():
+    rng = np.random.default_rng(14)
+    for s in range(200):
+        p = rng.uniform(-0.2, 0.2, size=(2, 3)).astype(np.float32)
+        n = _rand_unit(rng, 2)
+        want = _pcl_pair_features(p[0], n[0], p[1], n[1])
+        for mode in (O.MODE_LIBM, O.MODE_DET):
+            f, _, _ = O.pair_feature_darboux(p[0], n[0], p[1], n[1], 0.2094395, 0.01, mode=mode)
+            np.testing.assert_allclose(f, want, atol=1e-12)
+        c = np.concatenate([p, n], axis=1)
+        cm = synth.apply_pose(c, synth.rigid_pose(300 + s))
+        f1, _, _ = O.pair_feature_darboux(cm[0, :3], cm[0, 3:], cm[1, :3], cm[1, 3:], 0.2094395, 0.01)
+        d = np.abs(f1 - want)
+        d[0] = min(d[0], 2 * np.pi - d[0])   # atan2 branch cut
+        assert d.max() < 5e-5                # float32 clouds: invariance up to input rounding
+
+
+def test_darboux_degenerate_pairs_have_no_feature():
+    assert O.pair_feature_darboux([0.1, 0.2, 0.3], [1, 0, 0], [0.1, 0.2, 0.3], [0, 1, 0], 0.2, 0.01) is None   # same point
+    assert O.pair_feature_darboux([0, 0, 0], [0, 0, 1], [0, 0, 0.5], [0, 0, 1], 0.2, 0.01) is None             # d parallel to u
+    assert _pcl_pair_features([0, 0, 0], [0, 0, 1], [0, 0, 0.5], [0, 0, 1]) is None
+
+
+def test_darboux_self_match_recovers_the_pose():
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-0.1, 0.1, size=(220, 3)) * np.array([1.0, 0.6, 0.3])
+    cloud = np.concatenate([pts, _rand_unit(rng, 220)], axis=1).astype(np.float32)
+    T = synth.rigid_pose(77)
+    scene = synth.apply_pose(cloud, T)
+    ora = O.OracleDetector(0.05, 0.05).train_model(cloud, presampled=True, darboux=True).set_policy(key_exact=True)
+    res = ora.match(scene, relative_scene_sample_step=0.2, presampled=True)
+    np.testing.assert_allclose(res["poses"][0]["pose"], T, atol=0.12)
+    assert res["poses"][0]["num_votes"] > 0
+
+
 def test_degenerate_pair_keeps_zero_feature():
     f, key, _ = O.pair_feature([0.1, 0.2, 0.3], [1, 0, 0], [0.1, 0.2, 0.3], [0, 1, 0], 0.2094395, 0.01)
     assert list(f) == [0, 0, 0, 0] and list(key) == [0, 0, 0, 0]

@@ -28,7 +28,8 @@ class PPFError(RuntimeError):
 class TrainParams(C.Structure):
     _fields_ = [("relative_sampling_step", C.c_double), ("relative_distance_step", C.c_double),
                 ("num_angles", C.c_double), ("presampled", C.c_int32), ("distance_from_distance_step", C.c_int32),
-                ("max_tile_refs", C.c_int32), ("key_equality", C.c_int32)]
+                ("max_tile_refs", C.c_int32), ("key_equality", C.c_int32), ("feature", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class MatchParams(C.Structure):
@@ -192,7 +193,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.ppf_abi_version() != 2:
+        if L.ppf_abi_version() != 3:
             raise ImportError("libppf_hip.so ABI version mismatch")
         _lib = L
     return _lib

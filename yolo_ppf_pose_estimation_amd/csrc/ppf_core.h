@@ -77,6 +77,50 @@ PPF_HD uint32_t ppf_hash_feature(const double* f, double angle_step, double dist
                           ppf_d2i(f[3] / dist_step));
 }
 
+/* ---- PCL's pair feature (policy switch feature = PPF_FEATURE_DARBOUX; pcl::computePairFeatures as PPFEstimation
+ * uses it): with d = p2 - p1, a1 = n1.d/|d|, a2 = n2.d/|d|, the point whose normal is closer to the line takes the
+ * role of the source (u = its normal; PCL tests acos|a1| > acos|a2|, i.e. |a1| < |a2|), v = d x u / |d x u|, w = u x v:
+ *   f[0] = atan2(w.n, u.n)   f[1] = v.n   f[2] = a1 or -a2   f[3] = |d|      (n = the other point's normal)
+ * Returns 0 for degenerate pairs (|d| = 0 or d parallel to u), which PCL leaves out.  Keys are floor(f / step) --
+ * PCL divides the two cosines by the ANGLE step as well. */
+PPF_HD int ppf_pair_feature_darboux(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2, const ppf_vec3& n2, double* f) {
+  ppf_vec3 d = ppf_mk3(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z);
+  const double f4 = ppf_sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+  if (!(f4 > 0.0)) return 0;
+  const double a1 = ppf_dot3(n1, d) / f4, a2 = ppf_dot3(n2, d) / f4;
+  ppf_vec3 u = n1, n = n2;
+  double f3 = a1;
+  if (ppf_fabs(a1) < ppf_fabs(a2)) {
+    u = n2; n = n1;
+    d = ppf_mk3(-d.x, -d.y, -d.z);
+    f3 = -a2;
+  }
+  ppf_vec3 v = ppf_mk3(d.y * u.z - d.z * u.y, d.z * u.x - d.x * u.z, d.x * u.y - d.y * u.x);
+  const double vn = ppf_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+  if (!(vn > 0.0)) return 0;
+  v = ppf_mk3(v.x / vn, v.y / vn, v.z / vn);
+  const ppf_vec3 w = ppf_mk3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+  f[0] = ppf_atan2(ppf_dot3(w, n), ppf_dot3(u, n));
+  f[1] = ppf_dot3(v, n);
+  f[2] = f3;
+  f[3] = f4;
+  return 1;
+}
+PPF_HD int32_t ppf_floor_key(double x) { return ppf_d2i(__builtin_floor(x)); }
+
+/* the key table's shape: keys (k0 + o0, k1 + o1, k2 + o2, k3) inside n0 x n1 x n2 x nd are tabulated.  Offsets are zero
+ * for the reference's feature (three acos bins, never negative); PCL's feature has signed keys. */
+struct KeyDims {
+  int n0, n1, n2, nd, o0, o1, o2;
+};
+PPF_HD bool key_index(const KeyDims& d, const int32_t k0, const int32_t k1, const int32_t k2, const int32_t k3, size_t* idx) {
+  const uint32_t a = (uint32_t)(k0 + d.o0), b = (uint32_t)(k1 + d.o1), c = (uint32_t)(k2 + d.o2);
+  if (!((a < (uint32_t)d.n0) & (b < (uint32_t)d.n1) & (c < (uint32_t)d.n2) & ((uint32_t)k3 < (uint32_t)d.nd))) return false;
+  *idx = ((size_t)(a * (uint32_t)d.n1 + b) * (uint32_t)d.n2 + c) * (uint32_t)d.nd + (uint32_t)k3;
+  return true;
+}
+PPF_HD size_t key_table_size(const KeyDims& d) { return (size_t)d.n0 * d.n1 * d.n2 * d.nd; }
+
 /* ---- reference frame (row A4): R rotates n onto +x (Rodrigues about (0, n.z, -n.y)), t = -R p */
 PPF_HD void ppf_transform_rt(const ppf_vec3& p, const ppf_vec3& n, double* R, double* t) {
   double angle = ppf_acos(n.x);

@@ -216,7 +216,7 @@ __device__ __forceinline__ ppf_vec3 ld3(const float* a, const float* b, const fl
 
 /* ---- training: one workgroup per model reference point i, threads sweep j (row A5-train) ---- */
 __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_step, double dist_step,
-                                                     uint32_t slot_mask, int key_exact, int lut_na, int lut_nd,
+                                                     uint32_t slot_mask, int key_exact, int darboux, KeyDims kd,
                                                      uint32_t* __restrict__ pair_slot, float* __restrict__ pair_alpha,
                                                      unsigned long long* __restrict__ slot_bits) {
   __shared__ double frame[12];
@@ -236,17 +236,23 @@ __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_st
     }
     const ppf_vec3 p2 = ld3(m.x, m.y, m.z, j), n2 = ld3(m.nx, m.ny, m.nz, j);
     double f[4] = {0, 0, 0, 0};
-    ppf_pair_feature(p1, n1, p2, n2, f);
+    int32_t k0, k1, k2, k3;
+    if (darboux) { /* PPF_FEATURE_DARBOUX: PCL's feature, floor() keys; degenerate pairs are left out of the table */
+      if (!ppf_pair_feature_darboux(p1, n1, p2, n2, f)) { pair_slot[idx] = 0xFFFFFFFFu; pair_alpha[idx] = 0.f; continue; }
+      k0 = ppf_floor_key(f[0] / angle_step); k1 = ppf_floor_key(f[1] / angle_step); k2 = ppf_floor_key(f[2] / angle_step);
+      k3 = ppf_floor_key(f[3] / dist_step);
+    } else {
+      ppf_pair_feature(p1, n1, p2, n2, f);
+      k0 = ppf_d2i(f[0] / angle_step); k1 = ppf_d2i(f[1] / angle_step); k2 = ppf_d2i(f[2] / angle_step);
+      k3 = ppf_d2i(f[3] / dist_step);
+    }
     uint32_t slot;
     if (key_exact) { /* PPF_KEY_EXACT: the "slot" is the quantised key itself (its index in the key table) */
-      const int32_t k0 = ppf_d2i(f[0] / angle_step), k1 = ppf_d2i(f[1] / angle_step), k2 = ppf_d2i(f[2] / angle_step),
-                    k3 = ppf_d2i(f[3] / dist_step);
-      const bool in = ((uint32_t)k0 < (uint32_t)lut_na) & ((uint32_t)k1 < (uint32_t)lut_na) & ((uint32_t)k2 < (uint32_t)lut_na) &
-                      ((uint32_t)k3 < (uint32_t)lut_nd);
-      if (!in) { pair_slot[idx] = 0xFFFFFFFFu; pair_alpha[idx] = 0.f; continue; } /* cannot happen: ppf_model_train checks the range */
-      slot = (uint32_t)(((k0 * lut_na + k1) * lut_na + k2) * lut_nd + k3);
+      size_t ki;
+      if (!key_index(kd, k0, k1, k2, k3, &ki)) { pair_slot[idx] = 0xFFFFFFFFu; pair_alpha[idx] = 0.f; continue; } /* cannot happen: ppf_model_train checks the range */
+      slot = (uint32_t)ki;
     } else {
-      slot = ppf_hash_feature(f, angle_step, dist_step) & slot_mask; /* hash % slots, slots a power of two */
+      slot = ppf_murmur_key16(k0, k1, k2, k3) & slot_mask; /* hash % slots, slots a power of two */
     }
     pair_slot[idx] = slot;
     pair_alpha[idx] = (float)ppf_model_alpha(R, t, p2);
@@ -288,17 +294,16 @@ __device__ __forceinline__ int slot_to_bucket(const SlotWord* __restrict__ slotm
   return (int)(w.rank + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)));
 }
 
-/* key_lut[((k0*na + k1)*na + k2)*nd + k3] = dense bucket of hash(k0..k3) % slots, or -1 */
-__global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int key_exact, int na, int nd,
+/* key_lut[key_index(k0..k3)] = dense bucket of hash(k0..k3) % slots, or -1 */
+__global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restrict__ slotmap, uint32_t slot_mask, int key_exact, KeyDims kd,
                                                        int32_t* __restrict__ lut) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)na * na * na * nd;
-  if (idx >= total) return;
-  const int k3 = (int)(idx % nd);
-  size_t t = idx / nd;
-  const int k2 = (int)(t % na); t /= na;
-  const int k1 = (int)(t % na);
-  const int k0 = (int)(t / na);
+  if (idx >= key_table_size(kd)) return;
+  const int k3 = (int)(idx % kd.nd);
+  size_t t = idx / kd.nd;
+  const int k2 = (int)(t % kd.n2) - kd.o2; t /= kd.n2;
+  const int k1 = (int)(t % kd.n1) - kd.o1;
+  const int k0 = (int)(t / kd.n1) - kd.o0;
   lut[idx] = slot_to_bucket(slotmap, key_exact ? (uint32_t)idx : (ppf_murmur_key16(k0, k1, k2, k3) & slot_mask));
 }
 
@@ -1176,7 +1181,7 @@ struct ppf_model {
   DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
   DevBuf<uint4> records;          /* pair records, see place_entry */
   DevBuf<int32_t> key_lut;        /* quantised key -> bucket, see k_build_key_lut */
-  int lut_na = 0, lut_nd = 0;
+  KeyDims kd{};
   uint64_t n_records = 0;
   int device = 0;
 };
@@ -1356,27 +1361,35 @@ static int max_tile_rows(int num_angles) {
 }
 
 /* tabulate hash -> bucket for every key with angle bins 0..floor(pi/angle_step)+1 and distance bins 0..1023 (pairs up
- * to ~1000 distance steps apart: tens of model diameters); everything else keeps the hash path in k_pairs */
+ * to ~1000 distance steps apart: tens of model diameters); everything else keeps the hash path in k_pairs.
+ * PPF_FEATURE_DARBOUX: the angle key spans -pi..pi and the two cosine keys -1..1, all divided by the angle step and floored. */
 static void key_lut_dims(ppf_model* m) {
-  m->lut_na = (int)std::floor(PPF_PI / m->info.angle_step) + 2;
-  m->lut_nd = 1024;
-  const size_t total = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
-  if (total > ((size_t)1 << 26)) { /* very fine angle steps: shrink the distance range to keep the table at 256 MiB */
-    m->lut_nd = (int)std::max<size_t>(1, ((size_t)1 << 26) / ((size_t)m->lut_na * m->lut_na * m->lut_na));
+  KeyDims& d = m->kd;
+  if (m->params.feature == PPF_FEATURE_DARBOUX) {
+    d.o0 = (int)std::floor(PPF_PI / m->info.angle_step) + 2;
+    d.o1 = d.o2 = (int)std::floor(1.0 / m->info.angle_step) + 2;
+    d.n0 = 2 * d.o0 + 1;
+    d.n1 = d.n2 = 2 * d.o1 + 1;
+  } else {
+    d.o0 = d.o1 = d.o2 = 0;
+    d.n0 = d.n1 = d.n2 = (int)std::floor(PPF_PI / m->info.angle_step) + 2;
   }
+  d.nd = 1024;
+  const size_t per_dist = (size_t)d.n0 * d.n1 * d.n2;
+  if (per_dist * d.nd > ((size_t)1 << 26)) /* very fine angle steps: shrink the distance range to keep the table at 256 MiB */
+    d.nd = (int)std::max<size_t>(1, ((size_t)1 << 26) / per_dist);
 }
 /* hash slots of the table: next_pow2(N^2) like the reference's library, or (PPF_KEY_EXACT) one slot per quantised key */
 static uint32_t table_slots(const ppf_model* m) {
-  if (m->params.key_equality == PPF_KEY_EXACT)
-    return next_pow2(std::max<uint32_t>((uint32_t)((size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd), 16u));
+  if (m->params.key_equality == PPF_KEY_EXACT) return next_pow2(std::max<uint32_t>((uint32_t)key_table_size(m->kd), 16u));
   return next_pow2(std::max<uint32_t>((uint32_t)((size_t)m->info.n_ref * m->info.n_ref), 16u));
 }
 static ppf_status build_key_lut(ppf_model* m, hipStream_t st) {
   key_lut_dims(m);
-  const size_t n = (size_t)m->lut_na * m->lut_na * m->lut_na * m->lut_nd;
+  const size_t n = key_table_size(m->kd);
   HIPCHK(m->key_lut.reserve(n));
   k_build_key_lut<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(m->slotmap.p, m->info.slots - 1, m->params.key_equality == PPF_KEY_EXACT,
-                                                                           m->lut_na, m->lut_nd, m->key_lut.p);
+                                                                           m->kd, m->key_lut.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   return PPF_OK;
@@ -1395,7 +1408,8 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(bits.reserve(words));
   HIPCHK(hipMemsetAsync(bits.p, 0, words * sizeof(unsigned long long), st));
   k_train_pairs<<<dim3(N), dim3(256), 0, st>>>(m->cloud.view(), m->info.angle_step, m->info.distance_step, slots - 1,
-                                               m->params.key_equality == PPF_KEY_EXACT, m->lut_na, m->lut_nd, pair_slot.p, pair_alpha.p, bits.p);
+                                               m->params.key_equality == PPF_KEY_EXACT, m->params.feature == PPF_FEATURE_DARBOUX, m->kd,
+                                               pair_slot.p, pair_alpha.p, bits.p);
   HIPCHK(hipGetLastError());
   HIPCHK(word_cnt.reserve(words + 1));
   HIPCHK(word_rank.reserve(words + 1));
@@ -1553,8 +1567,10 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   key_lut_dims(m);
   if (params->key_equality != PPF_KEY_BUCKET && params->key_equality != PPF_KEY_EXACT)
     return fail(PPF_ERR_INVALID, "ppf_model_train: key_equality must be PPF_KEY_BUCKET or PPF_KEY_EXACT");
-  if (params->key_equality == PPF_KEY_EXACT && (double)diameter / (double)dist_step + 2.0 > (double)m->lut_nd)
-    return fail(PPF_ERR_INVALID, "ppf_model_train: PPF_KEY_EXACT needs diameter / distance step (%g) below %d", (double)diameter / dist_step, m->lut_nd);
+  if (params->feature != PPF_FEATURE_PPF && params->feature != PPF_FEATURE_DARBOUX)
+    return fail(PPF_ERR_INVALID, "ppf_model_train: feature must be PPF_FEATURE_PPF or PPF_FEATURE_DARBOUX");
+  if (params->key_equality == PPF_KEY_EXACT && (double)diameter / (double)dist_step + 2.0 > (double)m->kd.nd)
+    return fail(PPF_ERR_INVALID, "ppf_model_train: PPF_KEY_EXACT needs diameter / distance step (%g) below %d", (double)diameter / dist_step, m->kd.nd);
   m->info.slots = table_slots(m);
   m->info.position_threshold_default = params->relative_sampling_step;
   m->info.rotation_threshold_default = ((360 / angle_step) / 180.0 * PPF_PI);
@@ -1804,7 +1820,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.same_cloud = d_edge ? 0 : 1;
   va.scene_step = scene_step; va.ref_offset = params->ref_offset; va.ref_stride = params->ref_stride;
   va.slotmap = m->slotmap.p; va.slot_mask = m->info.slots - 1;
-  va.key_lut = m->key_lut.p; va.lut_na = m->lut_na; va.lut_nd = m->lut_nd;
+  va.key_lut = m->key_lut.p; va.kd = m->kd;
   va.bucket_off = m->bucket_off.p; va.n_buckets = (int)m->info.n_buckets;
   va.records = m->records.p;
   va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
@@ -1816,6 +1832,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.acc_dump = ws->acc_dump;
   va.bucket_total = m->bucket_total.p;
   va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
+  const bool darboux = m->params.feature == PPF_FEATURE_DARBOUX;
   va.pair_radius = params->pair_radius;
   va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || params->alpha_range_2pi || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
   const int n_paired = va.paired.n;
@@ -1836,7 +1853,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     for (int base = 0; base < n_ref; base += 32768) {
       va.ref_base = base;
       va.n_ref = std::min(32768, n_ref - base);
-      k_pairs<<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+      if (darboux) k_pairs<true><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+      else k_pairs<false><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
       HIPCHK(hipGetLastError());
     }
     va.count_only = 0;
@@ -1927,7 +1945,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 0], st));
-    k_pairs<<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+    if (darboux) k_pairs<true><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+    else k_pairs<false><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 1], st));
     k_ref_hits<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va);
@@ -2503,7 +2522,7 @@ ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sst
 
 /* ---- model (de)serialisation: versioned binary CSR (the reference's XML format is defined by a
  * private OpenCV patch and unknown) ------------------------------------------------- */
-static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '2'}; /* 02: pair-record table */
+static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '3'}; /* 02: pair-record table; 03: ppf_train_params.feature */
 
 ppf_status ppf_model_save(const ppf_model* m, const char* path) {
   if (!m || !path) return fail(PPF_ERR_INVALID, "ppf_model_save: NULL");
@@ -2554,6 +2573,7 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
   if (I.n_ref < 2 || N * N > 0x7FFFFFFFull) return bad("n_ref");
   if (!(I.num_angles >= 1 && I.num_angles <= 4096) || !(I.angle_step > 1e-4) || !(I.distance_step > 0) || !std::isfinite(I.diameter)) return bad("steps");
   if (m->params.key_equality != PPF_KEY_BUCKET && m->params.key_equality != PPF_KEY_EXACT) return bad("key_equality");
+  if (m->params.feature != PPF_FEATURE_PPF && m->params.feature != PPF_FEATURE_DARBOUX) return bad("feature");
   key_lut_dims(m);
   if (I.slots != table_slots(m)) return bad("slots");
   if (I.num_angles != (int)std::floor(2 * PPF_PI / I.angle_step)) return bad("num_angles");

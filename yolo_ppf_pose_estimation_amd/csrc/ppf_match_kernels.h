@@ -162,6 +162,17 @@ __device__ __forceinline__ void pair_key(const ppf_vec3& p1, const ppf_vec3& n1,
   }
 }
 
+/* PCL's pair feature (policy switch): the exact fp64 chain for every pair -- no fp32 estimate, this is not the path the
+ * headline metric runs.  false: degenerate pair, left out like PCL does. */
+__device__ __forceinline__ bool pair_key_darboux(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2, const ppf_vec3& n2,
+                                                 const double angle_step, const double dist_step, int32_t (&k)[4]) {
+  double f[4];
+  if (!ppf_pair_feature_darboux(p1, n1, p2, n2, f)) return false;
+  k[0] = ppf_floor_key(f[0] / angle_step); k[1] = ppf_floor_key(f[1] / angle_step); k[2] = ppf_floor_key(f[2] / angle_step);
+  k[3] = ppf_floor_key(f[3] / dist_step);
+  return true;
+}
+
 struct MatchArgs {
   CloudSoA surf;   /* reference points come from here */
   CloudSoA paired; /* second points of the pairs (== surf for match, the edge cloud for match_S2B) */
@@ -171,10 +182,10 @@ struct MatchArgs {
   /* model table */
   const SlotWord* slotmap;
   uint32_t slot_mask;
-  /* key -> dense bucket id (-1: empty slot), indexed ((k0*lut_na + k1)*lut_na + k2)*lut_nd + k3: the hash of every
-   * quantised key a scene can produce, tabulated once per model; keys outside the table take the hash path */
+  /* key -> dense bucket id (-1: empty slot), indexed by key_index(): the hash of every quantised key a scene can
+   * produce, tabulated once per model; keys outside the table take the hash path */
   const int32_t* key_lut;
-  int lut_na, lut_nd;
+  KeyDims kd;
   const uint32_t* bucket_off;
   int n_buckets;
   const uint4* records;    /* pair records {row_a, row_b, alpha_a, alpha_b}; bucket_off counts records */
@@ -238,6 +249,7 @@ __device__ __forceinline__ uint32_t pool_stripe(const uint32_t wg, const int str
 }
 
 /* grid: x = chunks of PAIR_BLOCK*PAIRS_PER_THREAD paired points, y = reference point of the batch */
+template <bool DARBOUX>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   __shared__ uint2 stash[PAIRS_PER_THREAD][PAIR_BLOCK]; /* {bucket, j} of this thread's hits, one slot per iteration */
   __shared__ uint32_t wtot[PAIR_BLOCK / 64];
@@ -283,22 +295,26 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
       }
       if (!skip) {
         int32_t key[4];
-        pair_key(p1, n1, p2, n2, a.angle_step, a.dist_step, fk, key);
-        int b;
-        if (((uint32_t)key[0] < (uint32_t)a.lut_na) & ((uint32_t)key[1] < (uint32_t)a.lut_na) & ((uint32_t)key[2] < (uint32_t)a.lut_na) &
-            ((uint32_t)key[3] < (uint32_t)a.lut_nd)) {
-          b = a.key_lut[(size_t)((key[0] * a.lut_na + key[1]) * a.lut_na + key[2]) * a.lut_nd + key[3]];
-        } else if (a.key_exact) { /* no model pair has a key outside the table */
-          b = -1;
-        } else { /* NaN features (INT_MIN bins) or pairs farther apart than the table covers */
-          b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
-        }
-        /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
-         * computed later (k_group), only for the pairs that found a bucket. */
-        my_pairs += 1u;
-        if (b >= 0) {
-          stash[it][tid] = make_uint2((uint32_t)b, (uint32_t)j);
-          hit_mask |= 1u << it;
+        bool valid = true;
+        if (DARBOUX) valid = pair_key_darboux(p1, n1, p2, n2, a.angle_step, a.dist_step, key);
+        else pair_key(p1, n1, p2, n2, a.angle_step, a.dist_step, fk, key);
+        if (valid) {
+          int b;
+          size_t ki;
+          if (key_index(a.kd, key[0], key[1], key[2], key[3], &ki)) {
+            b = a.key_lut[ki];
+          } else if (a.key_exact) { /* no model pair has a key outside the table */
+            b = -1;
+          } else { /* NaN features (INT_MIN bins) or pairs farther apart than the table covers */
+            b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
+          }
+          /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
+           * computed later (k_group), only for the pairs that found a bucket. */
+          my_pairs += 1u;
+          if (b >= 0) {
+            stash[it][tid] = make_uint2((uint32_t)b, (uint32_t)j);
+            hit_mask |= 1u << it;
+          }
         }
       }
     }

@@ -86,13 +86,15 @@ class _ModelHandle:
 
 class PPF3DDetector:
     def __init__(self, relativeSamplingStep: float = 0.05, relativeDistanceStep: float = 0.05, numAngles: float = 30,
-                 *, distance_from_distance_step: bool = False, max_tile_refs: int = 0, key_equality: int = 0):
+                 *, distance_from_distance_step: bool = False, max_tile_refs: int = 0, key_equality: int = 0,
+                 feature: int = 0):
         self.sampling_step_relative = float(relativeSamplingStep)
         self.distance_step_relative = float(relativeDistanceStep)
         self.angle_step_relative = float(numAngles)
         self._dist_flag = bool(distance_from_distance_step)
         self._max_tile_refs = int(max_tile_refs)
         self._key_equality = int(key_equality)  # 0: whole hash bucket votes (OpenCV); 1: exact quantised key (PCL)
+        self._feature = int(feature)            # 0: three acos angles (OpenCV); 1: Darboux-frame feature, floor keys (PCL)
         self._pair_radius = 0.0                 # > 0: scene pairs within this distance only (PCL)
         self._rot_metric_relative = False       # cluster on the relative rotation angle (PCL)
         self._alpha_range_2pi = False           # alpha differences wrapped into [-pi, pi], binned over 2 pi (PCL)
@@ -106,7 +108,7 @@ class PPF3DDetector:
     def __copy__(self):
         d = PPF3DDetector(self.sampling_step_relative, self.distance_step_relative, self.angle_step_relative,
                           distance_from_distance_step=self._dist_flag, max_tile_refs=self._max_tile_refs,
-                          key_equality=self._key_equality)
+                          key_equality=self._key_equality, feature=self._feature)
         d._pair_radius, d._rot_metric_relative = self._pair_radius, self._rot_metric_relative
         d._alpha_range_2pi = self._alpha_range_2pi
         d._position_threshold, d._rotation_threshold = self._position_threshold, self._rotation_threshold
@@ -144,6 +146,7 @@ class PPF3DDetector:
         tp.distance_from_distance_step = int(self._dist_flag)
         tp.max_tile_refs = self._max_tile_refs
         tp.key_equality = self._key_equality
+        tp.feature = self._feature
         out = C.c_void_p()
         check(lib().ppf_model_train(pc.ctypes.data, pc.shape[0], pc.shape[1], C.byref(tp), C.byref(out)))
         self._model = _ModelHandle(out.value)
