@@ -254,6 +254,8 @@ ppf_status ppf_workspace_destroy(ppf_workspace* ws);
 #define PPF_OPT_HIT_FRACTION 1
 #define PPF_OPT_GROUP_ROUND_BUCKETS 2
 #define PPF_OPT_CLUSTER_SERIAL 3 /* != 0: the serial greedy cluster assignment (the path for > 11,520 poses) for any size */
+#define PPF_OPT_ACC32 4          /* != 0: 32-bit accumulator cells from the start (otherwise only after a 16-bit cell overflowed, which
+                                   the vote kernel detects and the call answers by repeating itself once) */
 ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);
 /* record HIP events around the kernels of each call (read back through ppf_workspace_results' stats) */
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);

@@ -56,7 +56,7 @@ def test_c1_gpu_parity(bottle, c1, oracle_c1):
     _, r_match, r_s2b = oracle_c1
     crop, edge = c1
     det = PPF3DDetector(0.025, 0.05).trainModel(bottle)
-    assert det.info()["n_ref"] == 3870 and det.info()["n_tiles"] == 4
+    assert det.info()["n_ref"] == 3870 and det.info()["n_tiles"] == 2
     a = det.raw_votes(crop, 0.0714, 0.05)
     np.testing.assert_array_equal(a["triples"], r_match["triples"])
     assert a["stats"]["n_votes"] == int(r_match["votes_per_ref"].sum())

@@ -81,13 +81,18 @@ def test_votes_single_tile_presampled(bottle):
     assert got["n_ref"] == 200 and got["stats"]["n_votes"] > 0
 
 
-def test_votes_two_tiles(bottle):
-    """N_m = 2000 (step 0.036): two accumulator tiles, including the alpha-bin spill across them."""
+def test_votes_one_full_tile_and_two_tiles(bottle):
+    """N_m = 2000 (step 0.036): one accumulator tile of 16-bit cells with both halves of its words in use (rows 0..999 low,
+    1000..1999 high, the alpha-bin spill from row 999 to row 1000 crosses the halves); the same model cut into two tiles
+    (spill mirrored across the tile boundary) gives the same votes."""
     det = PPF3DDetector(0.036, 0.05).trainModel(bottle)
     ora = O.OracleDetector(0.036, 0.05).train_model(bottle)
-    assert det.info()["n_ref"] == 2000 and det.info()["n_tiles"] == 2
+    assert det.info()["n_ref"] == 2000 and det.info()["n_tiles"] == 1 and det.info()["tile_refs"] == 2000
     scene, _ = synth.make_scene(bottle, n_points=6000, seed=22)
     _check_against_oracle(det, ora, scene, 1.0 / 100.0, 0.05, True)
+    two = PPF3DDetector(0.036, 0.05, max_tile_refs=1000).trainModel(bottle)
+    assert two.info()["n_tiles"] == 2
+    _check_against_oracle(two, ora, scene, 1.0 / 100.0, 0.05, True)
 
 
 def test_votes_many_small_tiles(bottle):

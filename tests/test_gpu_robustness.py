@@ -84,6 +84,47 @@ def test_an_all_hit_scene_needs_the_worst_case_pool(det):
     assert got["stats"]["n_hits"] > 0
 
 
+def test_32_bit_cells_equal_the_oracle(det, crop, oracle_crop, bottle):
+    """PPF_OPT_ACC32: the repeat path of an accumulator overflow (32-bit cells, each tile in two passes, one per half of
+    its rows), forced: same triples and vote totals, with one tile and with several, with count tables and without."""
+    for d in (det, PPF3DDetector(0.05, 0.05, max_tile_refs=150).trainModel(bottle)):
+        for mode in (0, 1):
+            ws = Workspace()
+            ws.set_option(_capi.PPF_OPT_ACC32, 1)
+            res = _device_run(d, crop, ws, skip_clustering=True, vote_mode=mode)
+            np.testing.assert_array_equal(res["triples"], oracle_crop["triples"])
+            assert res["stats"]["n_votes"] == int(oracle_crop["votes_per_ref"].sum()) and res["stats"]["n_retries"] == 0
+
+
+def test_a_cell_beyond_65535_votes_repeats_the_call_with_32_bit_cells():
+    """16-bit accumulator cells: 1,000 scene points in one spot seen from the reference point, 200 model points in the same
+    spot seen from a model point -> about 200,000 votes for one (model point, alpha bin).  The vote kernel notices that the
+    votes it finds differ from the votes it cast, the call repeats itself once with 32-bit cells, the result is the
+    oracle's; the workspace then stays with 32-bit cells for this model."""
+    import torch
+    rng = np.random.default_rng(3)
+
+    def spot(n_far):
+        far = np.array([0.1, 0.02, 0.0]) + rng.uniform(-5e-4, 5e-4, size=(n_far, 3)) * np.array([1, 1, 0])
+        pts = np.vstack([np.zeros((1, 3)), far, rng.uniform(-0.1, 0.1, size=(40, 3)) * np.array([1, 1, 0])])
+        return np.hstack([pts, np.tile([0.0, 0.0, 1.0], (pts.shape[0], 1))]).astype(np.float32)
+
+    model, scene = spot(200), spot(1000)
+    det = PPF3DDetector(0.05, 0.05).trainModel(model, presampled=True)
+    ora = O.OracleDetector(0.05, 0.05).train_model(model, presampled=True)
+    step = 1.0 / scene.shape[0]          # one reference point: row 0
+    want = ora.match(scene, relative_scene_sample_step=step, presampled=True, cluster=False)
+    assert want["triples"][0][2] > 65535
+    ws = Workspace()
+    d = torch.from_numpy(scene).cuda()
+    for expected_repeats in (1, 0):
+        ws.match_device(det, d.data_ptr(), scene.shape[0], 6, step, 0.05, presampled=True, skip_clustering=True)
+        res = ws.results(scene.shape[0])
+        np.testing.assert_array_equal(res["triples"], want["triples"])
+        assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+        assert res["stats"]["n_retries"] == expected_repeats
+
+
 def test_several_group_rounds_give_the_same_votes(det, crop, oracle_crop):
     ws = Workspace()
     ws.set_option(_capi.PPF_OPT_GROUP_ROUND_BUCKETS, 1000)  # a few thousand buckets -> several passes per reference point
@@ -169,7 +210,7 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
 
 def test_fine_alpha_resolution_votes_directly(bottle):
     """numAngles > 31: no count tables (their Y range needs numAngles <= 31), every vote its own atomic, several tiles."""
-    det = PPF3DDetector(0.1, 0.05, 180).trainModel(bottle)
+    det = PPF3DDetector(0.1, 0.05, 180, max_tile_refs=100).trainModel(bottle)
     assert det.info()["num_angles"] == 180 and det.info()["n_tiles"] >= 2
     scene = synth.make_scene(bottle, n_points=3000, seed=8)[0]
     got = det.raw_votes(scene, 1.0 / 10.0, 0.05, presampled=True)

@@ -192,6 +192,14 @@ constexpr float SPILL_ALPHA_MIN = 3.1415f;         /* entries with alpha_m >= th
 /* LDS accumulator geometry (see ppf_match_kernels.h): row pitch in words and guard words below cell 0 */
 __host__ __device__ constexpr int vote_pitch(int A) { return (A + 1) | 1; }
 __host__ __device__ constexpr int vote_guard(int A) { return 64 + 2 * vote_pitch(A); }
+/* A tile of R model rows keeps 16-bit cells, two rows per 32-bit word: row r < H = ceil(R/2) in the low halves, row r + H
+ * in the high halves.  A pair record names a row by the byte offset of its bin 0 with the half in bit 0. */
+__host__ __device__ constexpr int vote_half_rows(int tile_refs) { return (tile_refs + 1) / 2; }
+__host__ __device__ inline uint32_t vote_row_code(int row_local, int tile_refs, int A) {
+  const int H = vote_half_rows(tile_refs);
+  const int hf = row_local >= H ? 1 : 0;
+  return (uint32_t)((vote_guard(A) + (row_local - hf * H) * vote_pitch(A)) * 4) | (uint32_t)hf;
+}
 
 struct CloudSoA {
   const float *x, *y, *z, *nx, *ny, *nz;
@@ -385,8 +393,7 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
   const int tile = i / tile_refs;
   const float am = pair_alpha[idx];
   if (phase == 0 && bucket_slot) bucket_slot[b] = slot;
-  place_entry(phase, (size_t)tile * n_buckets + b,
-              (uint32_t)((vote_guard(num_angles) + (i - tile * tile_refs) * vote_pitch(num_angles)) * 4), am, num_angles,
+  place_entry(phase, (size_t)tile * n_buckets + b, vote_row_code(i - tile * tile_refs, tile_refs, num_angles), am, num_angles,
               levels, counts, rec_off, class_cnt, class_cur, records, pair_rank ? 1 : 0, pair_rank ? pair_rank[idx] : 0u);
   /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
    * that point lives in the next tile, the entry is mirrored there: bin A -> cell 0, others -> guard. */
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__
   const int b = slot_to_bucket(slotmap, slot);
   const int tile = i / tile_refs;
   const float am = pair_alpha[idx];
-  const uint32_t row_bytes = (uint32_t)((vote_guard(num_angles) + (i - tile * tile_refs) * vote_pitch(num_angles)) * 4);
+  const uint32_t row_bytes = vote_row_code(i - tile * tile_refs, tile_refs, num_angles);
   uint32_t c, lv;
   entry_class_level(row_bytes, am, num_angles, 1, &c, &lv);
   const float q = am * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
@@ -1231,6 +1238,8 @@ struct ppf_workspace {
   struct Learned { const ppf_model* model; double hit, run; };
   std::vector<Learned> frac_by_model;    /* the two fractions remembered per model (batches alternate models) */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
+  bool acc32 = false;                    /* a 16-bit accumulator cell overflowed with this model: 32-bit cells until the model changes */
+  bool force_acc32 = false;              /* PPF_OPT_ACC32 */
   bool cluster_serial = false;           /* force the serial greedy assignment (otherwise only used above 11,520 poses) */
   int device = -1;
   uint32_t* acc_dump = nullptr; /* set by ppf_debug_accumulators for one call */
@@ -1575,7 +1584,7 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   m->info.position_threshold_default = params->relative_sampling_step;
   m->info.rotation_threshold_default = ((360 / angle_step) / 180.0 * PPF_PI);
   const int A = m->info.num_angles;
-  int max_refs = max_tile_rows(A);
+  int max_refs = 2 * max_tile_rows(A); /* 16-bit cells: two rows per accumulator word */
   if (params->max_tile_refs > 0) max_refs = std::min(max_refs, params->max_tile_refs);
   if (max_refs < 1) {
     return fail(PPF_ERR_INVALID, "ppf_model_train: num_angles %d too large for the LDS accumulator", A);
@@ -1639,7 +1648,7 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
           if (k >= m->info.n_entries) return fail(PPF_ERR_INVALID, "ppf_model_get_table: more entries than counted");
           if (entry_cell) { /* byte offset of the row -> reference layout local_ref*numAngles (mirrored spill entries: -numAngles) */
             const int32_t w = (int32_t)(rows[sl] / 4) - vote_guard(A);
-            entry_cell[k] = w < 0 ? -A : (w / vote_pitch(A)) * A;
+            entry_cell[k] = w < 0 ? -A : (w / vote_pitch(A) + (int32_t)(rows[sl] & 1u) * vote_half_rows(m->info.tile_refs)) * A;
           }
           if (entry_alpha) memcpy(&entry_alpha[k], &al[sl], 4);
           k++;
@@ -1677,6 +1686,9 @@ ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value)
       return PPF_OK;
     case PPF_OPT_CLUSTER_SERIAL:
       ws->cluster_serial = value != 0;
+      return PPF_OK;
+    case PPF_OPT_ACC32:
+      ws->force_acc32 = value != 0;
       return PPF_OK;
     default:
       return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: unknown option %d", option);
@@ -1774,6 +1786,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   const bool d_edge = ws->has_edge;
   if (ws->model != m) { /* another model: its own hit density (remembered if it has been here before) */
     workspace_remember_frac(ws);
+    ws->acc32 = false;
     bool found = false;
     for (auto& fm : ws->frac_by_model)
       if (fm.model == m) { ws->hit_frac = fm.hit; ws->run_frac = fm.run; found = true; }
@@ -1832,6 +1845,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.acc_dump = ws->acc_dump;
   va.bucket_total = m->bucket_total.p;
   va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
+  va.acc32 = (ws->acc32 || ws->force_acc32) ? 1 : 0;
   const bool darboux = m->params.feature == PPF_FEATURE_DARBOUX;
   va.pair_radius = params->pair_radius;
   va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || params->alpha_range_2pi || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
@@ -1908,7 +1922,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.runs = ws->runs.p; va.run_cap = run_cap; va.run_blocks = ws->run_blocks.p;
   va.work = ws->work.p; va.perm = ws->perm.p; va.perm_group = ws->perm_group.p;
 
-  const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)m->info.tile_refs * vote_pitch(m->info.num_angles)) * 4;
+  const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)vote_half_rows(m->info.tile_refs) * vote_pitch(m->info.num_angles)) * 4;
   if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
   /* k_group's dynamic LDS: counters, chunk prefix, and as many cached alpha_s as the rest holds */
   const size_t group_fixed = (size_t)((va.round_buckets + 1) & ~1) * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
@@ -1920,9 +1934,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (attr_err == hipSuccess)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    const void* votes[4] = {reinterpret_cast<const void*>(&k_vote<false, false>), reinterpret_cast<const void*>(&k_vote<true, false>),
+                            reinterpret_cast<const void*>(&k_vote<false, true>), reinterpret_cast<const void*>(&k_vote<true, true>)};
+    for (const void* f : votes)
+      if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr_err == hipSuccess)
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES - 1024);
   });
@@ -1958,8 +1973,14 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 2], st));
-    if (params->alpha_range_2pi) k_vote<true><<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
-    else k_vote<false><<<dim3((unsigned)((size_t)va.n_ref * T)), dim3(VOTE_BLOCK), lds, st>>>(va);
+    const dim3 vgrid((unsigned)((size_t)va.n_ref * T));
+    if (va.acc32) {
+      if (params->alpha_range_2pi) k_vote<true, true><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
+      else k_vote<false, true><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
+    } else {
+      if (params->alpha_range_2pi) k_vote<true, false><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
+      else k_vote<false, false><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
+    }
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 3], st));
   }
@@ -2029,7 +2050,9 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->checked = true;
       return PPF_OK;
     }
-    if (ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
+    if ((ovf & 7u) && ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
+    if ((ovf & 8u) && (ws->acc32 || ws->force_acc32)) return fail(PPF_ERR_HIP, "match: accumulator overflow reported with 32-bit cells");
+    if (ovf & 8u) ws->acc32 = true; /* a 16-bit cell overflowed: this scene votes with 32-bit cells from now on */
     if (ovf & 3u) ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0); /* raw or sorted hit pool */
     if (ovf & 4u) ws->run_frac = std::min(1.0, ws->run_frac * 2.0); /* run table */
     ws->stats.n_retries++;
@@ -2580,7 +2603,7 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
   const int A = I.num_angles, P = vote_pitch(A), GW = vote_guard(A);
   if (I.n_tiles < 1 || I.tile_refs < 1 || (uint64_t)I.n_tiles * I.tile_refs < N || (uint64_t)(I.n_tiles - 1) * I.tile_refs >= N)
     return bad("tiles");
-  if (I.tile_refs > max_tile_rows(A)) return bad("tile does not fit this build's LDS accumulator");
+  if (I.tile_refs > 2 * max_tile_rows(A)) return bad("tile does not fit this build's LDS accumulator");
   if (I.n_buckets > I.slots || (uint64_t)I.n_buckets > N * N) return bad("n_buckets");
   if (I.n_entries > N * N + N) return bad("n_entries");
   const uint64_t nb = I.n_buckets, ne = m->n_records, T = (uint64_t)I.n_tiles;
@@ -2622,12 +2645,13 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
     }
     if (prev != ne) return bad("bucket offsets (total)");
   }
-  { /* records: LDS byte offsets inside guard + tile rows (a vote adds up to A*4 bytes), finite alphas within (-pi, pi) */
-    const uint32_t limit_words = (uint32_t)(GW + I.tile_refs * P);
+  { /* records: LDS byte offsets inside guard + the tile's word rows (a vote adds up to A*4 bytes) with the half of the
+     * word in bit 0, finite alphas within (-pi, pi) */
+    const uint32_t limit_words = (uint32_t)(GW + vote_half_rows(I.tile_refs) * P);
     for (uint64_t k = 0; k < ne; k++) {
       const uint32_t rows[2] = {ent[k].x, ent[k].y}, al[2] = {ent[k].z, ent[k].w};
       for (int sl = 0; sl < 2; sl++) {
-        if ((rows[sl] & 3u) || rows[sl] / 4 + (uint32_t)A + 1 > limit_words) return bad("record row");
+        if ((rows[sl] & 2u) || rows[sl] / 4 + (uint32_t)A + 1 > limit_words) return bad("record row");
         float av;
         memcpy(&av, &al[sl], 4);
         if (!(std::fabs(av) <= 3.1416f)) return bad("record alpha");

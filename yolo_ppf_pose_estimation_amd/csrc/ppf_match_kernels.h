@@ -21,7 +21,17 @@
  *              hit's cell (Y, p) in units of alpha bins (see "aggregated votes").
  *
  *   k_vote     one workgroup per (reference point, accumulator tile); the tile's Hough accumulator
- *              lives in LDS.  A run (one bucket, m hits) meets the bucket's entries in one of two ways:
+ *              lives in LDS as 16-BIT cells, two model rows per 32-bit word: row r < H (H = half the tile's
+ *              rows) counts in the low halves, row r + H in the high halves of the same words.  A pair
+ *              record carries the byte offset of its row's bin 0 and, in bit 0, which half it owns, so a
+ *              vote stays one ds_add_u32 of 1 or 0x10000 at (row + 4*bin) and a tile holds twice the rows
+ *              (the 2,000-point model of the headline case: one tile instead of two, i.e. half the work
+ *              items and table traffic).  A cell that passes 65,535 would carry into its neighbour; every
+ *              vote cast lands somewhere in LDS (a cell or a guard word), so the workgroup compares the
+ *              sum of what it finds there with the number of votes it issued: any carry makes the two
+ *              differ (each carry loses 65,535 or 65,536 from the sum), the workgroup raises a flag and
+ *              the host repeats the call with 32-bit cells (each tile in two passes, one per half).
+ *              A run (one bucket, m hits) meets the bucket's entries in one of two ways:
  *                direct      every entry votes once per hit: 1 fma + cvt + fract + address + ds_add_u32
  *                            per vote, entries held in registers while the hits go by;
  *                aggregated  (m >= PPF_AGG_MIN_HITS) the hits of the run are first histogrammed by cell,
@@ -86,7 +96,7 @@ constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + c
 constexpr int CUR_STRIDE = 32;
 constexpr int CUR_SORTED = POOL_STRIPES * CUR_STRIDE;
 constexpr int CUR_RUNS = CUR_SORTED + CUR_STRIDE;
-constexpr int CUR_OVERFLOW = CUR_RUNS + CUR_STRIDE;
+constexpr int CUR_OVERFLOW = CUR_RUNS + CUR_STRIDE; /* bits 1, 2, 4: raw pool, sorted pool, run table too small; 8: a 16-bit accumulator cell overflowed */
 constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
 
 /* per-wave LDS scratch of the aggregated path */
@@ -215,6 +225,7 @@ struct MatchArgs {
   int agg_min_hits;             /* 0: every run votes directly */
   int key_exact;                /* PPF_KEY_EXACT table: keys outside the key table match nothing */
   double pair_radius;           /* > 0: pairs farther apart than this are skipped (not counted) */
+  int acc32;                    /* k_vote: 32-bit cells, every tile in two passes (one per half of its rows); 0: 16-bit cells */
   int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
   int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
@@ -656,13 +667,13 @@ __device__ __forceinline__ void vote_fix(const uint4* rec, const float S, const 
 }
 /* the 2U atomics of one hit: LDS address = row's bin 0 + 4k (one v_lshl_add_u32), ds_add_u32 */
 template <int U>
-__device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32_t (&pb)[U], const int (&ka)[U], const int (&kb)[U],
-                                           const int n_valid) {
+__device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32_t (&pb)[U], const uint32_t (&ia)[U], const uint32_t (&ib)[U],
+                                           const int (&ka)[U], const int (&kb)[U], const int n_valid) {
 #pragma unroll
   for (int u = 0; u < U; u++) {
     if (u < n_valid) {
-      lds_add(pa[u] + ((uint32_t)ka[u] << 2), 1u);
-      lds_add(pb[u] + ((uint32_t)kb[u] << 2), 1u);
+      lds_add(pa[u] + ((uint32_t)ka[u] << 2), ia[u]);
+      lds_add(pb[u] + ((uint32_t)kb[u] << 2), ib[u]);
     }
   }
 }
@@ -670,10 +681,11 @@ __device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32
 template <int U, bool WRAP>
 __device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, const float S, const float ohg_v, const int hh,
                                            const double* __restrict__ asd, const float G2, const int A, const uint32_t (&pa)[U],
-                                           const uint32_t (&pb)[U], const int (&pka)[U], const int (&pkb)[U], int (&nka)[U], int (&nkb)[U]) {
+                                           const uint32_t (&pb)[U], const uint32_t (&ia)[U], const uint32_t (&ib)[U], const int (&pka)[U],
+                                           const int (&pkb)[U], int (&nka)[U], int (&nkb)[U]) {
   float frmin;
   const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
-  vote_issue<U>(pa, pb, pka, pkb, n_valid);
+  vote_issue<U>(pa, pb, ia, ib, pka, pkb, n_valid);
   vote_bins<U, WRAP>(rec, S, Ohg, A, nka, nkb, frmin);
 #pragma unroll
   for (int i = 0; i < 2 * U; i++) {
@@ -684,17 +696,25 @@ __device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, 
 }
 /* all hits of a direct work item against one register batch of records; two sets of bins alternate so that a set is only
  * overwritten a full stage after the atomics that used it were issued */
+/* increment of a vote for the row a record names: bit 0 of the row offset says which half of the word the row owns */
+struct VoteInc {
+  uint32_t lo, hi; /* 16-bit cells: 1, 0x10000; 32-bit cells, pass h: 1 for the rows of half h, 0 for the others */
+};
+__device__ __forceinline__ uint32_t vote_inc(const VoteInc& vi, const uint32_t row_code) { return (row_code & 1u) ? vi.hi : vi.lo; }
+
 template <int U, bool WRAP>
-__device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* rec, const int n_valid, const float S,
+__device__ __forceinline__ void vote_hits(const uint32_t acc_base, const VoteInc& vi, const uint4* rec, const int n_valid, const float S,
                                           const float ohg_v, const int nh, const double* __restrict__ asd, const float G2,
                                           const int A) {
-  uint32_t pa[U], pb[U];
+  uint32_t pa[U], pb[U], ia[U], ib[U];
   int ka0[U], kb0[U], ka1[U], kb1[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    pa[u] = acc_base + rec[u].x;
-    pb[u] = acc_base + rec[u].y;
-    asm volatile("" : "+v"(pa[u]), "+v"(pb[u])); /* computed once per batch, not rematerialised per vote */
+    pa[u] = acc_base + (rec[u].x & ~3u);
+    pb[u] = acc_base + (rec[u].y & ~3u);
+    ia[u] = vote_inc(vi, rec[u].x);
+    ib[u] = vote_inc(vi, rec[u].y);
+    asm volatile("" : "+v"(pa[u]), "+v"(pb[u]), "+v"(ia[u]), "+v"(ib[u])); /* computed once per batch, not rematerialised per vote */
   }
   {
     float frmin;
@@ -704,14 +724,14 @@ __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* 
   }
   int hh = 1;
   for (; hh + 1 < nh; hh += 2) {
-    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
-    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh + 1, asd, G2, A, pa, pb, ka1, kb1, ka0, kb0);
+    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ia, ib, ka0, kb0, ka1, kb1);
+    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh + 1, asd, G2, A, pa, pb, ia, ib, ka1, kb1, ka0, kb0);
   }
   if (hh < nh) {
-    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ka0, kb0, ka1, kb1);
-    vote_issue<U>(pa, pb, ka1, kb1, n_valid);
+    vote_stage<U, WRAP>(rec, n_valid, S, ohg_v, hh, asd, G2, A, pa, pb, ia, ib, ka0, kb0, ka1, kb1);
+    vote_issue<U>(pa, pb, ia, ib, ka1, kb1, n_valid);
   } else {
-    vote_issue<U>(pa, pb, ka0, kb0, n_valid);
+    vote_issue<U>(pa, pb, ia, ib, ka0, kb0, n_valid);
   }
 }
 
@@ -719,16 +739,16 @@ __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const uint4* 
  * lane instead of one pair record per lane, so the 64 lanes of the single group are filled twice as well and a hit costs
  * one fma/cvt/fract/lshl_add/ds_add instead of two of each.  Same bins, same guard band, same exact fallback. */
 template <bool WRAP>
-__device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const uint32_t row_bytes, const uint32_t alpha_bits,
+__device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const VoteInc& vi, const uint32_t row_code, const uint32_t alpha_bits,
                                                  const float S, const float ohg_v, const int nh, const double* __restrict__ asd,
                                                  const float G2, const int A) {
-  uint32_t pr = acc_base + row_bytes;
-  asm volatile("" : "+v"(pr));
+  uint32_t pr = acc_base + (row_code & ~3u), inc = vote_inc(vi, row_code);
+  asm volatile("" : "+v"(pr), "+v"(inc));
   const float am = __uint_as_float(alpha_bits);
   uint32_t adr_prev = 0;
   for (int hh = 0; hh < nh; hh++) {
     const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
-    if (hh) lds_add(adr_prev, 1u);
+    if (hh) lds_add(adr_prev, inc);
     const float q = __builtin_fmaf(am, S, Ohg);
     int k = vote_wrap<WRAP>((int)q, A);
     if (__builtin_expect(__any(__builtin_amdgcn_fractf(q) < G2), 0)) {
@@ -740,7 +760,7 @@ __device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const 
     }
     adr_prev = pr + ((uint32_t)k << 2);
   }
-  if (nh > 0) lds_add(adr_prev, 1u);
+  if (nh > 0) lds_add(adr_prev, inc);
 }
 
 /* ---- aggregated votes ------------------------------------------------------------------------------------------- */
@@ -750,6 +770,10 @@ struct AggConsts {
   float S, half_a, Og, G2;
   double s64, half_a64;
   int A;
+  VoteInc vi;
+  /* v_perm_b32 selectors that move count byte jj of a table word to where the row's half counts: selector of byte 0 plus
+   * jj times a step (low half: byte 0; high half: byte 2; 32-bit cells, other half's pass: all zero) */
+  uint32_t sel_lo, step_lo, sel_hi, step_hi;
 };
 
 /* Count table of one range of <= AGG_SUB hits (global indices g0 .. g0+ms of the sorted payload), built by one wave in its
@@ -871,14 +895,23 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   uint2 ca = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qa, AGG_Q - 1) * 4), cb = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qb, AGG_Q - 1) * 4);
   if (qa == AGG_Q) { ca.x = 0u; ca.y = (uint32_t)ms; }
   if (qb == AGG_Q) { cb.x = 0u; cb.y = (uint32_t)ms; }
-  const uint32_t pa = k.acc_base + rec.x, pb = k.acc_base + rec.y;
+  const uint32_t pa = k.acc_base + (rec.x & ~3u), pb = k.acc_base + (rec.y & ~3u);
+  const bool ha = (rec.x & 1u) != 0, hb = (rec.y & 1u) != 0;
+  const uint32_t inc_a = ha ? k.vi.hi : k.vi.lo, inc_b = hb ? k.vi.hi : k.vi.lo;
   uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
   asm volatile("" : "+v"(va), "+v"(vb)); /* keep these as the bases: every atomic below is base + immediate offset */
   const uint32_t wa[5] = {a01.x, a01.y, a23.x, a23.y, a45.x}, wb[5] = {b01.x, b01.y, b23.x, b23.y, b45.x};
+  uint32_t sa[4], sb[4]; /* one v_perm_b32 per count: byte jj of the table word -> the half this entry's row owns */
+  {
+    const uint32_t sa0 = ha ? k.sel_hi : k.sel_lo, sta = ha ? k.step_hi : k.step_lo;
+    const uint32_t sb0 = hb ? k.sel_hi : k.sel_lo, stb = hb ? k.step_hi : k.step_lo;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) { sa[jj] = sa0 + (uint32_t)jj * sta; sb[jj] = sb0 + (uint32_t)jj * stb; }
+  }
 #pragma unroll
   for (int j = 0; j <= AGG_NY; j++) {
-    lds_add(va + (uint32_t)((AGG_NY - j) * 4), (wa[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-    lds_add(vb + (uint32_t)((AGG_NY - j) * 4), (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+    lds_add(va + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wa[j >> 2], sa[j & 3]));
+    lds_add(vb + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wb[j >> 2], sb[j & 3]));
   }
   votes += (ca.y - ca.x) + (cb.y - cb.x);
   /* byte addresses into the cell-sorted offsets; reads past a lane's own range stay inside the workgroup's LDS and
@@ -898,8 +931,8 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
       if (da && fa < k.G2) ba = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ((ia - base32) >> 2))], k.A);
       if (db && fb < k.G2) bb = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ((ib - base32) >> 2))], k.A);
     }
-    if (da) lds_add(pa + ((uint32_t)ba << 2), 1u);
-    if (db) lds_add(pb + ((uint32_t)bb << 2), 1u);
+    if (da) lds_add(pa + ((uint32_t)ba << 2), inc_a);
+    if (db) lds_add(pb + ((uint32_t)bb << 2), inc_b);
     ia += 4; ib += 4;
   }
 }
@@ -962,7 +995,7 @@ __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, i
 }
 
 /* WRAP: PCL's alpha binning (2 pi range with wrap-around, policy switch alpha_range_2pi): direct votes only */
-template <bool WRAP>
+template <bool WRAP, bool ACC32>
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
@@ -988,12 +1021,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const int rg = a.ref_base + r;
   const int tile_base = tile * a.tile_refs;
   const int refs_here = min(a.tile_refs, a.n_model - tile_base);
-  const int words = GW + refs_here * P;
-  { /* clear guard + cells with 16-byte LDS stores (the region starts 16-byte aligned) */
-    uint4* z = reinterpret_cast<uint4*>(lds_acc);
-    for (int c = tid; c < words / 4; c += VOTE_BLOCK) z[c] = make_uint4(0u, 0u, 0u, 0u);
-    for (int c = (words & ~3) + tid; c < words; c += VOTE_BLOCK) lds_acc[c] = 0u;
-  }
+  const int H = (a.tile_refs + 1) >> 1;            /* rows per half: row r < H owns the low halves, row r + H the high halves */
+  const int words = GW + min(H, refs_here) * P;
+  constexpr bool acc32 = ACC32; /* 32-bit cells, two passes per tile: the rare repeat after a 16-bit cell overflowed */
+  if (tid == 0) { red[50] = red[51] = red[52] = red[53] = 0u; } /* votes issued / votes found (64-bit each), see the overflow check */
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
   const uint4* __restrict__ records = a.records;
@@ -1020,6 +1051,22 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const uint32_t agg_min = (!WRAP && a.agg_min_hits > 0 && A <= AGG_MAX_ANGLES) ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
   unsigned long long ops = 0; /* LDS atomic lane-operations issued by this wave (wave-uniform part) */
   uint32_t agg_votes = 0;     /* ... plus this lane's one-by-one votes on the count-table path */
+  unsigned long long issued = 0; /* votes cast by this wave, wave-uniform: every lane slot of an item casts one vote per hit, into a cell or a guard word */
+
+  for (int pass = 0; pass < (acc32 ? 2 : 1); pass++) {
+  if (pass) __syncthreads(); /* the scan of the first pass is over */
+  { /* clear guard + cells with 16-byte LDS stores (the region starts 16-byte aligned) */
+    uint4* z = reinterpret_cast<uint4*>(lds_acc);
+    for (int c = tid; c < words / 4; c += VOTE_BLOCK) z[c] = make_uint4(0u, 0u, 0u, 0u);
+    for (int c = (words & ~3) + tid; c < words; c += VOTE_BLOCK) lds_acc[c] = 0u;
+  }
+  VoteInc vi;
+  vi.lo = acc32 ? (pass == 0 ? 1u : 0u) : 1u;
+  vi.hi = acc32 ? (pass == 1 ? 1u : 0u) : 0x10000u;
+  ak.vi = vi;
+  ak.sel_lo = (acc32 && pass == 1) ? 0x0c0c0c0cu : 0x0c0c0c00u; ak.step_lo = (acc32 && pass == 1) ? 0u : 1u;
+  ak.sel_hi = acc32 ? (pass == 1 ? 0x0c0c0c00u : 0x0c0c0c0cu) : 0x0c000c0cu;
+  ak.step_hi = acc32 ? (pass == 1 ? 1u : 0u) : 0x10000u;
 
   for (int blk = 0; blk < a.n_rounds; blk++) {
     const uint2 rb = a.run_blocks[(size_t)r * a.n_rounds + blk];
@@ -1104,6 +1151,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             rec_cur = rec_nxt;
           }
           ops += 2u * (AGG_NY + 1) * 64u * ((c + 63u) / 64u);
+          issued += 128ull * ((c + 63u) / 64u) * (uint32_t)cur.nh; /* counted + one-by-one votes of an entry = its hits */
         } else {
           /* ---- direct item: <= VOTE_MAX_HITS hits x <= VOTE_CHUNK records ---- */
           const uint32_t c = cur.c;
@@ -1115,6 +1163,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           constexpr uint32_t B = 64 * VOTE_UNROLL; /* records per batch */
           const uint32_t nfull = c / B;
           ops += 2ull * 64u * ((c + 63u) / 64u) * (uint32_t)nh;
+          issued += 128ull * VOTE_UNROLL * nfull * (uint32_t)nh;
           /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
            * flight while batch b is voted for every hit of the item.  The prefetch is unconditional
            * (the last one re-reads the final batch): a conditional one would merge two control-flow
@@ -1128,10 +1177,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           uint32_t b = 0;
           while (b < nfull) {
             load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
-            vote_hits<VOTE_UNROLL, WRAP>(acc_base, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+            vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
             if (++b >= nfull) break;
             load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
-            vote_hits<VOTE_UNROLL, WRAP>(acc_base, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+            vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
             ++b;
           }
           const uint32_t e0 = nfull * B;
@@ -1140,13 +1189,15 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             const uint4 rr = cur.rec0;
             const bool second = (lane & 1) != 0;
             const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            vote_hits_single<WRAP>(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            vote_hits_single<WRAP>(acc_base, vi, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            issued += 64ull * (uint32_t)nh;
           } else if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
             const uint32_t e = e0 + ((uint32_t)lane >> 1);
             const uint4 rr = src[min(e, c - 1)];
             const bool second = (lane & 1) != 0;
             const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            vote_hits_single<WRAP>(acc_base, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            vote_hits_single<WRAP>(acc_base, vi, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            issued += 64ull * (uint32_t)nh;
           } else if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
 #pragma unroll
             for (int u = 0; u < VOTE_UNROLL; u++) {
@@ -1155,14 +1206,15 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
               if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
             }
             const int n_valid = (int)((c - e0 + 63) / 64);
+            issued += 128ull * (uint32_t)n_valid * (uint32_t)nh;
             /* most buckets are smaller than a batch: only the 64-record groups that hold data get
              * their bin arithmetic, through an instantiation per group count */
             static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
             switch (n_valid) {
-              case 1: vote_hits<1, WRAP>(acc_base, ea, 1, S, ohg_v, nh, asd, G2, A); break;
-              case 2: vote_hits<2, WRAP>(acc_base, ea, 2, S, ohg_v, nh, asd, G2, A); break;
-              case 3: vote_hits<3, WRAP>(acc_base, ea, 3, S, ohg_v, nh, asd, G2, A); break;
-              default: vote_hits<4, WRAP>(acc_base, ea, 4, S, ohg_v, nh, asd, G2, A); break;
+              case 1: vote_hits<1, WRAP>(acc_base, vi, ea, 1, S, ohg_v, nh, asd, G2, A); break;
+              case 2: vote_hits<2, WRAP>(acc_base, vi, ea, 2, S, ohg_v, nh, asd, G2, A); break;
+              case 3: vote_hits<3, WRAP>(acc_base, vi, ea, 3, S, ohg_v, nh, asd, G2, A); break;
+              default: vote_hits<4, WRAP>(acc_base, vi, ea, 4, S, ohg_v, nh, asd, G2, A); break;
             }
           }
         }
@@ -1175,36 +1227,54 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 
   /* Scan in the reference's order (model ref ascending, alpha bin ascending, strict >) == smallest
    * upstream flat index ref*A + bin among the maxima; the spill cell of row ref-1 is folded into
-   * (ref, bin 0) on the way.  Also the exact vote total of the tile. */
+   * (ref, bin 0) on the way.  Also the exact vote total of the tile.  One thread per accumulator row: consecutive
+   * threads read consecutive rows, pitch P is odd -> no bank conflicts, no integer division; bins ascending with
+   * strict > keeps the row's first maximum.  32-bit cells: this pass holds the rows of half `pass` only. */
   uint32_t* dump = a.acc_dump ? a.acc_dump + (size_t)rg * a.n_model * A + (size_t)tile_base * A : nullptr;
   uint32_t bv = 0, bi = 0xFFFFFFFFu;
-  unsigned long long sum = 0;
-  /* one thread per accumulator row: consecutive threads read consecutive rows, pitch P is odd -> no bank
-   * conflicts, no integer division; bins ascending with strict > keeps the row's first maximum */
-  for (int ref = tid; ref < refs_here; ref += VOTE_BLOCK) {
-    const uint32_t* row = acc + ref * P;
+  unsigned long long sum = 0, found = 0;
+  const int row_lo = acc32 ? pass * H : 0, row_hi = acc32 ? min((pass + 1) * H, refs_here) : refs_here;
+  const uint32_t carry_spill = red[49]; /* 32-bit cells, second pass: cell A of row H-1, saved by the first pass */
+  for (int ref = row_lo + tid; ref < row_hi; ref += VOTE_BLOCK) {
+    const int hf = ref >= H ? 1 : 0;
+    const uint32_t* row = acc + (ref - hf * H) * P;
+    const int sh = acc32 ? 0 : hf * 16;
+    const uint32_t msk = acc32 ? 0xFFFFFFFFu : 0xFFFFu;
     for (int bin = 0; bin < A; bin++) {
-      uint32_t v = row[bin];
-      if (bin == 0 && ref > 0) v += row[A - P]; /* spill cell of the previous row */
+      uint32_t v = (row[bin] >> sh) & msk;
+      if (bin == 0 && ref > 0) { /* spill cell of the previous row; row H-1 lives in the low halves at the end of the tile */
+        if (ref == H) v += acc32 ? carry_spill : (acc[(H - 1) * P + A] & 0xFFFFu);
+        else v += (row[A - P] >> sh) & msk;
+      }
       if (dump) dump[ref * A + bin] = v;
       sum += v;
       if (v > bv) { bv = v; bi = (uint32_t)(ref * A + bin); }
     }
   }
-  unsigned long long wops = (unsigned long long)agg_votes; /* summed over the lanes below; the uniform part is added once */
+  if (!acc32) /* everything the votes left in LDS: guard words are whole counters, cell words two 16-bit counters */
+    for (int c = tid; c < words; c += VOTE_BLOCK) {
+      const uint32_t w = lds_acc[c];
+      found += c < GW ? (unsigned long long)w : (unsigned long long)((w & 0xFFFFu) + (w >> 16));
+    }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t v2 = __shfl_down(bv, o), i2 = __shfl_down(bi, o);
     sum += __shfl_down(sum, o);
-    wops += __shfl_down(wops, o);
+    found += __shfl_down(found, o);
     if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
   }
-  wops += ops;
   uint32_t* red_v = seg_prefix; /* staging arrays are free now */
   uint32_t* red_i = seg_prefix + VOTE_WAVES;
   __syncthreads();
   if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+  if (!acc32 && lane == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(&red[50]), issued);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&red[52]), found);
+  }
+  if (acc32 && pass == 0 && tid == 0 && refs_here > H) red[49] = acc[(H - 1) * P + A];
   __syncthreads();
+  /* 16-bit cells: a cell that wrapped or carried into its neighbour makes the votes found differ from the votes issued */
+  if (!acc32 && tid == 0 && (red[50] != red[52] || red[51] != red[53])) atomicOr(&a.cursors[CUR_OVERFLOW], 8u);
   if (wave == 0) {
     uint32_t v = (lane < VOTE_WAVES) ? red_v[lane] : 0u;
     uint32_t ix = (lane < VOTE_WAVES) ? red_i[lane] : 0xFFFFFFFFu;
@@ -1213,9 +1283,19 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       const uint32_t v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
       if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
     }
-    if (lane == 0) a.partial[(size_t)rg * a.n_tiles + tile] = make_uint2(v, ix);
+    if (lane == 0) {
+      if (pass == 1 && red[54] >= v) { v = red[54]; ix = red[55]; } /* the first pass scanned the rows that come first: it keeps ties */
+      red[54] = v; red[55] = ix;
+      if (pass == (acc32 ? 1 : 0)) a.partial[(size_t)rg * a.n_tiles + tile] = make_uint2(v, ix);
+    }
   }
   if (lane == 0 && sum) atomicAdd(&a.cellsum[(size_t)rg * a.n_tiles + tile], sum);
+  } /* pass */
+
+  unsigned long long wops = (unsigned long long)agg_votes; /* summed over the lanes below; the uniform part is added once */
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wops += __shfl_down(wops, o);
+  wops += ops;
   if (lane == 0 && wops) atomicAdd(&a.tally[0], wops);
 }
 
