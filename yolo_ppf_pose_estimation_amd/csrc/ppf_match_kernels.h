@@ -111,8 +111,11 @@ static_assert(AGG_SUB * 4 <= 768 && AGG_SUB <= 192 && AGG_NY * AGG_Q <= 768 && A
 static_assert(AGG_SCRATCH % 16 == 0, "wave scratch must keep 16-byte alignment");
 
 /* fp32 acos for BIN SELECTION only: acos(|x|) = sqrt(1-|x|) * P(|x|), degree-7 least-squares/minimax fit,
- * measured max error 3.4e-7 rad including fp32 evaluation (tests/test_gpu_fastkeys.py re-checks the keys
- * against the exact path).  `t` = 1-|x| is formed in fp64 so the estimate stays relative-accurate near |x| = 1. */
+ * measured max error 3.4e-7 rad including fp32 evaluation with a correctly rounded sqrt; the square root here is the bare
+ * v_sqrt_f32 (1 ulp: at most 1.9e-7 rad more; the IEEE fix-up sequence the compiler wraps around sqrtf costs 13
+ * instructions, three times per pair), so 5.3e-7 rad in all against a guard band of 4e-6 (tests/test_gpu_fastkeys.py
+ * re-checks the keys against the exact path).  `t` = 1-|x| is formed in fp64 so the estimate stays relative-accurate
+ * near |x| = 1 (t is 0 or a normal float: no denormal input). */
 __device__ __forceinline__ float acos32_estimate(double x) {
   const double ax = ppf_fabs(x);
   const float xf = (float)ax;
@@ -125,7 +128,7 @@ __device__ __forceinline__ float acos32_estimate(double x) {
   p = __builtin_fmaf(p, xf, 0.08899927139282227f);
   p = __builtin_fmaf(p, xf, -0.21459989249706268f);
   p = __builtin_fmaf(p, xf, 1.5707963705062866f);
-  const float a = __builtin_sqrtf(t) * p;
+  const float a = __builtin_amdgcn_sqrtf(t) * p;
   return x >= 0.0 ? a : 3.14159274101257324f - a;
 }
 
@@ -144,13 +147,19 @@ struct FastKeyConsts {
 __device__ __forceinline__ void pair_key(const ppf_vec3& p1, const ppf_vec3& n1, const ppf_vec3& p2, const ppf_vec3& n2,
                                          const double angle_step, const double dist_step, const FastKeyConsts& fk, int32_t (&k)[4]) {
   const double dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
-  const double f3 = ppf_sqrt(dx * dx + dy * dy + dz * dz);
-  double rinv = __builtin_amdgcn_rcp(f3);
-  rinv = rinv * (2.0 - f3 * rinv); /* one Newton step: ~1e-16 relative, far inside the guard */
+  /* |d| and 1/|d| from one v_rsq_f64 and two Newton steps (a few ulp: far inside the guards below) instead of the
+   * correctly rounded sqrt + a reciprocal; |d| = 0, denormal or huge makes r infinite or NaN and sends the lane to the
+   * exact chain through the checks on f3 and q3 */
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  const double hd = 0.5 * d2;
+  double rinv = __builtin_amdgcn_rsq(d2);
+  rinv = rinv * (1.5 - hd * rinv * rinv);
+  rinv = rinv * (1.5 - hd * rinv * rinv);
+  const double f3 = d2 * rinv;
   const double x0 = (n1.x * dx + n1.y * dy + n1.z * dz) * rinv;
   const double x1 = (n2.x * dx + n2.y * dy + n2.z * dz) * rinv;
   const double x2 = ppf_dot3(n1, n2); /* same expression as the exact path: bit-identical */
-  bool slow = !(f3 > PPF_EPS) || !(ppf_fabs(x0) <= 1.0 - 1e-12) || !(ppf_fabs(x1) <= 1.0 - 1e-12) || !(ppf_fabs(x2) <= 1.0);
+  bool slow = !(f3 > 2.0 * PPF_EPS) || !(ppf_fabs(x0) <= 1.0 - 1e-12) || !(ppf_fabs(x1) <= 1.0 - 1e-12) || !(ppf_fabs(x2) <= 1.0);
   {
     const float q0 = acos32_estimate(x0) * fk.rstep32, q1 = acos32_estimate(x1) * fk.rstep32,
                 q2 = acos32_estimate(x2) * fk.rstep32;
@@ -162,7 +171,7 @@ __device__ __forceinline__ void pair_key(const ppf_vec3& p1, const ppf_vec3& n1,
     const double q3 = f3 * fk.rdstep;
     k[3] = (int)q3;
     const double fr3 = q3 - (double)k[3];
-    slow |= !(fr3 > 1e-9 && fr3 < 1.0 - 1e-9) || !(q3 < 2.0e9);
+    slow |= !(fr3 > 1e-9 && fr3 < 1.0 - 1e-9) || !(q3 < 1.0e5); /* 1e5 bins x 1e-15 relative error of f3 stays below the 1e-9 guard */
   }
   if (slow) {
     double f[4] = {0, 0, 0, 0};
