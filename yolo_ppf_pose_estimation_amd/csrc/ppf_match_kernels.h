@@ -88,6 +88,7 @@ constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes;
 constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in [-8, 7] */
 constexpr int RUN_SEG = 256;          /* runs staged in LDS per segment */
 constexpr int GROUP_BLOCK = 512;       /* two k_group workgroups per CU when the bucket counters fit half the LDS (0.705 -> 0.665 ms on C2) */
+constexpr int GROUP_MLP = 4;            /* hits a k_group thread has in flight per step of its two passes */
 constexpr int GROUP_MAX_BUCKETS = 36000; /* LDS counters of k_group per round (144 KB) */
 constexpr int POOL_STRIPES = 64;      /* the raw hit pool is cut into stripes with one cursor each */
 constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + claim counter */
@@ -455,25 +456,50 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     const uint32_t nb = min((uint32_t)a.round_buckets, (uint32_t)a.n_buckets - b0);
     for (uint32_t k = tid; k < nb; k += GROUP_BLOCK) gcnt[k] = 0;
     __syncthreads();
-    {
+    { /* GROUP_MLP hits per thread and step: their pool reads, then their gathers, are all in flight before the first
+       * alpha_s is computed (one hit at a time the loop is a chain of two memory latencies per hit) */
       int c = 0;
-      for (uint32_t g = tid; g < n_list; g += GROUP_BLOCK) {
-        while (g >= cpre[c + 1]) c++;
-        const uint32_t at = desc[c].x + (g - cpre[c]);
-        const uint2 key = a.raw[at];
-        const uint32_t bl = key.x - b0;
-        if (bl < nb) {
-          const uint32_t total = a.bucket_total[key.x]; /* independent gather, issued with the others */
-          const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key.y);
-          const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
-          const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
-          double as = 0.0;
-          if (ppf_alpha_in_frame(qy, qz, &as)) {
-            atomicAdd(&gcnt[bl], 1u);
-            w += total;
-            if (g < n_cache) acache[g] = as;
-          } else {
-            a.raw[at].x = 0xFFFFFFFFu; /* retired: matches no round */
+      for (uint32_t g0 = tid; g0 < n_list; g0 += GROUP_MLP * GROUP_BLOCK) {
+        uint32_t at[GROUP_MLP];
+        uint2 key[GROUP_MLP];
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
+          key[u] = make_uint2(0xFFFFFFFFu, 0u);
+          at[u] = 0u;
+          if (g < n_list) {
+            while (g >= cpre[c + 1]) c++;
+            at[u] = desc[c].x + (g - cpre[c]);
+            key[u] = a.raw[at[u]];
+          }
+        }
+        uint32_t total[GROUP_MLP];
+        ppf_vec3 p2[GROUP_MLP];
+        bool in[GROUP_MLP];
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          in[u] = key[u].x - b0 < nb; /* retired hits (0xFFFFFFFF) and other rounds' buckets fall out here */
+          total[u] = 0u;
+          p2[u] = ppf_mk3(0.0, 0.0, 0.0);
+          if (in[u]) {
+            total[u] = a.bucket_total[key[u].x];
+            p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          if (in[u]) {
+            const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
+            const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
+            const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
+            double as = 0.0;
+            if (ppf_alpha_in_frame(qy, qz, &as)) {
+              atomicAdd(&gcnt[key[u].x - b0], 1u);
+              w += total[u];
+              if (g < n_cache) acache[g] = as;
+            } else {
+              a.raw[at[u]].x = 0xFFFFFFFFu; /* retired: matches no round */
+            }
           }
         }
       }
@@ -531,23 +557,51 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     __syncthreads();
     {
       int c = 0;
-      for (uint32_t g = tid; g < n_list; g += GROUP_BLOCK) {
-        while (g >= cpre[c + 1]) c++;
-        const uint2 key = a.raw[desc[c].x + (g - cpre[c])];
-        const uint32_t bl = key.x - b0;
-        if (bl < nb) {
-          double as = 0.0;
-          if (g < n_cache) {
-            as = acache[g];
-          } else {
-            const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key.y);
-            const double qy = ty + (R10 * p2.x + R11 * p2.y + R12 * p2.z);
-            const double qz = tz + (R20 * p2.x + R21 * p2.y + R22 * p2.z);
-            (void)ppf_alpha_in_frame(qy, qz, &as);
+      for (uint32_t g0 = tid; g0 < n_list; g0 += GROUP_MLP * GROUP_BLOCK) {
+        uint2 key[GROUP_MLP];
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
+          key[u] = make_uint2(0xFFFFFFFFu, 0u);
+          if (g < n_list) {
+            while (g >= cpre[c + 1]) c++;
+            key[u] = a.raw[desc[c].x + (g - cpre[c])];
           }
-          const uint32_t gi = hit_base + atomicAdd(&gcnt[bl], 1u);
-          a.s_a64[gi] = as;
-          a.s_cell[gi] = (uint16_t)hit_cell(as, s64);
+        }
+        double as[GROUP_MLP];
+        ppf_vec3 p2[GROUP_MLP];
+        bool in[GROUP_MLP], cached[GROUP_MLP];
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
+          in[u] = key[u].x - b0 < nb;
+          cached[u] = g < n_cache;
+          as[u] = 0.0;
+          p2[u] = ppf_mk3(0.0, 0.0, 0.0);
+          if (in[u]) {
+            if (cached[u]) as[u] = acache[g];
+            else p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
+          }
+        }
+        uint32_t gi[GROUP_MLP];
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          gi[u] = 0u;
+          if (in[u]) {
+            if (!cached[u]) {
+              const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
+              const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
+              (void)ppf_alpha_in_frame(qy, qz, &as[u]);
+            }
+            gi[u] = hit_base + atomicAdd(&gcnt[key[u].x - b0], 1u);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GROUP_MLP; u++) {
+          if (in[u]) {
+            a.s_a64[gi[u]] = as[u];
+            a.s_cell[gi[u]] = (uint16_t)hit_cell(as[u], s64);
+          }
         }
       }
     }
@@ -928,21 +982,30 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   const uint32_t base32 = k.ws + AGG_OFF_A32;
   uint32_t ia = base32 + ca.x * 4, ib = base32 + cb.x * 4;
   const uint32_t ea = base32 + ca.y * 4, eb = base32 + cb.y * 4;
+  /* two hits of each entry's cell per step: one ds_read2_b32 fetches both offsets (the LDS pipe is what this kernel runs
+   * out of, and a read with scattered addresses costs it as much as an atomic) */
   while (__any((ia < ea) | (ib < eb))) {
-    const bool da = ia < ea, db = ib < eb;
-    const float oa = __uint_as_float(lds_ld(ia)), ob = __uint_as_float(lds_ld(ib));
-    const float xa = __builtin_fmaf(am_a, k.S, oa), xb = __builtin_fmaf(am_b, k.S, ob);
-    int ba = (int)xa, bb = (int)xb;
-    const float fa = __builtin_amdgcn_fractf(xa), fb = __builtin_amdgcn_fractf(xb);
-    if (__builtin_expect(__any(__builtin_fminf(fa, fb) < k.G2), 0)) { /* some lane may sit in the guard band of a bin edge */
+    const bool da0 = ia < ea, da1 = ia + 4u < ea, db0 = ib < eb, db1 = ib + 4u < eb;
+    const uint2 oa = lds_ld2(ia), ob = lds_ld2(ib);
+    const float xa0 = __builtin_fmaf(am_a, k.S, __uint_as_float(oa.x)), xa1 = __builtin_fmaf(am_a, k.S, __uint_as_float(oa.y));
+    const float xb0 = __builtin_fmaf(am_b, k.S, __uint_as_float(ob.x)), xb1 = __builtin_fmaf(am_b, k.S, __uint_as_float(ob.y));
+    int ba0 = (int)xa0, ba1 = (int)xa1, bb0 = (int)xb0, bb1 = (int)xb1;
+    const float fa0 = __builtin_amdgcn_fractf(xa0), fa1 = __builtin_amdgcn_fractf(xa1);
+    const float fb0 = __builtin_amdgcn_fractf(xb0), fb1 = __builtin_amdgcn_fractf(xb1);
+    if (__builtin_expect(__any(__builtin_fminf(__builtin_fminf(fa0, fa1), __builtin_fminf(fb0, fb1)) < k.G2), 0)) { /* some lane may sit in the guard band of a bin edge */
       uint32_t za = rec.z, zb = rec.w;
       asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the loop */
-      if (da && fa < k.G2) ba = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ((ia - base32) >> 2))], k.A);
-      if (db && fb < k.G2) bb = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(k.ws + AGG_OFF_IDX + ((ib - base32) >> 2))], k.A);
+      const uint32_t ha = k.ws + AGG_OFF_IDX + ((ia - base32) >> 2), hb = k.ws + AGG_OFF_IDX + ((ib - base32) >> 2);
+      if (da0 && fa0 < k.G2) ba0 = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(ha)], k.A);
+      if (da1 && fa1 < k.G2) ba1 = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(ha + 1u)], k.A);
+      if (db0 && fb0 < k.G2) bb0 = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(hb)], k.A);
+      if (db1 && fb1 < k.G2) bb1 = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(hb + 1u)], k.A);
     }
-    if (da) lds_add(pa + ((uint32_t)ba << 2), inc_a);
-    if (db) lds_add(pb + ((uint32_t)bb << 2), inc_b);
-    ia += 4; ib += 4;
+    if (da0) lds_add(pa + ((uint32_t)ba0 << 2), inc_a);
+    if (db0) lds_add(pb + ((uint32_t)bb0 << 2), inc_b);
+    if (da1) lds_add(pa + ((uint32_t)ba1 << 2), inc_a);
+    if (db1) lds_add(pb + ((uint32_t)bb1 << 2), inc_b);
+    ia += 8; ib += 8;
   }
 }
 
