@@ -279,6 +279,32 @@ __global__ void k_bucket_total(const uint32_t* __restrict__ bucket_off, int n_bu
   total[b] = t;
 }
 
+/* Number of entries of every (tile, bucket) that belong to low-half rows.  With the dealing order above they are the
+ * first n0 dealing positions (position j = record 32*(j/64) + j%32, slot (j%64)/32), the high-half rows' entries follow,
+ * padding comes last: a 32-bit pass over the low halves needs records [0, 32*(n0/64) + min(n0%64, 32)), one over the
+ * high halves [32*(n0/64) + max(n0%64 - 32, 0), end) -- see k_vote. */
+__global__ void k_bucket_mid(const uint32_t* __restrict__ bucket_off, int n_buckets, int n_tiles, const uint4* __restrict__ records,
+                             uint32_t first_real, uint32_t* __restrict__ mid) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n_buckets * n_tiles) return;
+  const size_t t = idx / n_buckets, b = idx % n_buckets;
+  const uint32_t* row = bucket_off + t * ((size_t)n_buckets + 1);
+  const uint32_t off = row[b], cnt = row[b + 1] - off;
+  uint32_t lo = 0, hi = 64u * ((cnt + 31u) / 32u); /* positions < lo are low-half entries, positions >= hi are not */
+  while (lo < hi) {
+    const uint32_t j = (lo + hi) >> 1;
+    const uint32_t r = 32u * (j / 64u) + (j % 32u);
+    bool low = false;
+    if (r < cnt) {
+      const uint4 rec = records[off + r];
+      const uint32_t code = ((j % 64u) / 32u) ? rec.y : rec.x;
+      low = code >= first_real && !(code & 1u);
+    }
+    if (low) lo = j + 1; else hi = j;
+  }
+  mid[idx] = lo;
+}
+
 __global__ void k_popcount_words(const unsigned long long* __restrict__ bits, uint32_t* __restrict__ cnt, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) cnt[i] = (uint32_t)__popcll(bits[i]);
@@ -324,9 +350,11 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  * in which 32 consecutive entries hit 32 different LDS banks for (almost) every alpha_s:
  *   - bank class  c = (row_word + bin0(alpha_m)) mod 32: the bank of the vote when alpha_s == 0; for another
  *     alpha_s all bins shift together, up to one bin of jitter decided by where alpha_m sits inside its bin;
- *   - phase level lv = that position inside the bin, quantised to TABLE_LEVELS: entries of one level jitter together;
- *   - order = (level, round k = rank of the entry inside its (level, class), class): round k of a level holds one
- *     entry of every class that still has one.
+ *   - level lv = the half of the accumulator words the entry's row owns (vote_row_code): the rows of the low halves are
+ *     dealt first, so the records of a (tile, bucket) are those of its low-half rows, at most 32 mixed records, those of
+ *     its high-half rows -- the repeat of a call with 32-bit cells walks only its half's share (k_bucket_mid);
+ *   - order = (level, round k = rank of the entry by phase inside its (level, class), class): round k of a level holds
+ *     one entry of every class that still has one, entries of similar phase jitter together.
  * Dealing position j -> record 32*(j/64) + j%32, slot (j%64)/32: 32 consecutive dealing positions share a slot of
  * 32 consecutive records.  Unused slots of the last records hold dummies that vote into the LDS guard words.
  */
@@ -336,7 +364,7 @@ __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alph
   const float q = alpha_m * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
   const float fl = floorf(q);
   *cls = (row_bytes / 4u + (uint32_t)(int)fl) & 31u;
-  *lvl = min((uint32_t)((q - fl) * (float)levels), (uint32_t)(levels - 1));
+  *lvl = levels > 1 ? (row_bytes & 1u) : 0u; /* the half of the accumulator word the entry's row owns: low-half rows are dealt first */
 }
 
 __host__ __device__ __forceinline__ uint32_t records_for(uint32_t n_entries) {
@@ -402,7 +430,7 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
                 num_angles, levels, counts, rec_off, class_cnt, class_cur, records, pair_rank ? 2 : 0, 0u);
 }
 
-/* sort keys of the model pairs for the dealing order: key_class = (tile*n_buckets + bucket)*32 + bank class (invalid pairs:
+/* sort keys of the model pairs for the dealing order: key_class = ((tile*n_buckets + bucket)*2 + level)*32 + bank class (invalid pairs:
  * `invalid`), key_phase = position of alpha_m inside its bin, 16 bits */
 __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
                                                     const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int num_angles,
@@ -420,9 +448,9 @@ __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__
   const float am = pair_alpha[idx];
   const uint32_t row_bytes = vote_row_code(i - tile * tile_refs, tile_refs, num_angles);
   uint32_t c, lv;
-  entry_class_level(row_bytes, am, num_angles, 1, &c, &lv);
+  entry_class_level(row_bytes, am, num_angles, 2, &c, &lv);
   const float q = am * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
-  key_class[idx] = (uint32_t)(((size_t)tile * n_buckets + b) * 32 + c);
+  key_class[idx] = (uint32_t)((((size_t)tile * n_buckets + b) * 2 + lv) * 32 + c);
   key_phase[idx] = min((uint32_t)((q - floorf(q)) * 65536.0f), 65535u);
 }
 __global__ __launch_bounds__(256) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, size_t n,
@@ -519,6 +547,8 @@ struct FinalArgs {
   int scene_step, ref_offset, ref_stride, n_ref;
   int n_tiles, tile_refs, num_angles;
   int alpha_2pi; /* PCL's alpha binning: the winning bin stands for idx * 2pi/A - pi */
+  int acc32;     /* k_vote ran with 32-bit cells: two partial results per tile (one per half of its rows) and the edge values */
+  const uint32_t* edge;
   const uint2* partial;
   const unsigned long long* cellsum;
   const unsigned long long* pairs;
@@ -533,9 +563,20 @@ __global__ void k_finalize(FinalArgs a) {
   uint32_t maxVotes = 0, flat = 0;
   unsigned long long nv = 0;
   for (int t = 0; t < a.n_tiles; t++) {
-    const uint2 p = a.partial[(size_t)r * a.n_tiles + t];
+    const size_t slot = ((size_t)r * a.n_tiles + t) * 2;
+    const uint2 p = a.partial[slot];
     nv += a.cellsum[(size_t)r * a.n_tiles + t];
     if (p.x > maxVotes) { maxVotes = p.x; flat = (uint32_t)(t * a.tile_refs * a.num_angles) + p.y; }
+    if (a.acc32) { /* the high-half rows come after the low-half rows; bin 0 of their first row still lacks the spill
+                      cell of the row before it, which the low halves' workgroup counted */
+      uint2 q = a.partial[slot + 1];
+      const uint32_t carry = a.edge[slot];
+      if (carry) {
+        const uint32_t cv = a.edge[slot + 1] + carry, ci = (uint32_t)(vote_half_rows(a.tile_refs) * a.num_angles);
+        if (cv > q.x || (cv == q.x && ci <= q.y)) q = make_uint2(cv, ci);
+      }
+      if (q.x > maxVotes) { maxVotes = q.x; flat = (uint32_t)(t * a.tile_refs * a.num_angles) + q.y; }
+    }
   }
   const uint32_t refIndMax = maxVotes ? flat / (uint32_t)a.num_angles : 0u;
   const uint32_t alphaIndMax = maxVotes ? flat % (uint32_t)a.num_angles : 0u;
@@ -1186,6 +1227,7 @@ struct ppf_model {
   DevBuf<uint32_t> bucket_off;  /* n_tiles * (n_buckets + 1) */
   DevBuf<uint32_t> bucket_slot; /* n_buckets: hash slot of each dense bucket id */
   DevBuf<uint32_t> bucket_total; /* n_buckets: entries over all tiles */
+  DevBuf<uint32_t> bucket_mid;   /* n_tiles * n_buckets: see k_bucket_mid */
   DevBuf<uint4> records;          /* pair records, see place_entry */
   DevBuf<int32_t> key_lut;        /* quantised key -> bucket, see k_build_key_lut */
   KeyDims kd{};
@@ -1197,6 +1239,7 @@ struct ppf_workspace {
   CloudDev surf, edge;
   DevBuf<float> staging;
   DevBuf<uint2> partial;
+  DevBuf<uint32_t> half_edge; /* see MatchArgs::edge */
   /* hit scratch of one batch of reference points (see ppf_match_kernels.h) */
   DevBuf<double> frames;
   DevBuf<uint2> raw;                     /* striped pool of {bucket, j} */
@@ -1443,11 +1486,11 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(offsets.reserve(ncnt));
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
-  /* Dealing order inside a bucket: ONE phase level, and an entry's round is its RANK BY PHASE inside its bank class
+  /* Dealing order inside a bucket: two levels (the accumulator-word half of the entry's row), and an entry's round is its RANK BY PHASE inside its bank class
    * (the position of alpha_m inside its bin), so a round holds entries of similar phase from every class: they take
    * the one-bin jitter together, and the classes are as full, hence as balanced, as they can be. */
   const bool sorted_deal = true;
-  const int levels = 1;
+  const int levels = 2;
   const size_t ncls = ncnt * (size_t)levels * 32;
   DevBuf<uint32_t> class_cnt, class_cur;
   HIPCHK(class_cnt.reserve(ncls));
@@ -1491,7 +1534,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
     DevBuf<uint32_t> kcls, kph, v1, kt, v2, starts;
     HIPCHK(kcls.reserve(NN)); HIPCHK(kph.reserve(NN)); HIPCHK(v1.reserve(NN)); HIPCHK(kt.reserve(NN)); HIPCHK(v2.reserve(NN));
     HIPCHK(pair_rank.reserve(NN));
-    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 32);
+    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 64);
     k_train_keys<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets, m->info.tile_refs,
                                                    m->info.num_angles, invalid, kcls.p, kph.p, v1.p);
     HIPCHK(hipGetLastError());
@@ -1517,6 +1560,12 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(m->bucket_total.reserve(std::max<uint32_t>(n_buckets, 1)));
   if (n_buckets) {
     k_bucket_total<<<dim3((n_buckets + 255) / 256), dim3(256), 0, st>>>(m->bucket_off.p, (int)n_buckets, T, m->bucket_total.p);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(m->bucket_mid.reserve(std::max<size_t>((size_t)n_buckets * T, 1)));
+  if (n_buckets) {
+    k_bucket_mid<<<dim3((unsigned)(((size_t)n_buckets * T + 255) / 256)), dim3(256), 0, st>>>(
+        m->bucket_off.p, (int)n_buckets, T, m->records.p, (uint32_t)((vote_guard(m->info.num_angles) - m->info.num_angles) * 4), m->bucket_mid.p);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -1818,7 +1867,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   if (n_ref == 0) return PPF_OK;
 
   const int T = m->info.n_tiles;
-  HIPCHK(ws->partial.reserve((size_t)n_ref * T));
+  HIPCHK(ws->partial.reserve((size_t)n_ref * T * 2));
+  HIPCHK(ws->half_edge.reserve((size_t)n_ref * T * 2));
   const size_t n_cnt = (size_t)n_ref * T + n_ref + 6; /* cellsum | pairs | totals[2] | tally[4]: LDS operations, hits, runs, - */
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
@@ -1839,11 +1889,13 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.n_tiles = T; va.tile_refs = m->info.tile_refs; va.num_angles = m->info.num_angles; va.n_model = m->info.n_ref;
   va.angle_step = m->info.angle_step; va.dist_step = m->info.distance_step;
   va.partial = ws->partial.p;
+  va.edge = ws->half_edge.p;
   va.cellsum = ws->counters.p;
   va.pairs = ws->counters.p + (size_t)n_ref * T;
   va.tally = ws->counters.p + (size_t)n_ref * T + n_ref + 2;
   va.acc_dump = ws->acc_dump;
   va.bucket_total = m->bucket_total.p;
+  va.bucket_mid = m->bucket_mid.p;
   va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
   va.acc32 = (ws->acc32 || ws->force_acc32) ? 1 : 0;
   const bool darboux = m->params.feature == PPF_FEATURE_DARBOUX;
@@ -1973,7 +2025,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 2], st));
-    const dim3 vgrid((unsigned)((size_t)va.n_ref * T));
+    const dim3 vgrid((unsigned)((size_t)va.n_ref * T * (va.acc32 ? 2 : 1)));
     if (va.acc32) {
       if (params->alpha_range_2pi) k_vote<true, true><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
       else k_vote<false, true><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
@@ -1990,6 +2042,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   fa.scene_step = scene_step; fa.ref_offset = params->ref_offset; fa.ref_stride = params->ref_stride; fa.n_ref = n_ref;
   fa.n_tiles = T; fa.tile_refs = m->info.tile_refs; fa.num_angles = m->info.num_angles;
   fa.alpha_2pi = params->alpha_range_2pi != 0;
+  fa.acc32 = va.acc32; fa.edge = ws->half_edge.p;
   fa.partial = ws->partial.p; fa.cellsum = va.cellsum; fa.pairs = va.pairs;
   fa.votes = ws->votes.p; fa.poses = ws->raw_poses.p;
   fa.totals = ws->counters.p + (size_t)n_ref * T + n_ref;
@@ -2657,6 +2710,22 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
         if (!(std::fabs(av) <= 3.1416f)) return bad("record alpha");
       }
     }
+    /* every (tile, bucket) in dealing order (position j = record 32*(j/64) + j%32, slot (j%64)/32): entries of low-half
+     * rows, entries of high-half rows, padding -- what k_bucket_mid and the 32-bit passes of k_vote rely on */
+    const uint32_t first_real = (uint32_t)((GW - A) * 4);
+    for (uint64_t t = 0; t < T; t++)
+      for (uint64_t b = 0; b < nb; b++) {
+        const uint32_t off = boff[t * (nb + 1) + b], cnt = boff[t * (nb + 1) + b + 1] - off;
+        int state = 0; /* 0: low halves, 1: high halves, 2: padding */
+        for (uint32_t j = 0; j < 64u * ((cnt + 31u) / 32u); j++) {
+          const uint32_t r = 32u * (j / 64u) + (j % 32u);
+          if (r >= cnt) continue;
+          const uint32_t code = ((j % 64u) / 32u) ? ent[off + r].y : ent[off + r].x;
+          const int kind = code < first_real ? 2 : (int)(code & 1u);
+          if (kind < state) return bad("record halves (order)");
+          state = kind;
+        }
+      }
   }
   if (check_only) return PPF_OK;
   m->refcount = 1;
@@ -2677,6 +2746,15 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
     else if (I.n_buckets) {
       k_bucket_total<<<dim3((I.n_buckets + 255) / 256), dim3(256)>>>(m->bucket_off.p, (int)I.n_buckets, I.n_tiles, m->bucket_total.p);
       if (hipDeviceSynchronize() != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: bucket totals failed");
+    }
+  }
+  if (s == PPF_OK) {
+    hipError_t e = m->bucket_mid.reserve(std::max<size_t>((size_t)I.n_buckets * I.n_tiles, 1));
+    if (e != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: %s", hipGetErrorString(e));
+    else if (I.n_buckets) {
+      k_bucket_mid<<<dim3((unsigned)(((size_t)I.n_buckets * I.n_tiles + 255) / 256)), dim3(256)>>>(
+          m->bucket_off.p, (int)I.n_buckets, I.n_tiles, m->records.p, (uint32_t)((GW - A) * 4), m->bucket_mid.p);
+      if (hipDeviceSynchronize() != hipSuccess) s = fail(PPF_ERR_HIP, "ppf_model_load: bucket halves failed");
     }
   }
   if (s == PPF_OK) s = build_key_lut(m, nullptr); /* not stored in the file: rebuilt from the slot map */

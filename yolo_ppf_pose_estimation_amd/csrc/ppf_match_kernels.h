@@ -229,6 +229,7 @@ struct MatchArgs {
   uint2* run_blocks;       /* [n_ref][n_rounds] {first run, runs} */
   int n_rounds, round_buckets; /* k_group sorts round_buckets bucket ids per pass over the reference point's hits */
   const uint32_t* bucket_total; /* [n_buckets] entries of a bucket over all tiles */
+  const uint32_t* bucket_mid;   /* [n_tiles][n_buckets] entries of low-half rows = the first dealing positions of the bucket (k_bucket_mid) */
   unsigned long long* work;     /* [n_ref] votes the reference point will cast (sum of its hits' bucket sizes) */
   uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
   const uint32_t* perm_group;   /* [n_ref] reference points ordered by hit count, for k_group */
@@ -239,7 +240,8 @@ struct MatchArgs {
   int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
   int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
-  uint2* partial;               /* [n_ref_all * n_tiles] {max votes, local flat index} */
+  uint2* partial;               /* [n_ref_all * n_tiles * 2] {max votes, local flat index}: slot 2*tile (16-bit cells) or 2*tile + pass (32-bit cells) */
+  uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: spill cell of the last low-half row; pass 1: bin 0 of the first high-half row */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
   unsigned long long* tally;    /* [3] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group */
@@ -1088,7 +1090,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   /* tile-major launch order: the workgroups in flight work on the same accumulator tile, i.e. the same slice of the
    * model table (a 10k-point model: 80 MB of 800 MB), which then stays in L2 / Infinity Cache while the reference
    * points go by (C4: 483 -> 471 ms; C2, whose table fits the cache anyway: no change) */
-  const int tile = blockIdx.x / a.n_ref, slot = blockIdx.x - tile * a.n_ref;
+  /* 32-bit cells (the repeat after an overflow): one workgroup per (reference point, tile, half of the tile's rows), the two
+   * halves launched one after the other, so the workgroups in flight still share one slice of the table */
+  const int vt = blockIdx.x / a.n_ref, slot = blockIdx.x - vt * a.n_ref;
+  const int tile = ACC32 ? vt >> 1 : vt;
   const int r = (int)a.perm[slot]; /* heaviest reference points first */
   const int rg = a.ref_base + r;
   const int tile_base = tile * a.tile_refs;
@@ -1125,8 +1130,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   uint32_t agg_votes = 0;     /* ... plus this lane's one-by-one votes on the count-table path */
   unsigned long long issued = 0; /* votes cast by this wave, wave-uniform: every lane slot of an item casts one vote per hit, into a cell or a guard word */
 
-  for (int pass = 0; pass < (acc32 ? 2 : 1); pass++) {
-  if (pass) __syncthreads(); /* the scan of the first pass is over */
+  const int pass = ACC32 ? (vt & 1) : 0;
   { /* clear guard + cells with 16-byte LDS stores (the region starts 16-byte aligned) */
     uint4* z = reinterpret_cast<uint4*>(lds_acc);
     for (int c = tid; c < words / 4; c += VOTE_BLOCK) z[c] = make_uint4(0u, 0u, 0u, 0u);
@@ -1153,6 +1157,11 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint4 run = a.runs[rb.x + seg0 + tid];
           off = boff[run.x];
           cnt = boff[run.x + 1] - off;
+          if (acc32) { /* this pass counts one half of the tile's rows: only the records that can hold them */
+            const uint32_t n0 = a.bucket_mid[(size_t)tile * a.n_buckets + run.x], blk = 32u * (n0 >> 6), d = n0 & 63u;
+            if (pass == 0) cnt = min(cnt, blk + min(d, 32u));
+            else { const uint32_t skip = min(cnt, blk + (d > 32u ? d - 32u : 0u)); off += skip; cnt -= skip; }
+          }
           hs = run.y;
           mm = run.z;
           if (cnt) {
@@ -1306,7 +1315,6 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   uint32_t bv = 0, bi = 0xFFFFFFFFu;
   unsigned long long sum = 0, found = 0;
   const int row_lo = acc32 ? pass * H : 0, row_hi = acc32 ? min((pass + 1) * H, refs_here) : refs_here;
-  const uint32_t carry_spill = red[49]; /* 32-bit cells, second pass: cell A of row H-1, saved by the first pass */
   for (int ref = row_lo + tid; ref < row_hi; ref += VOTE_BLOCK) {
     const int hf = ref >= H ? 1 : 0;
     const uint32_t* row = acc + (ref - hf * H) * P;
@@ -1315,10 +1323,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     for (int bin = 0; bin < A; bin++) {
       uint32_t v = (row[bin] >> sh) & msk;
       if (bin == 0 && ref > 0) { /* spill cell of the previous row; row H-1 lives in the low halves at the end of the tile */
-        if (ref == H) v += acc32 ? carry_spill : (acc[(H - 1) * P + A] & 0xFFFFu);
+        if (ref == H) v += acc32 ? 0u : (acc[(H - 1) * P + A] & 0xFFFFu); /* 32-bit cells: the other half's workgroup holds it, k_finalize adds it */
         else v += (row[A - P] >> sh) & msk;
       }
-      if (dump) dump[ref * A + bin] = v;
+      if (dump) { if (acc32 && ref == H && bin == 0) atomicAdd(&dump[ref * A + bin], v); else dump[ref * A + bin] = v; }
       sum += v;
       if (v > bv) { bv = v; bi = (uint32_t)(ref * A + bin); }
     }
@@ -1343,7 +1351,11 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     atomicAdd(reinterpret_cast<unsigned long long*>(&red[50]), issued);
     atomicAdd(reinterpret_cast<unsigned long long*>(&red[52]), found);
   }
-  if (acc32 && pass == 0 && tid == 0 && refs_here > H) red[49] = acc[(H - 1) * P + A];
+  if (acc32 && tid == 0) { /* what the two halves owe each other across the row H-1 / row H boundary */
+    const uint32_t e = refs_here > H ? (pass == 0 ? acc[(H - 1) * P + A] : acc[0]) : 0u;
+    a.edge[((size_t)rg * a.n_tiles + tile) * 2 + pass] = e;
+    if (pass == 0) { sum += e; if (dump && e) atomicAdd(&dump[H * A], e); } /* the scan of the high halves leaves this spill out */
+  }
   __syncthreads();
   /* 16-bit cells: a cell that wrapped or carried into its neighbour makes the votes found differ from the votes issued */
   if (!acc32 && tid == 0 && (red[50] != red[52] || red[51] != red[53])) atomicOr(&a.cursors[CUR_OVERFLOW], 8u);
@@ -1355,14 +1367,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       const uint32_t v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
       if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
     }
-    if (lane == 0) {
-      if (pass == 1 && red[54] >= v) { v = red[54]; ix = red[55]; } /* the first pass scanned the rows that come first: it keeps ties */
-      red[54] = v; red[55] = ix;
-      if (pass == (acc32 ? 1 : 0)) a.partial[(size_t)rg * a.n_tiles + tile] = make_uint2(v, ix);
-    }
+    if (lane == 0) a.partial[((size_t)rg * a.n_tiles + tile) * 2 + pass] = make_uint2(v, ix);
   }
   if (lane == 0 && sum) atomicAdd(&a.cellsum[(size_t)rg * a.n_tiles + tile], sum);
-  } /* pass */
 
   unsigned long long wops = (unsigned long long)agg_votes; /* summed over the lanes below; the uniform part is added once */
 #pragma unroll
