@@ -170,6 +170,8 @@ typedef struct ppf_match_stats {
   uint64_t scratch_bytes;  /* device scratch of the call: hit pools, run table, frames */
   int32_t n_batches;       /* batches of reference points the call was cut into */
   int32_t n_retries;       /* repeats because the hit pools (sized from earlier calls) were too small */
+  uint64_t n_acc32_items;  /* (reference point, accumulator tile)s voted with 32-bit cells: those whose 16-bit cells overflowed, or all
+                              of them once a workspace has seen a tenth of a call's votes cast in such ones (or with PPF_OPT_ACC32) */
 } ppf_match_stats;
 
 /* totals of one ppf_batch_run */
@@ -254,8 +256,8 @@ ppf_status ppf_workspace_destroy(ppf_workspace* ws);
 #define PPF_OPT_HIT_FRACTION 1
 #define PPF_OPT_GROUP_ROUND_BUCKETS 2
 #define PPF_OPT_CLUSTER_SERIAL 3 /* != 0: the serial greedy cluster assignment (the path for > 11,520 poses) for any size */
-#define PPF_OPT_ACC32 4          /* != 0: 32-bit accumulator cells from the start (otherwise only after a 16-bit cell overflowed, which
-                                   the vote kernel detects and the call answers by repeating itself once) */
+#define PPF_OPT_ACC32 4          /* != 0: 32-bit accumulator cells for every (reference point, tile) (otherwise 16-bit cells first, and 32-bit
+                                   cells only for those the vote kernel saw overflow) */
 ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);
 /* record HIP events around the kernels of each call (read back through ppf_workspace_results' stats) */
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);

@@ -96,11 +96,12 @@ def test_32_bit_cells_equal_the_oracle(det, crop, oracle_crop, bottle):
             assert res["stats"]["n_votes"] == int(oracle_crop["votes_per_ref"].sum()) and res["stats"]["n_retries"] == 0
 
 
-def test_a_cell_beyond_65535_votes_repeats_the_call_with_32_bit_cells():
+def test_a_cell_beyond_65535_votes_is_voted_again_with_32_bit_cells(bottle):
     """16-bit accumulator cells: 1,000 scene points in one spot seen from the reference point, 200 model points in the same
     spot seen from a model point -> about 200,000 votes for one (model point, alpha bin).  The vote kernel notices that the
-    votes it finds differ from the votes it cast, the call repeats itself once with 32-bit cells, the result is the
-    oracle's; the workspace then stays with 32-bit cells for this model."""
+    votes it finds differ from the votes it cast and flags the (reference point, tile); the 32-bit launch that follows votes
+    it again: the result is the oracle's, without a repeat of the call.  A workspace that sees a tenth of a call's votes
+    cast in overflowing items goes straight to 32-bit cells from the next call on."""
     import torch
     rng = np.random.default_rng(3)
 
@@ -117,12 +118,36 @@ def test_a_cell_beyond_65535_votes_repeats_the_call_with_32_bit_cells():
     assert want["triples"][0][2] > 65535
     ws = Workspace()
     d = torch.from_numpy(scene).cuda()
-    for expected_repeats in (1, 0):
+    for _ in range(2):   # first call: flagged and voted again; second: 32-bit cells from the start (1 of 1 items overflowed)
         ws.match_device(det, d.data_ptr(), scene.shape[0], 6, step, 0.05, presampled=True, skip_clustering=True)
         res = ws.results(scene.shape[0])
         np.testing.assert_array_equal(res["triples"], want["triples"])
         assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
-        assert res["stats"]["n_retries"] == expected_repeats
+        assert res["stats"]["n_retries"] == 0 and res["stats"]["n_acc32_items"] == 1
+
+
+def test_a_few_overflowing_reference_points_do_not_change_the_rest(bottle):
+    """The same spot glued onto an ordinary crop: the reference points inside the spot overflow their 16-bit cells and are
+    voted again with 32-bit cells, the others keep their 16-bit result; all equal the oracle."""
+    import torch
+    rng = np.random.default_rng(4)
+    far = np.array([0.1, 0.02, 0.0]) + rng.uniform(-5e-4, 5e-4, size=(400, 3)) * np.array([1, 1, 0])
+    spot = np.hstack([np.vstack([np.zeros((1, 3)), far]), np.tile([0.0, 0.0, 1.0], (401, 1))]).astype(np.float32)
+    model = np.vstack([spot[:300], synth.make_scene(bottle, n_points=600, seed=2)[0]]).astype(np.float32)
+    scene = np.vstack([spot, synth.make_scene(bottle, n_points=3000, seed=5)[0]]).astype(np.float32)
+    det = PPF3DDetector(0.05, 0.05).trainModel(model, presampled=True)
+    ora = O.OracleDetector(0.05, 0.05).train_model(model, presampled=True)
+    step = 1.0 / 40.0
+    want = ora.match(scene, relative_scene_sample_step=step, presampled=True, cluster=False)
+    n_over = int((want["triples"][:, 2] > 65535).sum())
+    assert 0 < n_over < len(want["triples"]) // 4  # (the votes of these few are most of the call's: the next call would use 32-bit cells)
+    ws = Workspace()
+    d = torch.from_numpy(scene).cuda()
+    ws.match_device(det, d.data_ptr(), scene.shape[0], 6, step, 0.05, presampled=True, skip_clustering=True)
+    res = ws.results(scene.shape[0])
+    np.testing.assert_array_equal(res["triples"], want["triples"])
+    assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+    assert res["stats"]["n_acc32_items"] >= n_over and res["stats"]["n_retries"] == 0
 
 
 def test_several_group_rounds_give_the_same_votes(det, crop, oracle_crop):

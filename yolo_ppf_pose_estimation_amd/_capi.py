@@ -68,7 +68,8 @@ class MatchStats(C.Structure):
                 ("n_poses", C.c_int32), ("n_pairs", C.c_uint64), ("n_votes", C.c_uint64),
                 ("ms_vote_kernel", C.c_float), ("ms_pair_kernel", C.c_float), ("ms_total_device", C.c_float),
                 ("ms_group_kernel", C.c_float), ("n_hits", C.c_uint64), ("n_lds_atomics", C.c_uint64),
-                ("scratch_bytes", C.c_uint64), ("n_batches", C.c_int32), ("n_retries", C.c_int32)]
+                ("scratch_bytes", C.c_uint64), ("n_batches", C.c_int32), ("n_retries", C.c_int32),
+                ("n_acc32_items", C.c_uint64)]
 
 
 class BatchStats(C.Structure):

@@ -547,7 +547,9 @@ struct FinalArgs {
   int scene_step, ref_offset, ref_stride, n_ref;
   int n_tiles, tile_refs, num_angles;
   int alpha_2pi; /* PCL's alpha binning: the winning bin stands for idx * 2pi/A - pi */
-  int acc32;     /* k_vote ran with 32-bit cells: two partial results per tile (one per half of its rows) and the edge values */
+  int acc32;     /* every (reference point, tile) was voted with 32-bit cells: two partial results per tile (one per half of
+                    its rows) and the edge values; otherwise only those flagged in ovf_items */
+  const uint32_t* ovf_items;
   const uint32_t* edge;
   const uint2* partial;
   const unsigned long long* cellsum;
@@ -567,7 +569,7 @@ __global__ void k_finalize(FinalArgs a) {
     const uint2 p = a.partial[slot];
     nv += a.cellsum[(size_t)r * a.n_tiles + t];
     if (p.x > maxVotes) { maxVotes = p.x; flat = (uint32_t)(t * a.tile_refs * a.num_angles) + p.y; }
-    if (a.acc32) { /* the high-half rows come after the low-half rows; bin 0 of their first row still lacks the spill
+    if (a.acc32 || a.ovf_items[(size_t)r * a.n_tiles + t]) { /* the high-half rows come after the low-half rows; bin 0 of their first row still lacks the spill
                       cell of the row before it, which the low halves' workgroup counted */
       uint2 q = a.partial[slot + 1];
       const uint32_t carry = a.edge[slot];
@@ -1240,6 +1242,7 @@ struct ppf_workspace {
   DevBuf<float> staging;
   DevBuf<uint2> partial;
   DevBuf<uint32_t> half_edge; /* see MatchArgs::edge */
+  DevBuf<uint32_t> ovf_items, ovf_list; /* see MatchArgs */
   /* hit scratch of one batch of reference points (see ppf_match_kernels.h) */
   DevBuf<double> frames;
   DevBuf<uint2> raw;                     /* striped pool of {bucket, j} */
@@ -1253,7 +1256,7 @@ struct ppf_workspace {
   DevBuf<unsigned long long> work;
   DevBuf<uint32_t> perm;
   DevBuf<uint32_t> perm_group;
-  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[4] */
+  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[5] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
   DevBuf<ppf_pose> d_final;
@@ -1869,12 +1872,14 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   const int T = m->info.n_tiles;
   HIPCHK(ws->partial.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->half_edge.reserve((size_t)n_ref * T * 2));
-  const size_t n_cnt = (size_t)n_ref * T + n_ref + 6; /* cellsum | pairs | totals[2] | tally[4]: LDS operations, hits, runs, - */
+  HIPCHK(ws->ovf_items.reserve((size_t)n_ref * T));
+  const size_t n_cnt = (size_t)n_ref * T + n_ref + 7; /* cellsum | pairs | totals[2] | tally[5]: LDS operations, hits, runs, 32-bit items, votes cast twice */
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
   HIPCHK(ws->raw_poses.reserve(n_ref));
   if (ws->timing) HIPCHK(hipEventRecord(ws->ev[0], st));
   HIPCHK(hipMemsetAsync(ws->counters.p, 0, n_cnt * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(ws->ovf_items.p, 0, (size_t)n_ref * T * sizeof(uint32_t), st));
 
   MatchArgs va;
   memset(&va, 0, sizeof(va));
@@ -1890,6 +1895,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.angle_step = m->info.angle_step; va.dist_step = m->info.distance_step;
   va.partial = ws->partial.p;
   va.edge = ws->half_edge.p;
+  va.ovf_items = ws->ovf_items.p;
   va.cellsum = ws->counters.p;
   va.pairs = ws->counters.p + (size_t)n_ref * T;
   va.tally = ws->counters.p + (size_t)n_ref * T + n_ref + 2;
@@ -1897,7 +1903,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.bucket_total = m->bucket_total.p;
   va.bucket_mid = m->bucket_mid.p;
   va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
-  va.acc32 = (ws->acc32 || ws->force_acc32) ? 1 : 0;
+  const bool acc32_all = ws->acc32 || ws->force_acc32; /* otherwise: 16-bit cells, then 32-bit cells for the (reference point, tile)s that overflowed */
   const bool darboux = m->params.feature == PPF_FEATURE_DARBOUX;
   va.pair_radius = params->pair_radius;
   va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || params->alpha_range_2pi || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
@@ -1964,6 +1970,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->work.reserve(batch));
   HIPCHK(ws->perm.reserve(batch));
   HIPCHK(ws->perm_group.reserve(batch));
+  HIPCHK(ws->ovf_list.reserve((size_t)batch * T));
+  va.ovf_list = ws->ovf_list.p;
   ws->stats.scratch_bytes = ws->frames.bytes() + ws->raw.bytes() + ws->cursors.bytes() + ws->chunk_desc.bytes() + ws->hit_count.bytes() +
                             ws->s_a64.bytes() + ws->s_cell.bytes() + ws->runs.bytes() + ws->run_blocks.bytes() +
                             ws->work.bytes() + ws->perm.bytes() + ws->perm_group.bytes();
@@ -2025,14 +2033,18 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 2], st));
-    const dim3 vgrid((unsigned)((size_t)va.n_ref * T * (va.acc32 ? 2 : 1)));
-    if (va.acc32) {
-      if (params->alpha_range_2pi) k_vote<true, true><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
-      else k_vote<false, true><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
-    } else {
-      if (params->alpha_range_2pi) k_vote<true, false><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
-      else k_vote<false, false><<<vgrid, dim3(VOTE_BLOCK), lds, st>>>(va);
+    const dim3 grid16((unsigned)((size_t)va.n_ref * T)), grid32((unsigned)((size_t)va.n_ref * T * 2));
+    if (!acc32_all) {
+      va.acc32 = 0;
+      if (params->alpha_range_2pi) k_vote<true, false><<<grid16, dim3(VOTE_BLOCK), lds, st>>>(va);
+      else k_vote<false, false><<<grid16, dim3(VOTE_BLOCK), lds, st>>>(va);
+      HIPCHK(hipGetLastError());
     }
+    va.acc32 = acc32_all ? 1 : 2; /* 2: the (reference point, tile)s the 16-bit launch listed, over a grid that does not depend on their number */
+    const dim3 g32 = acc32_all ? grid32 : dim3(std::min(grid32.x, 1024u));
+    if (params->alpha_range_2pi) k_vote<true, true><<<g32, dim3(VOTE_BLOCK), lds, st>>>(va);
+    else k_vote<false, true><<<g32, dim3(VOTE_BLOCK), lds, st>>>(va);
+    va.acc32 = 0;
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 3], st));
   }
@@ -2042,7 +2054,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   fa.scene_step = scene_step; fa.ref_offset = params->ref_offset; fa.ref_stride = params->ref_stride; fa.n_ref = n_ref;
   fa.n_tiles = T; fa.tile_refs = m->info.tile_refs; fa.num_angles = m->info.num_angles;
   fa.alpha_2pi = params->alpha_range_2pi != 0;
-  fa.acc32 = va.acc32; fa.edge = ws->half_edge.p;
+  fa.acc32 = acc32_all ? 1 : 0; fa.ovf_items = ws->ovf_items.p; fa.edge = ws->half_edge.p;
   fa.partial = ws->partial.p; fa.cellsum = va.cellsum; fa.pairs = va.pairs;
   fa.votes = ws->votes.p; fa.poses = ws->raw_poses.p;
   fa.totals = ws->counters.p + (size_t)n_ref * T + n_ref;
@@ -2071,7 +2083,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
   if (ws->checked || ws->n_ref == 0) { ws->checked = true; return PPF_OK; }
   for (;;) {
     const int T = ws->model->info.n_tiles;
-    unsigned long long tot[5];
+    unsigned long long tot[7];
     uint32_t ovf = 0;
     HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
@@ -2080,6 +2092,10 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->stats.n_pairs = tot[1];
       ws->stats.n_lds_atomics = tot[2];
       ws->stats.n_hits = tot[3];
+      ws->stats.n_acc32_items = tot[5];
+      /* The 16-bit launch is about 12 % cheaper than the 32-bit one, and what it flags is voted twice: a scene that casts more
+       * than a tenth of its votes in (reference point, tile)s that overflow goes straight to 32-bit cells from now on. */
+      if (!ws->acc32 && (double)tot[6] > 0.10 * (double)tot[0]) ws->acc32 = true;
       if (tot[1]) ws->hit_frac = std::min(1.0, std::max(1e-3, 1.06 * (double)tot[3] / (double)tot[1]));
       if (tot[3]) ws->run_frac = std::min(1.0, std::max(0.02, 1.10 * (double)tot[4] / (double)tot[3]));
       ws->frac_known = true;
@@ -2103,9 +2119,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->checked = true;
       return PPF_OK;
     }
-    if ((ovf & 7u) && ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
-    if ((ovf & 8u) && (ws->acc32 || ws->force_acc32)) return fail(PPF_ERR_HIP, "match: accumulator overflow reported with 32-bit cells");
-    if (ovf & 8u) ws->acc32 = true; /* a 16-bit cell overflowed: this scene votes with 32-bit cells from now on */
+    if (ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
     if (ovf & 3u) ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0); /* raw or sorted hit pool */
     if (ovf & 4u) ws->run_frac = std::min(1.0, ws->run_frac * 2.0); /* run table */
     ws->stats.n_retries++;

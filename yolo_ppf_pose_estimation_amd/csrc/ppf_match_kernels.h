@@ -29,8 +29,10 @@
  *              items and table traffic).  A cell that passes 65,535 would carry into its neighbour; every
  *              vote cast lands somewhere in LDS (a cell or a guard word), so the workgroup compares the
  *              sum of what it finds there with the number of votes it issued: any carry makes the two
- *              differ (each carry loses 65,535 or 65,536 from the sum), the workgroup raises a flag and
- *              the host repeats the call with 32-bit cells (each tile in two passes, one per half).
+ *              differ (each carry loses 65,535 or 65,536 from the sum); the workgroup then flags its
+ *              (reference point, tile) and a second launch with 32-bit cells, one workgroup per half of
+ *              the tile's rows, votes the flagged ones again (a scene that flags many of them goes straight
+ *              to 32-bit cells from its next call on).
  *              A run (one bucket, m hits) meets the bucket's entries in one of two ways:
  *                direct      every entry votes once per hit: 1 fma + cvt + fract + address + ds_add_u32
  *                            per vote, entries held in registers while the hits go by;
@@ -97,7 +99,8 @@ constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + c
 constexpr int CUR_STRIDE = 32;
 constexpr int CUR_SORTED = POOL_STRIPES * CUR_STRIDE;
 constexpr int CUR_RUNS = CUR_SORTED + CUR_STRIDE;
-constexpr int CUR_OVERFLOW = CUR_RUNS + CUR_STRIDE; /* bits 1, 2, 4: raw pool, sorted pool, run table too small; 8: a 16-bit accumulator cell overflowed */
+constexpr int CUR_OVFCOUNT = CUR_RUNS + CUR_STRIDE; /* (reference point, tile)s of this batch whose 16-bit cells overflowed: length of ovf_list */
+constexpr int CUR_OVERFLOW = CUR_OVFCOUNT + CUR_STRIDE; /* bits 1, 2, 4: raw pool, sorted pool, run table too small */
 constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
 
 /* per-wave LDS scratch of the aggregated path */
@@ -236,7 +239,10 @@ struct MatchArgs {
   int agg_min_hits;             /* 0: every run votes directly */
   int key_exact;                /* PPF_KEY_EXACT table: keys outside the key table match nothing */
   double pair_radius;           /* > 0: pairs farther apart than this are skipped (not counted) */
-  int acc32;                    /* k_vote: 32-bit cells, every tile in two passes (one per half of its rows); 0: 16-bit cells */
+  int acc32;                    /* k_vote<.., true> (32-bit cells, one workgroup per half of a tile's rows): 1 = every (reference point, tile),
+                                   2 = only those the 16-bit launch flagged in ovf_items */
+  uint32_t* ovf_items;          /* [n_ref_all * n_tiles] != 0: a 16-bit cell of this (reference point, tile) overflowed */
+  uint32_t* ovf_list;           /* [n_ref * n_tiles] the same for this batch as a list: local reference point | tile << 16 (cursors[CUR_OVFCOUNT] entries) */
   int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
   int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
@@ -244,7 +250,7 @@ struct MatchArgs {
   uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: spill cell of the last low-half row; pass 1: bin 0 of the first high-half row */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
-  unsigned long long* tally;    /* [3] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group */
+  unsigned long long* tally;    /* [5] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group; (reference point, tile)s voted with 32-bit cells; votes the 16-bit launch cast for the ones it flagged */
   uint32_t* acc_dump;           /* optional [n_ref_all][n_model*num_angles] full accumulators (debug/tests) */
 };
 
@@ -1090,18 +1096,33 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   /* tile-major launch order: the workgroups in flight work on the same accumulator tile, i.e. the same slice of the
    * model table (a 10k-point model: 80 MB of 800 MB), which then stays in L2 / Infinity Cache while the reference
    * points go by (C4: 483 -> 471 ms; C2, whose table fits the cache anyway: no change) */
-  /* 32-bit cells (the repeat after an overflow): one workgroup per (reference point, tile, half of the tile's rows), the two
-   * halves launched one after the other, so the workgroups in flight still share one slice of the table */
-  const int vt = blockIdx.x / a.n_ref, slot = blockIdx.x - vt * a.n_ref;
-  const int tile = ACC32 ? vt >> 1 : vt;
-  const int r = (int)a.perm[slot]; /* heaviest reference points first */
+  /* 32-bit cells: one unit of work per (reference point, tile, half of the tile's rows), the two halves of a tile one after
+   * the other so that the workgroups in flight still share one slice of the table.  After a 16-bit launch (a.acc32 == 2)
+   * the units are the flagged (reference point, tile)s of ovf_list, shared out over a small fixed grid: a launch with
+   * nothing to repeat costs a few microseconds. */
+  const bool listed = ACC32 && a.acc32 == 2;
+  const uint32_t n_work = listed ? 2u * a.cursors[CUR_OVFCOUNT] : gridDim.x;
+  uint32_t wid = blockIdx.x;
+  if (ACC32 && wid >= n_work) return;
+  do { /* one unit per workgroup except for the listed units of the 32-bit launch */
+  int vt, tile, r;
+  if (listed) {
+    const uint32_t e = a.ovf_list[wid >> 1];
+    r = (int)(e & 0xFFFFu);
+    tile = (int)(e >> 16);
+    vt = 2 * tile + (int)(wid & 1u);
+  } else {
+    vt = (int)(wid / (uint32_t)a.n_ref);
+    tile = ACC32 ? vt >> 1 : vt;
+    r = (int)a.perm[wid - (uint32_t)vt * (uint32_t)a.n_ref]; /* heaviest reference points first */
+  }
   const int rg = a.ref_base + r;
   const int tile_base = tile * a.tile_refs;
   const int refs_here = min(a.tile_refs, a.n_model - tile_base);
   const int H = (a.tile_refs + 1) >> 1;            /* rows per half: row r < H owns the low halves, row r + H the high halves */
   const int words = GW + min(H, refs_here) * P;
   constexpr bool acc32 = ACC32; /* 32-bit cells, two passes per tile: the rare repeat after a 16-bit cell overflowed */
-  if (tid == 0) { red[50] = red[51] = red[52] = red[53] = 0u; } /* votes issued / votes found (64-bit each), see the overflow check */
+  if (tid == 0) { red[50] = red[51] = red[52] = red[53] = red[58] = red[59] = 0u; } /* votes issued / found / counted (64-bit each), see the overflow check */
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
   const uint4* __restrict__ records = a.records;
@@ -1347,18 +1368,14 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   uint32_t* red_i = seg_prefix + VOTE_WAVES;
   __syncthreads();
   if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
-  if (!acc32 && lane == 0) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(&red[50]), issued);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&red[52]), found);
-  }
-  if (acc32 && tid == 0) { /* what the two halves owe each other across the row H-1 / row H boundary */
-    const uint32_t e = refs_here > H ? (pass == 0 ? acc[(H - 1) * P + A] : acc[0]) : 0u;
-    a.edge[((size_t)rg * a.n_tiles + tile) * 2 + pass] = e;
-    if (pass == 0) { sum += e; if (dump && e) atomicAdd(&dump[H * A], e); } /* the scan of the high halves leaves this spill out */
+  if (lane == 0) {
+    if (!acc32) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&red[50]), issued);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&red[52]), found);
+    }
+    if (sum) atomicAdd(reinterpret_cast<unsigned long long*>(&red[58]), sum);
   }
   __syncthreads();
-  /* 16-bit cells: a cell that wrapped or carried into its neighbour makes the votes found differ from the votes issued */
-  if (!acc32 && tid == 0 && (red[50] != red[52] || red[51] != red[53])) atomicOr(&a.cursors[CUR_OVERFLOW], 8u);
   if (wave == 0) {
     uint32_t v = (lane < VOTE_WAVES) ? red_v[lane] : 0u;
     uint32_t ix = (lane < VOTE_WAVES) ? red_i[lane] : 0xFFFFFFFFu;
@@ -1367,15 +1384,39 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       const uint32_t v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
       if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
     }
-    if (lane == 0) a.partial[((size_t)rg * a.n_tiles + tile) * 2 + pass] = make_uint2(v, ix);
+    if (lane == 0) {
+      const size_t item = (size_t)rg * a.n_tiles + tile;
+      unsigned long long total = *reinterpret_cast<unsigned long long*>(&red[58]);
+      /* 16-bit cells: a cell that wrapped or carried into its neighbour makes the votes found differ from the votes issued;
+       * the (reference point, tile) is then voted again with 32-bit cells, and nothing of this attempt counts */
+      const bool overflow = !acc32 && (red[50] != red[52] || red[51] != red[53]);
+      if (overflow) {
+        a.ovf_items[item] = 1u;
+        a.ovf_list[atomicAdd(&a.cursors[CUR_OVFCOUNT], 1u)] = (uint32_t)r | ((uint32_t)tile << 16);
+        atomicAdd(&a.tally[4], *reinterpret_cast<unsigned long long*>(&red[50])); /* work that is done twice */
+        if (dump && refs_here > H) dump[H * A] = 0u; /* the 32-bit launch adds its two parts of this cell */
+      } else {
+        if (acc32) { /* what the two halves owe each other across the row H-1 / row H boundary */
+          const uint32_t e = refs_here > H ? (pass == 0 ? acc[(H - 1) * P + A] : acc[0]) : 0u;
+          a.edge[item * 2 + pass] = e;
+          if (pass == 0) { total += e; if (dump && e) atomicAdd(&dump[H * A], e); } /* the scan of the high halves leaves this spill out */
+          if (pass == 0) atomicAdd(&a.tally[3], 1ull);
+        }
+        a.partial[item * 2 + pass] = make_uint2(v, ix);
+        if (total) atomicAdd(&a.cellsum[item], total);
+      }
+    }
   }
-  if (lane == 0 && sum) atomicAdd(&a.cellsum[(size_t)rg * a.n_tiles + tile], sum);
 
   unsigned long long wops = (unsigned long long)agg_votes; /* summed over the lanes below; the uniform part is added once */
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wops += __shfl_down(wops, o);
   wops += ops;
   if (lane == 0 && wops) atomicAdd(&a.tally[0], wops);
+  if (!ACC32) break;
+  wid += gridDim.x;
+  if (wid < n_work) __syncthreads(); /* the next unit clears the accumulator this one's last readers are done with */
+  } while (wid < n_work);
 }
 
 /* fixed LDS of k_vote: header + run staging + per-wave count tables (the guard and the cells are sized per model) */
