@@ -190,8 +190,10 @@ constexpr float SPILL_ALPHA_MIN = 3.1415f;         /* entries with alpha_m >= th
 /* ============================================================================================ */
 
 /* LDS accumulator geometry (see ppf_match_kernels.h): row pitch in words and guard words below cell 0 */
-__host__ __device__ constexpr int vote_pitch(int A) { return (A + 1) | 1; }
-__host__ __device__ constexpr int vote_guard(int A) { return 64 + 2 * vote_pitch(A); }
+__host__ __device__ constexpr int vote_pitch(int A) { return A; } /* rows follow each other without a gap: bin A of a row (the reference's spill) IS bin 0 of the next row */
+__host__ __device__ constexpr int vote_guard(int A) { return 64 + 2 * ((A + 1) | 1); }
+/* accumulator words of a tile: guard, ceil(tile_refs / 2) word rows, and one word behind them for the spill of each half's last row */
+__host__ __device__ constexpr int vote_lds_words(int tile_refs, int A) { return vote_guard(A) + ((tile_refs + 1) / 2) * vote_pitch(A) + 1; }
 /* A tile of R model rows keeps 16-bit cells, two rows per 32-bit word: row r < H = ceil(R/2) in the low halves, row r + H
  * in the high halves.  A pair record names a row by the byte offset of its bin 0 with the half in bit 0. */
 __host__ __device__ constexpr int vote_half_rows(int tile_refs) { return (tile_refs + 1) / 2; }
@@ -1411,7 +1413,7 @@ int ppf_device_count(void) {
 /* ---- model ------------------------------------------------------------------------------------ */
 /* model reference points whose accumulator rows fit one k_vote workgroup's LDS next to its fixed part */
 static int max_tile_rows(int num_angles) {
-  const long budget = (long)LDS_BYTES - (long)VOTE_LDS_FIXED - 4L * vote_guard(num_angles);
+  const long budget = (long)LDS_BYTES - (long)VOTE_LDS_FIXED - 4L * (vote_guard(num_angles) + 1);
   return budget <= 0 ? 0 : (int)(budget / (4L * vote_pitch(num_angles)));
 }
 
@@ -1982,7 +1984,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.runs = ws->runs.p; va.run_cap = run_cap; va.run_blocks = ws->run_blocks.p;
   va.work = ws->work.p; va.perm = ws->perm.p; va.perm_group = ws->perm_group.p;
 
-  const size_t lds = VOTE_LDS_FIXED + ((size_t)vote_guard(m->info.num_angles) + (size_t)vote_half_rows(m->info.tile_refs) * vote_pitch(m->info.num_angles)) * 4;
+  const size_t lds = VOTE_LDS_FIXED + (size_t)vote_lds_words(m->info.tile_refs, m->info.num_angles) * 4;
   if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
   /* k_group's dynamic LDS: counters, chunk prefix, and as many cached alpha_s as the rest holds */
   const size_t group_fixed = (size_t)((va.round_buckets + 1) & ~1) * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
@@ -2667,7 +2669,7 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
   key_lut_dims(m);
   if (I.slots != table_slots(m)) return bad("slots");
   if (I.num_angles != (int)std::floor(2 * PPF_PI / I.angle_step)) return bad("num_angles");
-  const int A = I.num_angles, P = vote_pitch(A), GW = vote_guard(A);
+  const int A = I.num_angles, GW = vote_guard(A);
   if (I.n_tiles < 1 || I.tile_refs < 1 || (uint64_t)I.n_tiles * I.tile_refs < N || (uint64_t)(I.n_tiles - 1) * I.tile_refs >= N)
     return bad("tiles");
   if (I.tile_refs > 2 * max_tile_rows(A)) return bad("tile does not fit this build's LDS accumulator");
@@ -2714,11 +2716,11 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
   }
   { /* records: LDS byte offsets inside guard + the tile's word rows (a vote adds up to A*4 bytes) with the half of the
      * word in bit 0, finite alphas within (-pi, pi) */
-    const uint32_t limit_words = (uint32_t)(GW + vote_half_rows(I.tile_refs) * P);
+    const uint32_t limit_words = (uint32_t)vote_lds_words(I.tile_refs, A);
     for (uint64_t k = 0; k < ne; k++) {
       const uint32_t rows[2] = {ent[k].x, ent[k].y}, al[2] = {ent[k].z, ent[k].w};
       for (int sl = 0; sl < 2; sl++) {
-        if ((rows[sl] & 2u) || rows[sl] / 4 + (uint32_t)A + 1 > limit_words) return bad("record row");
+        if ((rows[sl] & 2u) || rows[sl] / 4 + (uint32_t)A + 1 > limit_words) return bad("record row"); /* bin A of the last row: the word behind the rows */
         float av;
         memcpy(&av, &al[sl], 4);
         if (!(std::fabs(av) <= 3.1416f)) return bad("record alpha");

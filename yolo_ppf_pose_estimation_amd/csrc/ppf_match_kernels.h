@@ -88,7 +88,7 @@ constexpr int AGG_Q = 32;             /* cells per alpha bin */
 constexpr int AGG_NY = 16;            /* integer parts Y + 8 of a hit */
 constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes; 3 hits per lane) */
 constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in [-8, 7] */
-constexpr int RUN_SEG = 256;          /* runs staged in LDS per segment */
+constexpr int RUN_SEG = 512;          /* runs staged in LDS per segment (every segment costs the workgroup two dependent reads and three barriers: 256 -> 512 is worth 3 % on C2) */
 constexpr int GROUP_BLOCK = 512;       /* two k_group workgroups per CU when the bucket counters fit half the LDS (0.705 -> 0.665 ms on C2) */
 constexpr int GROUP_MLP = 4;            /* hits a k_group thread has in flight per step of its two passes */
 constexpr int GROUP_MAX_BUCKETS = 36000; /* LDS counters of k_group per round (144 KB) */
@@ -247,7 +247,7 @@ struct MatchArgs {
   int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
   uint2* partial;               /* [n_ref_all * n_tiles * 2] {max votes, local flat index}: slot 2*tile (16-bit cells) or 2*tile + pass (32-bit cells) */
-  uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: spill cell of the last low-half row; pass 1: bin 0 of the first high-half row */
+  uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: bin A of the last low-half row; pass 1: bin 0 of the first high-half row */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
   unsigned long long* tally;    /* [5] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group; (reference point, tile)s voted with 32-bit cells; votes the 16-bit launch cast for the ones it flagged */
@@ -631,11 +631,14 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
 }
 
 /*
- * Accumulator layout in LDS (words):  [guard: VOTE_GUARD(P)] [tile_refs x P cells]
- *   P = (A+1)|1 is the row pitch: A alpha bins + the "bin == A" spill cell of the row (the reference
- *   indexes corrI*A + alpha_index without a range check, so alpha_index == A lands on the next model
- *   reference point's bin 0; the spill cell is folded into that bin when the accumulator is scanned).
- *   An odd pitch also spreads rows over all 32 LDS banks.
+ * Accumulator layout in LDS (words):  [guard] [ceil(tile_refs / 2) rows x A cells] [1 word]
+ *   A cell is 16 bits wide: row r < H = ceil(tile_refs / 2) counts in the low halves of its word row, row r + H in the
+ *   high halves of the same words (32-bit cells, the repeat after an overflow: one half of the rows per workgroup).
+ *   Rows follow each other without a gap, so the "bin == A" the reference can produce (it indexes corrI*A + alpha_index
+ *   without a range check: alpha_index == A is the next model reference point's bin 0) lands where the reference
+ *   puts it by itself; only the last low-half row has its successor in the high halves: its bin A is the word behind
+ *   the rows, added to row H's bin 0 when the accumulator is scanned (the same word's high half takes the bin A of
+ *   the tile's last row, which belongs to the next tile: see the mirrored entries of the table).
  *   The guard words below cell 0 take every vote that must not count: mirrored spill entries
  *   (word offset GW-A) with any bin other than A, and the lanes past the end of a bucket (word = lane).
  *   With it the vote needs no range check at all.  Entry offsets are bytes from the guard's start.
@@ -1120,7 +1123,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const int tile_base = tile * a.tile_refs;
   const int refs_here = min(a.tile_refs, a.n_model - tile_base);
   const int H = (a.tile_refs + 1) >> 1;            /* rows per half: row r < H owns the low halves, row r + H the high halves */
-  const int words = GW + min(H, refs_here) * P;
+  const int words = GW + min(H, refs_here) * P + 1; /* + the word that takes bin A of each half's last row */
   constexpr bool acc32 = ACC32; /* 32-bit cells, two passes per tile: the rare repeat after a 16-bit cell overflowed */
   if (tid == 0) { red[50] = red[51] = red[52] = red[53] = red[58] = red[59] = 0u; } /* votes issued / found / counted (64-bit each), see the overflow check */
 
@@ -1328,10 +1331,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   __syncthreads();
 
   /* Scan in the reference's order (model ref ascending, alpha bin ascending, strict >) == smallest
-   * upstream flat index ref*A + bin among the maxima; the spill cell of row ref-1 is folded into
-   * (ref, bin 0) on the way.  Also the exact vote total of the tile.  One thread per accumulator row: consecutive
-   * threads read consecutive rows, pitch P is odd -> no bank conflicts, no integer division; bins ascending with
-   * strict > keeps the row's first maximum.  32-bit cells: this pass holds the rows of half `pass` only. */
+   * upstream flat index ref*A + bin among the maxima.  Also the exact vote total of the tile.  One thread per accumulator
+   * row, no integer division; bins ascending with strict > keeps the row's first maximum.  32-bit cells: this workgroup
+   * holds the rows of half `pass` only. */
   uint32_t* dump = a.acc_dump ? a.acc_dump + (size_t)rg * a.n_model * A + (size_t)tile_base * A : nullptr;
   uint32_t bv = 0, bi = 0xFFFFFFFFu;
   unsigned long long sum = 0, found = 0;
@@ -1343,10 +1345,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     const uint32_t msk = acc32 ? 0xFFFFFFFFu : 0xFFFFu;
     for (int bin = 0; bin < A; bin++) {
       uint32_t v = (row[bin] >> sh) & msk;
-      if (bin == 0 && ref > 0) { /* spill cell of the previous row; row H-1 lives in the low halves at the end of the tile */
-        if (ref == H) v += acc32 ? 0u : (acc[(H - 1) * P + A] & 0xFFFFu); /* 32-bit cells: the other half's workgroup holds it, k_finalize adds it */
-        else v += (row[A - P] >> sh) & msk;
-      }
+      /* a row's bin A (the reference's spill into the next row) is the next row's bin 0 in memory; only the last low-half row
+       * has its successor elsewhere: its bin A is the low half of the word behind the rows (32-bit cells: the other
+       * half's workgroup holds it, k_finalize adds it) */
+      if (bin == 0 && ref == H && !acc32) v += acc[H * P] & 0xFFFFu;
       if (dump) { if (acc32 && ref == H && bin == 0) atomicAdd(&dump[ref * A + bin], v); else dump[ref * A + bin] = v; }
       sum += v;
       if (v > bv) { bv = v; bi = (uint32_t)(ref * A + bin); }
@@ -1397,7 +1399,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         if (dump && refs_here > H) dump[H * A] = 0u; /* the 32-bit launch adds its two parts of this cell */
       } else {
         if (acc32) { /* what the two halves owe each other across the row H-1 / row H boundary */
-          const uint32_t e = refs_here > H ? (pass == 0 ? acc[(H - 1) * P + A] : acc[0]) : 0u;
+          const uint32_t e = refs_here > H ? (pass == 0 ? acc[H * P] : acc[0]) : 0u;
           a.edge[item * 2 + pass] = e;
           if (pass == 0) { total += e; if (dump && e) atomicAdd(&dump[H * A], e); } /* the scan of the high halves leaves this spill out */
           if (pass == 0) atomicAdd(&a.tally[3], 1ull);
