@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--shard", default="crops", choices=["crops", "refs"],
                     help="c4 at N > 1: 'refs' strides the reference points of the one scene over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU baseline: seconds per repetition")
+    ap.add_argument("--cells", choices=["auto", "32"], default="auto",
+                    help="accumulator cells of the vote kernel: auto = 16-bit, 32-bit for what overflows (the library's default); "
+                         "32 = 32-bit from the first call (profiling a workload that always overflows, e.g. c4)")
     ap.add_argument("--pipeline-depth", type=int, default=1,
                     help="crops in flight: 1 (default) = strictly one after another, so the HIP-event kernel times "
                          "behind `roofline` are the kernel's own; 2-3 overlap independent crops on separate streams")
@@ -227,7 +230,7 @@ def main(argv=None):
         else:
             dist.init_process_group(backend=backend)
 
-    from yolo_ppf_pose_estimation_amd import parallel, workloads as W
+    from yolo_ppf_pose_estimation_amd import _capi, parallel, workloads as W
     from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
     from yolo_ppf_pose_estimation_amd.device import BatchMatcher, Workspace
 
@@ -297,6 +300,9 @@ def main(argv=None):
         depth = max(1, min(args.pipeline_depth, max(args.warmup, 1)))
         streams = [torch.cuda.Stream() for _ in range(depth)]
         wss = [Workspace(timing=True) for _ in range(depth)]
+        if args.cells == "32":
+            for w_ in wss:
+                w_.set_option(_capi.PPF_OPT_ACC32, 1)
         n_ref_total = (n_scene + step_stride - 1) // step_stride
         ref_kw = {"ref_offset": rank, "ref_stride": world, "skip_clustering": True} if shard_refs else {}
         n_ref_rank = len(range(rank, n_ref_total, world)) if shard_refs else n_ref_total

@@ -18,9 +18,9 @@ echo "bench lines done"
 echo "2-rank rehearsals done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c2" -o c2 -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$ROOT/$OUT/trace_c2.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c4" -o c4 -- python3 "$ROOT/bench.py" --config c4 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c4.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c4" -o c4 -- python3 "$ROOT/bench.py" --config c4 --cells 32 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c4.log" 2>&1
 echo "traces done"
 cd "$ROOT"
 tools/pmc_vote.sh "$OUT/pmc_c2"
-BENCH_ARGS="--config c4" tools/pmc_vote.sh "$OUT/pmc_c4"
+BENCH_ARGS="--config c4 --cells 32" tools/pmc_vote.sh "$OUT/pmc_c4"   # c4 overflows 16-bit cells: profile its steady state (32-bit cells from the first call)
 echo "pmc done"

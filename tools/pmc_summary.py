@@ -13,12 +13,17 @@ import json
 import sys
 
 
+STEPS_PROFILED = 3  # tools/pmc_vote.sh runs bench.py --steps 2 --warmup 1: three identical steps
+
+
 def load(path):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    """Counters per kernel and STEP (sum over the launches of the run / steps).  The two k_vote instantiations (16-bit cells;
+    32-bit cells: the launch that repeats what overflowed, or everything with --cells 32) are added up as "k_vote"."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()  # "void k_vote<false>(MatchArgs)" -> k_vote
-        agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()  # "void k_vote<false, true>(MatchArgs)" -> k_vote
+        agg[name][row["Counter_Name"]] += float(row["Counter_Value"])
+    return {k: {c: v / STEPS_PROFILED for c, v in d.items()} for k, d in agg.items()}
 
 
 def main():
@@ -32,7 +37,7 @@ def main():
     kv = keep.get("k_vote", {})
     out = {
         "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_vote.sh), python3 bench.py --steps 2 --warmup 1 "
-                  "--no-cpu-baseline, MI355X; per-launch averages",
+                  "--no-cpu-baseline, MI355X; counters are sums over the launches of one step (k_vote: both instantiations)",
         "workload": workload,
         "n_votes_per_launch": n_votes if launches == 1 else None,
         "n_votes_per_step": n_votes,
@@ -43,10 +48,10 @@ def main():
     if "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
         rep = (kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024.0
         cor = (2 * kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024.0
-        out["hbm_bytes_per_launch_k_vote"] = {"as_reported": rep, "gfx950_corrected_2xFETCH": cor,
-                                              "note": "gfx950 read-counter halving: bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md)"}
-        out["hbm_bytes_per_step_k_vote"] = cor * launches
-        out["hbm_gbs_k_vote"] = cor * launches / (kvote_ms * 1e-3) / 1e9
+        out["hbm_bytes_per_step_k_vote_as_reported"] = rep
+        out["hbm_bytes_note"] = "gfx950 read-counter halving: bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md)"
+        out["hbm_bytes_per_step_k_vote"] = cor
+        out["hbm_gbs_k_vote"] = cor / (kvote_ms * 1e-3) / 1e9
     if "SQ_WAVE_CYCLES" in kv:
         simd_quad = kv["SQ_WAVE_CYCLES"] / 4.0  # 4 waves per SIMD resident for the whole launch (16-wave workgroups, 1 per CU)
         out["k_vote_issue"] = {
