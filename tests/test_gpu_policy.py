@@ -134,6 +134,33 @@ def test_all_five_together(bottle, crop):
     _compare(det, ora, crop)
 
 
+def test_policy_switches_with_32_bit_cells(bottle, crop):
+    """The 32-bit instantiations of the vote kernel (the launch that repeats what overflowed 16-bit cells) under the
+    switches that pick another vote kernel or table: 2 pi alpha range (`k_vote<true, true>`), Darboux feature with exact keys,
+    several tiles -- forced through PPF_OPT_ACC32, compared with the oracle."""
+    import torch
+    from yolo_ppf_pose_estimation_amd import _capi
+    from yolo_ppf_pose_estimation_amd.device import Workspace
+    d = torch.from_numpy(crop).cuda()
+    cases = [
+        (PPF3DDetector(0.05, 0.05, max_tile_refs=300).trainModel(bottle).setPolicy(alpha_range_2pi=True),
+         O.OracleDetector(0.05, 0.05).train_model(bottle).set_policy(alpha_2pi=True)),
+        (PPF3DDetector(0.05, 0.05, key_equality=1, feature=1, max_tile_refs=300).trainModel(bottle),
+         O.OracleDetector(0.05, 0.05).train_model(bottle, darboux=True).set_policy(key_exact=True)),
+    ]
+    for det, ora in cases:
+        assert det.info()["n_tiles"] >= 3
+        want = ora.match(crop, relative_scene_sample_step=STEP, presampled=True, cluster=False)
+        for force in (0, 1):
+            ws = Workspace()
+            ws.set_option(_capi.PPF_OPT_ACC32, force)
+            ws.match_device(det, d.data_ptr(), crop.shape[0], 6, STEP, 0.05, presampled=True, skip_clustering=True)
+            res = ws.results(crop.shape[0])
+            np.testing.assert_array_equal(res["triples"], want["triples"])
+            assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+            assert (res["stats"]["n_acc32_items"] > 0) == bool(force)
+
+
 def test_all_four_together(bottle, crop):
     det = PPF3DDetector(0.05, 0.05, key_equality=1).trainModel(bottle)
     radius = 0.5 * det.info()["diameter"]
