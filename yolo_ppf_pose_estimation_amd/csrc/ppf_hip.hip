@@ -299,7 +299,7 @@ __global__ void k_bucket_mid(const uint32_t* __restrict__ bucket_off, int n_buck
     bool low = false;
     if (r < cnt) {
       const uint4 rec = records[off + r];
-      const uint32_t code = ((j % 64u) / 32u) ? rec.y : rec.x;
+      const uint32_t code = (((j % 64u) / 32u) ? rec.y : rec.x) & ROW_CODE_MASK;
       low = code >= first_real && !(code & 1u);
     }
     if (low) lo = j + 1; else hi = j;
@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  * 32 consecutive records.  Unused slots of the last records hold dummies that vote into the LDS guard words.
  */
 
+__device__ uint32_t agg_cell_bits(float am, int A); /* ppf_match_kernels.h */
+
 __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
                                                   uint32_t* cls, uint32_t* lvl) {
   const float q = alpha_m * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
@@ -403,7 +405,7 @@ __device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_b
   }
   uint32_t* rec = reinterpret_cast<uint32_t*>(&records[rec_off[tb] + 32u * (j / 64u) + (j % 32u)]);
   const uint32_t slot = (j % 64u) / 32u;
-  rec[slot] = row_bytes;
+  rec[slot] = row_bytes | agg_cell_bits(am, num_angles);
   rec[2 + slot] = __float_as_uint(am);
 }
 
@@ -481,10 +483,10 @@ __global__ void k_record_counts(const uint32_t* __restrict__ counts, uint32_t* _
 /* every slot starts as a dummy: row = one of the first 64 guard words (never a cell), alpha = 0.0065 (any value whose
  * alpha*A/(4 pi) sits in the middle of a 1/32 cell for the usual A: the count-table path of k_vote then treats it like any
  * other entry instead of taking its on-a-cell-boundary route) */
-__global__ void k_record_init(uint4* __restrict__ records, size_t n) {
+__global__ void k_record_init(uint4* __restrict__ records, size_t n, int num_angles) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const uint32_t w = (uint32_t)(i & 63u) * 4u;
+    const uint32_t w = (uint32_t)(i & 63u) * 4u | agg_cell_bits(0.0065f, num_angles);
     const uint32_t al = __float_as_uint(0.0065f);
     records[i] = make_uint4(w, w, al, al);
   }
@@ -1531,7 +1533,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
                           (size_t)(n_buckets + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   HIPCHK(m->records.reserve(std::max<uint32_t>(n_records, 1)));
   if (n_records) {
-    k_record_init<<<dim3((n_records + 255) / 256), dim3(256), 0, st>>>(m->records.p, n_records);
+    k_record_init<<<dim3((n_records + 255) / 256), dim3(256), 0, st>>>(m->records.p, n_records, m->info.num_angles);
     HIPCHK(hipGetLastError());
   }
   DevBuf<uint32_t> pair_rank;
@@ -1696,7 +1698,7 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
     for (size_t b = 0; b < nb; b++) {
       if (bucket_off) bucket_off[(size_t)t * (nb + 1) + b] = (uint32_t)k;
       for (uint32_t r = roff[(size_t)t * (nb + 1) + b]; r < roff[(size_t)t * (nb + 1) + b + 1]; r++) {
-        const uint32_t rows[2] = {rec[r].x, rec[r].y}, al[2] = {rec[r].z, rec[r].w};
+        const uint32_t rows[2] = {rec[r].x & ROW_CODE_MASK, rec[r].y & ROW_CODE_MASK}, al[2] = {rec[r].z, rec[r].w};
         for (int sl = 0; sl < 2; sl++) {
           if (rows[sl] < first_real) continue;
           if (k >= m->info.n_entries) return fail(PPF_ERR_INVALID, "ppf_model_get_table: more entries than counted");
@@ -2718,9 +2720,11 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
      * word in bit 0, finite alphas within (-pi, pi) */
     const uint32_t limit_words = (uint32_t)vote_lds_words(I.tile_refs, A);
     for (uint64_t k = 0; k < ne; k++) {
-      const uint32_t rows[2] = {ent[k].x, ent[k].y}, al[2] = {ent[k].z, ent[k].w};
+      const uint32_t codes[2] = {ent[k].x, ent[k].y}, al[2] = {ent[k].z, ent[k].w};
       for (int sl = 0; sl < 2; sl++) {
-        if ((rows[sl] & 2u) || rows[sl] / 4 + (uint32_t)A + 1 > limit_words) return bad("record row"); /* bin A of the last row: the word behind the rows */
+        const uint32_t row = codes[sl] & ROW_CODE_MASK, cx = (codes[sl] >> ROW_X_SHIFT) & 31u, cq = (codes[sl] >> ROW_Q_SHIFT) & 63u;
+        if ((row & 2u) || row / 4 + (uint32_t)A + 1 > limit_words) return bad("record row"); /* bin A of the last row: the word behind the rows */
+        if ((codes[sl] >> 29) || cx > (uint32_t)A || cq > (uint32_t)AGG_Q) return bad("record cell");
         float av;
         memcpy(&av, &al[sl], 4);
         if (!(std::fabs(av) <= 3.1416f)) return bad("record alpha");
@@ -2736,7 +2740,7 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
         for (uint32_t j = 0; j < 64u * ((cnt + 31u) / 32u); j++) {
           const uint32_t r = 32u * (j / 64u) + (j % 32u);
           if (r >= cnt) continue;
-          const uint32_t code = ((j % 64u) / 32u) ? ent[off + r].y : ent[off + r].x;
+          const uint32_t code = (((j % 64u) / 32u) ? ent[off + r].y : ent[off + r].x) & ROW_CODE_MASK;
           const int kind = code < first_real ? 2 : (int)(code & 1u);
           if (kind < state) return bad("record halves (order)");
           state = kind;

@@ -784,8 +784,8 @@ __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const VoteInc
   int ka0[U], kb0[U], ka1[U], kb1[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    pa[u] = acc_base + (rec[u].x & ~3u);
-    pb[u] = acc_base + (rec[u].y & ~3u);
+    pa[u] = acc_base + (rec[u].x & ROW_OFFSET_MASK);
+    pb[u] = acc_base + (rec[u].y & ROW_OFFSET_MASK);
     ia[u] = vote_inc(vi, rec[u].x);
     ib[u] = vote_inc(vi, rec[u].y);
     asm volatile("" : "+v"(pa[u]), "+v"(pb[u]), "+v"(ia[u]), "+v"(ib[u])); /* computed once per batch, not rematerialised per vote */
@@ -816,7 +816,7 @@ template <bool WRAP>
 __device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const VoteInc& vi, const uint32_t row_code, const uint32_t alpha_bits,
                                                  const float S, const float ohg_v, const int nh, const double* __restrict__ asd,
                                                  const float G2, const int A) {
-  uint32_t pr = acc_base + (row_code & ~3u), inc = vote_inc(vi, row_code);
+  uint32_t pr = acc_base + (row_code & ROW_OFFSET_MASK), inc = vote_inc(vi, row_code);
   asm volatile("" : "+v"(pr), "+v"(inc));
   const float am = __uint_as_float(alpha_bits);
   uint32_t adr_prev = 0;
@@ -953,15 +953,28 @@ __device__ __forceinline__ void agg_cell(const AggConsts& k, const float am, int
   q = one_by_one ? AGG_Q : min(q, AGG_Q - 1);
 }
 
+/* agg_cell for the table build: the bits a row code carries (zero when numAngles is too fine for count tables) */
+__device__ uint32_t agg_cell_bits(const float am, const int A) {
+  if (A > AGG_MAX_ANGLES) return 0u;
+  AggConsts k;
+  k.s64 = (double)A / (4 * PPF_PI);
+  k.S = (float)k.s64;
+  k.half_a = 0.5f * (float)A;
+  k.half_a64 = 0.5 * (double)A;
+  int X, q;
+  agg_cell(k, am, X, q);
+  return ((uint32_t)X << ROW_X_SHIFT) | ((uint32_t)q << ROW_Q_SHIFT);
+}
+
 /* The two model entries of one pair record against the count table: 17 counted atomics each, then one vote per hit of
  * each entry's own cell (all hits for an entry that votes one by one) with the direct arithmetic -- both entries walk
  * their cells in one loop, so the LDS round trip of a hit's offset is shared.  `votes` counts the one-by-one votes. */
 __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, const double* __restrict__ g_a64, const int ms,
                                          uint32_t& votes) {
   const float am_a = __uint_as_float(rec.z), am_b = __uint_as_float(rec.w);
-  int Xa, qa, Xb, qb;
-  agg_cell(k, am_a, Xa, qa);
-  agg_cell(k, am_b, Xb, qb);
+  /* X and cell of the two entries: evaluated by the table build (agg_cell_bits), carried in the row codes */
+  const int Xa = (int)((rec.x >> ROW_X_SHIFT) & 31u), qa = (int)((rec.x >> ROW_Q_SHIFT) & 63u);
+  const int Xb = (int)((rec.y >> ROW_X_SHIFT) & 31u), qb = (int)((rec.y >> ROW_Q_SHIFT) & 63u);
   const uint32_t ta = k.ws + (uint32_t)qa * AGG_ROW, tb = k.ws + (uint32_t)qb * AGG_ROW;
   const uint2 a01 = lds_ld2(ta), a23 = lds_ld2(ta + 8), a45 = lds_ld2(ta + 16);
   const uint2 b01 = lds_ld2(tb), b23 = lds_ld2(tb + 8), b45 = lds_ld2(tb + 16);
@@ -969,7 +982,7 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   uint2 ca = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qa, AGG_Q - 1) * 4), cb = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qb, AGG_Q - 1) * 4);
   if (qa == AGG_Q) { ca.x = 0u; ca.y = (uint32_t)ms; }
   if (qb == AGG_Q) { cb.x = 0u; cb.y = (uint32_t)ms; }
-  const uint32_t pa = k.acc_base + (rec.x & ~3u), pb = k.acc_base + (rec.y & ~3u);
+  const uint32_t pa = k.acc_base + (rec.x & ROW_OFFSET_MASK), pb = k.acc_base + (rec.y & ROW_OFFSET_MASK);
   const bool ha = (rec.x & 1u) != 0, hb = (rec.y & 1u) != 0;
   const uint32_t inc_a = ha ? k.vi.hi : k.vi.lo, inc_b = hb ? k.vi.hi : k.vi.lo;
   uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
@@ -1251,7 +1264,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             const uint32_t e = e0 + (uint32_t)lane;
             const uint4 rec_nxt = src[min(e + 64, c - 1)]; /* next block's records in flight under this block's votes */
             uint4 rec = rec_cur;
-            if (e >= c) { rec.x = tail_bytes; rec.y = tail_bytes; }
+            if (e >= c) { rec.x = tail_bytes | (rec.x & ~ROW_CODE_MASK); rec.y = tail_bytes | (rec.y & ~ROW_CODE_MASK); } /* the clamped record's cells go with its alphas */
             agg_pair(ak, rec, g_a64, cur.nh, agg_votes);
             rec_cur = rec_nxt;
           }
