@@ -404,6 +404,7 @@ def main(argv=None):
             line["clustered_poses"] = st.get("n_poses", 0)
             line["scratch_bytes"] = st.get("scratch_bytes", None)
             line["batches_per_step"] = st.get("n_batches", None)
+            line["acc32_items_per_step"] = st.get("n_acc32_items", None)  # (reference point, tile)s voted with 32-bit cells (0: all 16-bit)
             avg_vote_s = float(np.mean(vote_ms)) * 1e-3
             line["kernel_ms"] = {"k_pairs": float(np.mean(pair_ms)), "k_group": float(np.mean(group_ms)),
                                  "k_vote": float(np.mean(vote_ms)), "device_total": float(np.mean(dev_ms))}

@@ -83,7 +83,10 @@ constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
 constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded per lane per batch */
 constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * 4; /* pair records per direct work item (1024 = 2048 entries) */
 constexpr int VOTE_MAX_HITS = 16;     /* hits of one run voted per direct work item */
-constexpr int AGG_CHUNK = 2048;       /* pair records per aggregated work item */
+#ifndef PPF_AGG_CHUNK
+#define PPF_AGG_CHUNK 2048
+#endif
+constexpr int AGG_CHUNK = PPF_AGG_CHUNK; /* pair records per aggregated work item (each item builds the count table of its hits) */
 constexpr int AGG_Q = 32;             /* cells per alpha bin */
 constexpr int AGG_NY = 16;            /* integer parts Y + 8 of a hit */
 constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes; 3 hits per lane) */
