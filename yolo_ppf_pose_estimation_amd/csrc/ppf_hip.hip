@@ -882,10 +882,11 @@ __global__ __launch_bounds__(256) void k_clm_matrix(ClusterArgs a, unsigned long
   }
 }
 /* heads[w] = bit mask of the poses that open a cluster, prefix[w] = clusters opened before word w, *n_out = clusters.
- * Rows are staged through LDS in rounds (multiples of 64 rows, odd pitch against bank conflicts).  One wave walks
- * them 64 at a time with ONE ROW PER LANE: each lane ANDs its row with the head words of the earlier groups (known,
- * kept in LDS), then the 64 rows of the group are resolved among themselves on the scalar side: row r opens a
- * cluster iff it matched no earlier head and none of the group's rows before it that opened one. */
+ * Rows are staged through LDS in rounds (multiples of 64 rows, odd pitch against bank conflicts); all waves first AND
+ * every row of the round with the head words of the earlier rounds.  One wave then walks the round 64 rows at a time
+ * with ONE ROW PER LANE: each lane ANDs its row with the head words of the round's earlier groups, then the 64 rows of
+ * the group are resolved among themselves: row r opens a cluster iff it matched no earlier head and none of the group's
+ * rows before it that opened one. */
 __global__ __launch_bounds__(1024) void k_clm_heads(ClusterArgs a, const unsigned long long* __restrict__ bits, int words, int pitch,
                                                     int rows_per_round, unsigned long long* __restrict__ heads, uint32_t* __restrict__ prefix) {
   extern __shared__ unsigned long long clm_lds[]; /* head words [words] | rows [rows_per_round][pitch] */
@@ -903,23 +904,39 @@ __global__ __launch_bounds__(1024) void k_clm_heads(ClusterArgs a, const unsigne
       s_rows[r * pitch + w] = w <= ((s0 + r) >> 6) ? bits[(size_t)(s0 + r) * words + w] : 0ull;
     }
     __syncthreads();
+    /* every row against the heads of the EARLIER ROUNDS (all known): one row per thread, all sixteen waves; the verdict
+     * replaces the row's word 0, which nobody reads again.  What is left for the one wave that walks the groups are the
+     * head words of this round's own groups. */
+    const int W0 = s0 >> 6;
+    if (W0 > 0) {
+      for (int r = tid; r < cnt; r += 1024) {
+        unsigned long long* row = s_rows + r * pitch;
+        bool p = false;
+        for (int w = 0; w < W0; w++) p |= (row[w] & s_heads[w]) != 0ull;
+        row[0] = p ? 1ull : 0ull;
+      }
+      __syncthreads();
+    }
     if (wave == 0) {
       for (int g0 = 0; g0 < cnt; g0 += 64) { /* s0 and g0 are multiples of 64: the group is word G of the mask */
         const int G = (s0 + g0) >> 6;
         const int r = g0 + lane;
         const bool valid = r < cnt;
         const unsigned long long* row = s_rows + (valid ? r : g0) * pitch;
-        bool pre = !valid;
-        for (int w = 0; w < G; w++) pre |= (row[w] & s_heads[w]) != 0ull;
+        bool pre = !valid || (W0 > 0 && row[0] != 0ull);
+        for (int w = W0; w < G; w++) pre |= (row[w] & s_heads[w]) != 0ull;
         const unsigned long long blk = valid ? row[G] : 0ull; /* matches among the rows of this group (lower ones) */
         const unsigned long long taken = __ballot(pre);
-        const uint32_t blo = (uint32_t)blk, bhi = (uint32_t)(blk >> 32);
-        unsigned long long gh = 0ull;
-        for (unsigned long long cand = ~taken; cand; cand &= cand - 1ull) { /* only rows no earlier head took */
-          const int q = __ffsll((long long)cand) - 1;
-          const unsigned long long bq = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)blo, q) |
-                                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)bhi, q) << 32);
-          if ((bq & gh) == 0ull) gh |= 1ull << q;
+        /* the group among itself, all lanes at once: a row still undecided opens a cluster when none of the rows before it
+         * that it matches is a head or still undecided, and is taken when one of them is a head; the lowest undecided row is
+         * always decided, most rounds decide nearly all of them */
+        unsigned long long gh = 0ull, cand = ~taken;
+        while (cand) {
+          const bool und = (cand >> lane) & 1ull;
+          const unsigned long long nh = __ballot(und && (blk & (gh | cand)) == 0ull);
+          const unsigned long long nt = __ballot(und && (blk & gh) != 0ull);
+          gh |= nh;
+          cand &= ~(nh | nt);
         }
         if (lane == 0) s_heads[G] = gh;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
