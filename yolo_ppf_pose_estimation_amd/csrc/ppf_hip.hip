@@ -12,11 +12,13 @@
  *                 in one 16-byte load (the reference indexes 2^k slots by hash % slots and never
  *                 compares keys, so only "which slots are non-empty" has to be kept)
  *   bucket_off    n_tiles x (n_buckets+1) u32 CSR offsets, one CSR per accumulator tile
- *   records       pair records {row_a, row_b, alpha_a, alpha_b}: row = u32 LDS byte offset of the model ref's accumulator
- *                 row (guard + local_ref*pitch)*4, alpha = f32 alpha_m; 8 B per model pair, bank- and phase-interleaved
- *                 (see place_entry); bucket_off counts records
- *   accumulator   LDS, tile_refs x numAngles u32 per workgroup (one workgroup = one scene
- *                 reference point x one tile of model reference points)
+ *   records       pair records {row_a, row_b, alpha_a, alpha_b}: row = u32 code of the model ref's accumulator row (LDS byte
+ *                 offset (guard + word_row*numAngles)*4, the half of the word its 16-bit cells use in bit 0, the entry's
+ *                 count-table X and cell above bit 17: vote_row_code, agg_cell_bits), alpha = f32 alpha_m; 8 B per model
+ *                 pair; per (tile, bucket) low-half rows first, bank- and phase-interleaved inside each half (see
+ *                 place_entry); bucket_off counts records
+ *   accumulator   LDS, ceil(tile_refs/2) x numAngles words of two 16-bit cells per workgroup (one workgroup = one scene
+ *                 reference point x one tile of model reference points; 32-bit cells: one half of the tile's rows)
  *
  * Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
  * No CPU fallback exists: without a HIP device the compute entry points return PPF_ERR_HIP.
