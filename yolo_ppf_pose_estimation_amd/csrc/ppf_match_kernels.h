@@ -447,9 +447,23 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
       if (!(base <= a.sorted_cap && n_raw <= a.sorted_cap - base)) { ok = 0; atomicOr(&a.cursors[CUR_OVERFLOW], 2u); }
     }
     sh[0] = base; sh[1] = ok;
+  }
+  if (wave == 1) { /* prefix of the pieces' hit counts, 64 pieces per step, while thread 0 waits for its atomic (one thread
+                      summing them one by one was a chain of pair_chunks dependent global reads: a sixth of the kernel) */
     uint32_t run = 0;
-    for (int c = 0; c < a.pair_chunks; c++) { cpre[c] = run; run += desc[c].y; }
-    cpre[a.pair_chunks] = run;
+    for (int c0 = 0; c0 < a.pair_chunks; c0 += 64) {
+      const int c = c0 + lane;
+      const uint32_t v = c < a.pair_chunks ? desc[c].y : 0u;
+      uint32_t incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+      }
+      if (c < a.pair_chunks) cpre[c] = run + incl - v;
+      run += __shfl(incl, 63);
+    }
+    if (lane == 0) cpre[a.pair_chunks] = run;
   }
   __syncthreads();
   const uint32_t hit_base = sh[0];
