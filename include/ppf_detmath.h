@@ -123,42 +123,31 @@ PPF_HD double ppf_atan(double x) {
                aT10 = 1.62858201153657823623e-02;
   int32_t hx = ppf_hi(x);
   int32_t ix = hx & 0x7fffffff;
-  double hi = 0.0, lo = 0.0;
-  int id;
   if (ix >= 0x44100000) { /* |x| >= 2^66, inf or NaN */
     if (ppf_isnan(x)) return x + x;
     double v = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
     return (hx > 0) ? v : -v;
   }
-  if (ix < 0x3fdc0000) { /* |x| < 0.4375 */
-    if (ix < 0x3e200000) return x; /* |x| < 2^-29 */
-    id = -1;
-  } else {
-    x = ppf_fabs(x);
-    if (ix < 0x3ff30000) {
-      if (ix < 0x3fe60000) {
-        id = 0; x = (2.0 * x - 1.0) / (2.0 + x);
-        hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17;
-      } else {
-        id = 1; x = (x - 1.0) / (x + 1.0);
-        hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17;
-      }
-    } else {
-      if (ix < 0x40038000) {
-        id = 2; x = (x - 1.5) / (1.0 + 1.5 * x);
-        hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17;
-      } else {
-        id = 3; x = -1.0 / x;
-        hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17;
-      }
-    }
-  }
-  double z = x * x;
+  if (ix < 0x3e200000) return x; /* |x| < 2^-29 */
+  /* The argument reduction of the five ranges, written without branches: every range's numerator and denominator are the
+   * expressions fdlibm evaluates in that range, chosen by selects, followed by ONE division (|x| < 0.4375: x / 1.0 == x).
+   * Same operations on the same operands as the branching form, hence the same bits; on a GPU a wave whose lanes fall
+   * into different ranges no longer walks through four divisions one after the other. */
+  const double ax = ppf_fabs(x);
+  const int r0 = ix < 0x3fdc0000, r1 = ix < 0x3fe60000, r2 = ix < 0x3ff30000, r3 = ix < 0x40038000;
+  const double num = r0 ? x : r1 ? (2.0 * ax - 1.0) : r2 ? (ax - 1.0) : r3 ? (ax - 1.5) : -1.0;
+  const double den = r0 ? 1.0 : r1 ? (2.0 + ax) : r2 ? (ax + 1.0) : r3 ? (1.0 + 1.5 * ax) : ax;
+  const double hi = r0 ? 0.0 : r1 ? 4.63647609000806093515e-01 : r2 ? 7.85398163397448278999e-01
+                    : r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00;
+  const double lo = r0 ? 0.0 : r1 ? 2.26987774529616870924e-17 : r2 ? 3.06161699786838301793e-17
+                    : r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17;
+  const double t = num / den;
+  double z = t * t;
   double w = z * z;
   double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
   double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-  if (id < 0) return x - x * (s1 + s2);
-  z = hi - ((x * (s1 + s2) - lo) - x);
+  if (r0) return t - t * (s1 + s2);
+  z = hi - ((t * (s1 + s2) - lo) - t);
   return (hx < 0) ? -z : z;
 }
 
