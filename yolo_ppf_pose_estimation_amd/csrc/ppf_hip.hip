@@ -350,26 +350,32 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  * The entries of a (tile, bucket) are stored as PAIR RECORDS {row_a, row_b, alpha_a, alpha_b} (16 B): a lane of
  * k_vote loads one record (global_load_dwordx4), computes both alpha bins with one v_pk_fma_f32 and casts two
  * LDS atomics.  One ds_add_u32 wave-instruction therefore covers the a-slots (or the b-slots) of 64 consecutive
- * records, i.e. two groups of 32 as far as LDS banking is concerned.  Entries are first put in a DEALING ORDER
- * in which 32 consecutive entries hit 32 different LDS banks for (almost) every alpha_s:
- *   - bank class  c = (row_word + bin0(alpha_m)) mod 32: the bank of the vote when alpha_s == 0; for another
- *     alpha_s all bins shift together, up to one bin of jitter decided by where alpha_m sits inside its bin;
+ * records; the LDS pipe takes them in groups of 16 lanes and serialises the lanes of a group that meet in one of its 64
+ * banks (profiles/r02_ubench_lds_ops.txt).  Entries are therefore put in a DEALING ORDER in which 16 consecutive entries
+ * hit (almost always) 16 different banks:
+ *   - bank  c = (row_word + bin0(alpha_m)) mod 64: the bank of the vote when alpha_s == 0, and of the counted adds of
+ *     the count-table path up to a constant; for another alpha_s all bins shift together, up to one bin of jitter
+ *     decided by where alpha_m sits inside its bin;
  *   - level lv = the half of the accumulator words the entry's row owns (vote_row_code): the rows of the low halves are
  *     dealt first, so the records of a (tile, bucket) are those of its low-half rows, at most 32 mixed records, those of
- *     its high-half rows -- the repeat of a call with 32-bit cells walks only its half's share (k_bucket_mid);
- *   - order = (level, round k = rank of the entry by phase inside its (level, class), class): round k of a level holds
- *     one entry of every class that still has one, entries of similar phase jitter together.
+ *     its high-half rows -- the launch with 32-bit cells walks only its half's share (k_bucket_mid);
+ *   - inside a level the k-th entry (by phase) of a bank that holds n of them gets the key (k + 1/2) / n, and the
+ *     entries are dealt in key order: every bank's entries are spread evenly over the level, a bank with many
+ *     entries (a model row that owns much of the bucket) as well as one with few -- dealing the banks round robin
+ *     left the tail of a level to the few heavy banks (1.32 serialised passes per 16 counted adds on the headline
+ *     table, against 1.09 now; direct votes with their jitter 1.58 -> 1.31).
  * Dealing position j -> record 32*(j/64) + j%32, slot (j%64)/32: 32 consecutive dealing positions share a slot of
- * 32 consecutive records.  Unused slots of the last records hold dummies that vote into the LDS guard words.
+ * 32 consecutive records (lanes 16g .. 16g+15 of a wave-instruction are 16 consecutive dealing positions).  Unused slots of the last records hold dummies that vote into the LDS guard words.
  */
 
 __device__ uint32_t agg_cell_bits(float am, int A); /* ppf_match_kernels.h */
+constexpr uint32_t DEAL_BANKS = 64; /* LDS banks the dealing order spreads a bucket's entries over */
 
 __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
                                                   uint32_t* cls, uint32_t* lvl) {
   const float q = alpha_m * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
   const float fl = floorf(q);
-  *cls = (row_bytes / 4u + (uint32_t)(int)fl) & 31u;
+  *cls = (row_bytes / 4u + (uint32_t)(int)fl) & (DEAL_BANKS - 1u);
   *lvl = levels > 1 ? (row_bytes & 1u) : 0u; /* the half of the accumulator word the entry's row owns: low-half rows are dealt first */
 }
 
@@ -377,34 +383,25 @@ __host__ __device__ __forceinline__ uint32_t records_for(uint32_t n_entries) {
   return 32u * (n_entries / 64u) + min(32u, n_entries % 64u);
 }
 
-/* phase 0: count; phase 1: place (rec_off = record offset of the (tile, bucket)) */
-/* rank_mode 0: k = arrival order inside the (level, class) (atomic cursor); 1: k = `rank` (the entry's rank by phase
- * inside its class, from a sort); 2: k counted down from the top of the class (the few mirrored spill entries, which
- * are not part of the sort) */
+/* phase 0: count; phase 1: place (rec_off = record offset of the (tile, bucket)).
+ * pos = the entry's dealing position inside its level (k_train_spread + sorts); mirror: one of the few mirrored spill
+ * entries, which are not part of the sorts: they take the last positions of the low-half level */
 __device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_bytes, float am, int num_angles, int levels,
                                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
                                             uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
-                                            uint4* __restrict__ records, int rank_mode = 0, uint32_t rank = 0) {
+                                            uint4* __restrict__ records, bool mirror, uint32_t pos) {
   uint32_t c, lv;
   entry_class_level(row_bytes, am, num_angles, levels, &c, &lv);
-  const size_t cbase = tb * (size_t)levels * 32;
+  const size_t cbase = tb * (size_t)levels * DEAL_BANKS;
   if (phase == 0) {
     atomicAdd(&counts[tb], 1u);
-    atomicAdd(&class_cnt[cbase + lv * 32 + c], 1u);
+    atomicAdd(&class_cnt[cbase + lv * DEAL_BANKS + c], 1u);
     return;
   }
-  uint32_t k;
-  if (rank_mode == 1) k = rank;
-  else if (rank_mode == 2) k = class_cnt[cbase + lv * 32 + c] - 1u - atomicAdd(&class_cur[cbase + lv * 32 + c], 1u);
-  else k = atomicAdd(&class_cur[cbase + lv * 32 + c], 1u);
-  uint32_t j = 0;
-  for (uint32_t l = 0; l < lv; l++)
-    for (uint32_t cc = 0; cc < 32; cc++) j += class_cnt[cbase + l * 32 + cc];
-#pragma unroll 8
-  for (uint32_t cc = 0; cc < 32; cc++) {
-    const uint32_t n = class_cnt[cbase + lv * 32 + cc];
-    j += min(n, k) + ((cc < c && n > k) ? 1u : 0u);
-  }
+  uint32_t n0 = 0; /* entries of the low-half level */
+  if (lv || mirror)
+    for (uint32_t cc = 0; cc < DEAL_BANKS; cc++) n0 += class_cnt[cbase + cc];
+  const uint32_t j = mirror ? n0 - 1u - atomicAdd(&class_cur[cbase], 1u) : (lv ? n0 : 0u) + pos;
   uint32_t* rec = reinterpret_cast<uint32_t*>(&records[rec_off[tb] + 32u * (j / 64u) + (j % 32u)]);
   const uint32_t slot = (j % 64u) / 32u;
   rec[slot] = row_bytes | agg_cell_bits(am, num_angles);
@@ -428,15 +425,15 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
   const float am = pair_alpha[idx];
   if (phase == 0 && bucket_slot) bucket_slot[b] = slot;
   place_entry(phase, (size_t)tile * n_buckets + b, vote_row_code(i - tile * tile_refs, tile_refs, num_angles), am, num_angles,
-              levels, counts, rec_off, class_cnt, class_cur, records, pair_rank ? 1 : 0, pair_rank ? pair_rank[idx] : 0u);
+              levels, counts, rec_off, class_cnt, class_cur, records, false, pair_rank ? pair_rank[idx] : 0u);
   /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
    * that point lives in the next tile, the entry is mirrored there: bin A -> cell 0, others -> guard. */
   if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1)
     place_entry(phase, (size_t)(tile + 1) * n_buckets + b, (uint32_t)((vote_guard(num_angles) - num_angles) * 4), am,
-                num_angles, levels, counts, rec_off, class_cnt, class_cur, records, pair_rank ? 2 : 0, 0u);
+                num_angles, levels, counts, rec_off, class_cnt, class_cur, records, true, 0u);
 }
 
-/* sort keys of the model pairs for the dealing order: key_class = ((tile*n_buckets + bucket)*2 + level)*32 + bank class (invalid pairs:
+/* sort keys of the model pairs for the dealing order: key_class = ((tile*n_buckets + bucket)*2 + level)*64 + bank (invalid pairs:
  * `invalid`), key_phase = position of alpha_m inside its bin, 16 bits */
 __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
                                                     const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int num_angles,
@@ -456,8 +453,23 @@ __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__
   uint32_t c, lv;
   entry_class_level(row_bytes, am, num_angles, 2, &c, &lv);
   const float q = am * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
-  key_class[idx] = (uint32_t)((((size_t)tile * n_buckets + b) * 2 + lv) * 32 + c);
+  key_class[idx] = (uint32_t)((((size_t)tile * n_buckets + b) * 2 + lv) * DEAL_BANKS + c);
   key_phase[idx] = min((uint32_t)((q - floorf(q)) * 65536.0f), 65535u);
+}
+/* second stage of the dealing order: key_frac = (k + 1/2) / n as a 32-bit fraction, k = the pair's rank by phase inside its
+ * (tile, bucket, level, bank) and n that group's size; key_seg = (tile*n_buckets + bucket)*2 + level */
+__global__ __launch_bounds__(256) void k_train_spread(const uint32_t* __restrict__ key_class, const uint32_t* __restrict__ pair_rank,
+                                                      const uint32_t* __restrict__ class_cnt, uint32_t invalid, size_t n,
+                                                      uint32_t* __restrict__ key_frac, uint32_t* __restrict__ key_seg,
+                                                      uint32_t* __restrict__ vals) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  vals[idx] = (uint32_t)idx;
+  const uint32_t kc = key_class[idx];
+  if (kc == invalid) { key_frac[idx] = 0u; key_seg[idx] = invalid / DEAL_BANKS; return; }
+  const uint32_t nb = class_cnt[kc]; /* >= rank + 1 */
+  key_frac[idx] = (uint32_t)((((unsigned long long)(2u * pair_rank[idx] + 1u)) << 31) / nb);
+  key_seg[idx] = kc / DEAL_BANKS;
 }
 __global__ __launch_bounds__(256) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, size_t n,
                                                     uint32_t* __restrict__ dst) {
@@ -1512,12 +1524,10 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(offsets.reserve(ncnt));
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
-  /* Dealing order inside a bucket: two levels (the accumulator-word half of the entry's row), and an entry's round is its RANK BY PHASE inside its bank class
-   * (the position of alpha_m inside its bin), so a round holds entries of similar phase from every class: they take
-   * the one-bin jitter together, and the classes are as full, hence as balanced, as they can be. */
-  const bool sorted_deal = true;
+  /* Dealing order inside a bucket (see "table layout" above): two levels (the accumulator-word half of the entry's row),
+   * inside a level every bank's entries in phase order, spread evenly over the level. */
   const int levels = 2;
-  const size_t ncls = ncnt * (size_t)levels * 32;
+  const size_t ncls = ncnt * (size_t)levels * DEAL_BANKS;
   DevBuf<uint32_t> class_cnt, class_cur;
   HIPCHK(class_cnt.reserve(ncls));
   HIPCHK(class_cur.reserve(ncls));
@@ -1555,33 +1565,55 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
     k_record_init<<<dim3((n_records + 255) / 256), dim3(256), 0, st>>>(m->records.p, n_records, m->info.num_angles);
     HIPCHK(hipGetLastError());
   }
-  DevBuf<uint32_t> pair_rank;
-  if (sorted_deal) { /* rank of every pair by phase inside its (tile, bucket, class): two stable sorts */
-    DevBuf<uint32_t> kcls, kph, v1, kt, v2, starts;
+  DevBuf<uint32_t> pair_pos; /* dealing position of every pair inside its (tile, bucket, level) */
+  {
+    DevBuf<uint32_t> kcls, kph, v1, kt, v2, starts, pair_rank;
     HIPCHK(kcls.reserve(NN)); HIPCHK(kph.reserve(NN)); HIPCHK(v1.reserve(NN)); HIPCHK(kt.reserve(NN)); HIPCHK(v2.reserve(NN));
-    HIPCHK(pair_rank.reserve(NN));
-    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 64);
+    HIPCHK(pair_rank.reserve(NN)); HIPCHK(pair_pos.reserve(NN));
+    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 2 * DEAL_BANKS);
     k_train_keys<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets, m->info.tile_refs,
                                                    m->info.num_angles, invalid, kcls.p, kph.p, v1.p);
     HIPCHK(hipGetLastError());
+    /* (1) rank of every pair by phase inside its (tile, bucket, level, bank): two stable sorts (phase, then group) */
     uint32_t* va = nullptr;
     uint32_t n_runs = 0;
     s = sort_segments(kph, v1, kt, v2, (int)NN, 65535ull, starts, &va, &n_runs, st);
     if (s != PPF_OK) return s;
-    k_gather_u32<<<dim3(nblk), dim3(256), 0, st>>>(kcls.p, va, NN, kph.p); /* class keys in phase order */
+    k_gather_u32<<<dim3(nblk), dim3(256), 0, st>>>(kcls.p, va, NN, kph.p); /* group keys in phase order */
     HIPCHK(hipGetLastError());
-    DevBuf<uint32_t>& vin = va == v1.p ? v1 : v2;
-    DevBuf<uint32_t>& vtmp = va == v1.p ? v2 : v1;
-    s = sort_segments(kph, vin, kt, vtmp, (int)NN, (unsigned long long)invalid, starts, &va, &n_runs, st);
-    if (s != PPF_OK) return s;
+    {
+      DevBuf<uint32_t>& vin = va == v1.p ? v1 : v2;
+      DevBuf<uint32_t>& vtmp = va == v1.p ? v2 : v1;
+      s = sort_segments(kph, vin, kt, vtmp, (int)NN, (unsigned long long)invalid, starts, &va, &n_runs, st);
+      if (s != PPF_OK) return s;
+    }
     k_train_ranks<<<dim3(nblk), dim3(256), 0, st>>>(va, starts.p, n_runs, NN, pair_rank.p);
     HIPCHK(hipGetLastError());
+    /* (2) position inside the level: the banks' entries spread evenly, i.e. sorted by (rank + 1/2) / bank size; ties keep
+     * the pair order (stable sorts from the identity) */
+    k_train_spread<<<dim3(nblk), dim3(256), 0, st>>>(kcls.p, pair_rank.p, class_cnt.p, invalid, NN, kph.p, kt.p, v1.p);
+    HIPCHK(hipGetLastError());
+    {
+      DevBuf<uint32_t> kseg;
+      HIPCHK(kseg.reserve(NN));
+      HIPCHK(hipMemcpyAsync(kseg.p, kt.p, NN * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      s = sort_segments(kph, v1, kt, v2, (int)NN, 0xFFFFFFFFull, starts, &va, &n_runs, st);
+      if (s != PPF_OK) return s;
+      k_gather_u32<<<dim3(nblk), dim3(256), 0, st>>>(kseg.p, va, NN, kph.p); /* level keys in fraction order */
+      HIPCHK(hipGetLastError());
+      DevBuf<uint32_t>& vin = va == v1.p ? v1 : v2;
+      DevBuf<uint32_t>& vtmp = va == v1.p ? v2 : v1;
+      s = sort_segments(kph, vin, kt, vtmp, (int)NN, (unsigned long long)(invalid / DEAL_BANKS), starts, &va, &n_runs, st);
+      if (s != PPF_OK) return s;
+      k_train_ranks<<<dim3(nblk), dim3(256), 0, st>>>(va, starts.p, n_runs, NN, pair_pos.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(st));
+    }
     HIPCHK(hipStreamSynchronize(st)); /* the sort scratch dies here */
   }
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
                                                 m->info.tile_refs, T, m->info.num_angles, levels, counts.p, offsets.p,
-                                                class_cnt.p, class_cur.p, m->records.p, nullptr, 1,
-                                                sorted_deal ? pair_rank.p : nullptr);
+                                                class_cnt.p, class_cur.p, m->records.p, nullptr, 1, pair_pos.p);
   HIPCHK(hipGetLastError());
   HIPCHK(m->bucket_total.reserve(std::max<uint32_t>(n_buckets, 1)));
   if (n_buckets) {
