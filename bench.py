@@ -437,15 +437,15 @@ def main(argv=None):
                 "lds_wave_instr_peak_per_s": lds_instr_peak,
                 "frac_of_lds_instr_peak": issue["lds_wave_instructions_sampled"] / avg_vote_s / lds_instr_peak,
                 "lds_bank_conflict_frac_of_lds_cycles": issue["lds_bank_conflict_frac_of_lds_cycles"],
-                "frac_of_lds_instr_peak_conflicts_counted": issue["lds_wave_instructions_sampled"] / avg_vote_s / lds_instr_peak
-                                                            / max(1e-9, 1.0 - issue["lds_bank_conflict_frac_of_lds_cycles"]),
                 "valu_wave_instr_per_s": issue["valu_wave_instructions_sampled"] / avg_vote_s,
                 "valu_wave_instr_peak_per_s": 1024 * 2.4e9 / 4.45,
                 "frac_of_valu_issue_peak": issue["valu_wave_instructions_sampled"] / avg_vote_s / (1024 * 2.4e9 / 4.45),
-                "note": "k_vote is bound by the LDS pipe: SQ_INSTS_LDS of one step / k_vote time against one 64-lane LDS "
-                        "wave-instruction per 4.38 cycles per CU (the ds_add_u32 rate of profiles/r01_ubench_valu_lds.txt); the "
-                        "second fraction divides by the share of LDS cycles that are not bank conflicts.  VALU: SQ_INSTS_VALU "
-                        "against 1024 SIMDs x 2.4 GHz / 4.45 cycles; busy fractions = SQ_ACTIVE_INST_* / (SQ_WAVE_CYCLES / 4)",
+                "note": "SQ_INSTS_LDS of one step / k_vote time against one 64-lane LDS wave-instruction per 4.38 cycles per CU "
+                        "(conflict-free ds_add_u32, profiles/r01_ubench_valu_lds.txt; with scattered addresses an atomic or a "
+                        "read costs the pipe about 7 cycles, profiles/r02_ubench_lds_ops.txt, so the kernel's mix sits closer to "
+                        "the pipe's limit than this fraction says; lds_bank_conflict_frac_of_lds_cycles = SQ_LDS_BANK_CONFLICT / "
+                        "SQ_LDS_IDX_ACTIVE).  VALU: SQ_INSTS_VALU against 1024 SIMDs x 2.4 GHz / 4.45 cycles; busy fractions = "
+                        "SQ_ACTIVE_INST_* / (SQ_WAVE_CYCLES / 4)",
             }
             atom = tally["atomics"] / args.steps if tally["atomics"] else None
             line["lds_roofline"] = {

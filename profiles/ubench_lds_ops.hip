@@ -35,6 +35,9 @@ template <int OP> __global__ __launch_bounds__(1024) void k(uint32_t* out, int i
     else if (OP == 16) w = ((mix((uint32_t)(lane & 31) * 7919u + (uint32_t)u) * 0u + (((uint32_t)lane * 13u + (uint32_t)u * 5u) & 31u)) + 32u * (hu % 500u)); // distinct mod 32 inside each half-wave, random otherwise
     else if (OP == 17) w = ((((uint32_t)lane * 13u + (uint32_t)u * 5u) & 63u) + 64u * (hu % 250u));                             // distinct mod 64 over the wave, random otherwise
     else if (OP == 18) w = ((((uint32_t)lane * 5u + (uint32_t)u * 3u) & 15u) + 16u * (hu % 1000u));                             // distinct mod 16 inside each group of 16 lanes
+    else if (OP == 19) w = (((uint32_t)lane & 15u) + 64u * (((uint32_t)lane >> 4) + 4u * (uint32_t)u + 32u * (hu % 7u)));   // distinct banks inside each 16 lanes, the same 16 banks in all four groups
+    else if (OP == 20) w = (((uint32_t)lane & 31u) + 64u * (((uint32_t)lane >> 5) + 2u * (uint32_t)u + 16u * (hu % 13u)));  // distinct inside each 32 lanes, the same 32 banks in both halves
+    else if (OP == 21) w = ((((uint32_t)lane & 15u) * 4u + ((uint32_t)lane >> 4)) + 64u * ((uint32_t)u + 8u * (hu % 29u)));   // all 64 lanes distinct banks, lanes l and l+16 in neighbouring banks
     else w = 0;
     base[u] = w;
   }
@@ -45,7 +48,7 @@ template <int OP> __global__ __launch_bounds__(1024) void k(uint32_t* out, int i
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       uint32_t* p = acc + adr[u];
-      if (OP == 0 || OP == 6 || OP == 7 || OP == 8 || OP == 16 || OP == 17 || OP == 18) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (OP == 0 || OP == 6 || OP == 7 || OP == 8 || OP == 16 || OP == 17 || OP == 18 || OP == 19 || OP == 20 || OP == 21) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (OP == 9 || OP == 12) __hip_atomic_fetch_add(p, 1u << (16u * ((h >> (u + 3)) & 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (OP == 1) { if (lane < 16) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       if (OP == 2) { if ((lane & 3) == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -72,11 +75,12 @@ int main() {
   const char* names[] = {"ds_add_u32 conflict-free", "ds_add_u32 lanes 0..15 only", "ds_add_u32 every 4th lane", "ds_add_u64 conflict-free", "ds_read_b32", "ds_read_b64",
                          "ds_add_u32 random words", "ds_add_u32 vote-like pitch 31", "ds_add_u32 vote-like pitch 32", "ds_add_u32 packed-half rows pitch 16",
                          "ds_add_rtn_u32 conflict-free", "ds_write_b32", "ds_add_u32 packed-half rows pitch 17", "ds_add_u64 vote-like pitch 32", "ds_add_u64 random 8-byte slots", "ds_read_b32 random words",
-                         "ds_add_u32 banks distinct mod 32 per half-wave", "ds_add_u32 banks distinct mod 64 per wave", "ds_add_u32 banks distinct mod 16 per 16 lanes"};
-  float t[19];
+                         "ds_add_u32 banks distinct mod 32 per half-wave", "ds_add_u32 banks distinct mod 64 per wave", "ds_add_u32 banks distinct mod 16 per 16 lanes",
+                         "ds_add_u32 16 banks, distinct inside each 16 lanes, shared by the 4 groups", "ds_add_u32 32 banks, distinct inside each 32 lanes, shared by the halves", "ds_add_u32 64 distinct banks, interleaved groups"};
+  float t[22];
   t[0] = run<0>(d, iters); t[1] = run<1>(d, iters); t[2] = run<2>(d, iters); t[3] = run<3>(d, iters); t[4] = run<4>(d, iters); t[5] = run<5>(d, iters); t[6] = run<6>(d, iters);
-  t[7] = run<7>(d, iters); t[8] = run<8>(d, iters); t[9] = run<9>(d, iters); t[10] = run<10>(d, iters); t[11] = run<11>(d, iters); t[12] = run<12>(d, iters); t[13] = run<13>(d, iters); t[14] = run<14>(d, iters); t[15] = run<15>(d, iters); t[16] = run<16>(d, iters); t[17] = run<17>(d, iters); t[18] = run<18>(d, iters);
+  t[7] = run<7>(d, iters); t[8] = run<8>(d, iters); t[9] = run<9>(d, iters); t[10] = run<10>(d, iters); t[11] = run<11>(d, iters); t[12] = run<12>(d, iters); t[13] = run<13>(d, iters); t[14] = run<14>(d, iters); t[15] = run<15>(d, iters); t[16] = run<16>(d, iters); t[17] = run<17>(d, iters); t[18] = run<18>(d, iters); t[19] = run<19>(d, iters); t[20] = run<20>(d, iters); t[21] = run<21>(d, iters);
   // one workgroup of 16 waves per CU: wave-instructions per CU = iters * 8 * 16
-  for (int i = 0; i < 19; i++) printf("%-40s %8.3f ms  -> %6.2f cycles per wave-instruction per CU\n", names[i], t[i], t[i] * 1e-3 * 2.4e9 / ((double)iters * 8 * 16));
+  for (int i = 0; i < 22; i++) printf("%-40s %8.3f ms  -> %6.2f cycles per wave-instruction per CU\n", names[i], t[i], t[i] * 1e-3 * 2.4e9 / ((double)iters * 8 * 16));
   return 0;
 }
