@@ -1,6 +1,7 @@
 """Seeded random sweep of the hot path against the oracle: 24 configurations drawn over model shape and sampling
 step, alpha resolution, distance-step rule, scene size / sampling / reference stride, presampled or not, surface or
-surface-to-boundary matching, clustering thresholds, forced accumulator tiling.  Every one must give bit-exact vote
+surface-to-boundary matching, clustering thresholds, forced accumulator tiling, and for every third draw the vote kernel's
+32-bit-cell instantiation as well.  Every one must give bit-exact vote
 triples, vote and pair totals, bit-identical raw poses and the oracle's clustered poses (the bar of
 tests/test_gpu_parity.py)."""
 import numpy as np
@@ -63,6 +64,20 @@ def test_random_configuration(bottle, seed):
     assert got["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum()), cfg
     for g, w in zip(got["raw_poses"], want["raw_poses"]):
         assert np.array_equal(g.pose, w["pose"]), cfg
+    if seed % 3 == 0:  # the 32-bit instantiation of the vote kernel on the same draw (device-resident entry, forced)
+        import torch
+        from yolo_ppf_pose_estimation_amd import _capi
+        from yolo_ppf_pose_estimation_amd.device import Workspace
+        ws = Workspace()
+        ws.set_option(_capi.PPF_OPT_ACC32, 1)
+        d_scene = torch.from_numpy(np.ascontiguousarray(scene, dtype=np.float32)).cuda()
+        d_edge = torch.from_numpy(np.ascontiguousarray(edge, dtype=np.float32)).cuda() if edge is not None else None
+        ws.match_device(det, d_scene.data_ptr(), scene.shape[0], 6, cfg["ref_step"], cfg["scene_dist"], presampled=cfg["presampled"],
+                        d_edge_ptr=d_edge.data_ptr() if d_edge is not None else None, ne=0 if edge is None else edge.shape[0],
+                        skip_clustering=True)
+        res = ws.results(max(scene.shape[0], 1))
+        np.testing.assert_array_equal(res["triples"], want["triples"], err_msg="32-bit cells " + str(cfg))
+        assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum()) and res["stats"]["n_acc32_items"] > 0, cfg
     poses = det.match(scene, cfg["ref_step"], cfg["scene_dist"], presampled=cfg["presampled"], edge=edge)
     assert len(poses) == want["n_final"], cfg
     for g, w in zip(poses, want["poses"]):
