@@ -105,6 +105,33 @@ def test_c2_full_size_identities(det_c2):
     assert full["stats"]["scratch_bytes"] < 1.0e9 and full["stats"]["n_batches"] == 1
 
 
+def test_c2_crop_seen_twice_overflows_some_16_bit_cells(bottle, det_c2):
+    """The C2 crop with every point present twice (second copy moved by a few micrometres): twice the votes per cell, the
+    heavy reference points pass 65,535 in one (the single 2,000-row tile has both halves of its words in use).  Those are
+    flagged and voted again with 32-bit cells, the others keep their 16-bit result: 25 strided reference points against the
+    oracle, on a scene of 100,000 points."""
+    import torch
+    from yolo_ppf_pose_estimation_amd.device import Workspace
+    crop = W.c2_scene()
+    rng = np.random.default_rng(77)
+    twin = crop.copy()
+    twin[:, :3] += rng.uniform(-2e-6, 2e-6, size=(crop.shape[0], 3)).astype(np.float32)
+    scene = np.vstack([crop, twin]).astype(np.float32)
+    stride = 200   # 100,000 / 20 = 5,000 reference points, every 200th of them
+    ws = Workspace()
+    d = torch.from_numpy(scene).cuda()
+    ws.match_device(det_c2, d.data_ptr(), scene.shape[0], 6, STEP, W.REL_DISTANCE, presampled=True, ref_offset=0, ref_stride=stride,
+                    skip_clustering=True)
+    res = ws.results(scene.shape[0])
+    ora = O.OracleDetector(W.C2["model_step"], W.REL_DISTANCE).train_model(bottle)
+    refs = [k * stride * int(1.0 / STEP) for k in range(res["n_ref"])]
+    want = ora.match(scene, relative_scene_sample_step=STEP, presampled=True, ref_list=refs, cluster=False)
+    np.testing.assert_array_equal(res["triples"], want["triples"])
+    assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+    n_over = int((want["triples"][:, 2] > 65535).sum())
+    assert n_over > 0 and res["stats"]["n_acc32_items"] >= n_over and res["stats"]["n_retries"] == 0
+
+
 def test_c3_rank_crops_equal_the_oracle_fixture(bottle, det_c2):
     fx = _fixture("config_c3.npz")
     off, stride = int(fx["ref_offset"][0]), int(fx["ref_stride"][0])
