@@ -140,3 +140,21 @@ def test_block_cache_size_classes():
         assert g >= prev
         prev = g
     assert len({f(n) for n in range(256, 4096)}) <= 8 * 4 + 1  # four octaves, eight classes each
+
+
+def test_workspace_options_are_checked_on_the_host():
+    """ppf_workspace_create / _set_option / _destroy need no device: valid options are accepted, unknown ones and values out
+    of range are PPF_ERR_INVALID with a message."""
+    ws = C.c_void_p()
+    assert lib().ppf_workspace_create(C.byref(ws)) == _capi.PPF_OK
+    try:
+        so = lib().ppf_workspace_set_option
+        assert so(ws, _capi.PPF_OPT_HIT_FRACTION, C.c_double(0.1)) == _capi.PPF_OK
+        assert so(ws, _capi.PPF_OPT_HIT_FRACTION, C.c_double(0.0)) == _capi.PPF_ERR_INVALID and "hit fraction" in _capi.last_error()
+        assert so(ws, _capi.PPF_OPT_GROUP_ROUND_BUCKETS, C.c_double(1000)) == _capi.PPF_OK
+        assert so(ws, _capi.PPF_OPT_CLUSTER_SERIAL, C.c_double(1)) == _capi.PPF_OK
+        assert so(ws, _capi.PPF_OPT_ACC32, C.c_double(1)) == _capi.PPF_OK and so(ws, _capi.PPF_OPT_ACC32, C.c_double(0)) == _capi.PPF_OK
+        assert so(ws, 99, C.c_double(1)) == _capi.PPF_ERR_INVALID and "unknown option" in _capi.last_error()
+        assert so(None, _capi.PPF_OPT_ACC32, C.c_double(1)) == _capi.PPF_ERR_INVALID
+    finally:
+        assert lib().ppf_workspace_destroy(ws) == _capi.PPF_OK
