@@ -1884,6 +1884,18 @@ ppf_workspace::~ppf_workspace() {
 /* bytes of hit scratch one hit costs: raw {bucket, j} + sorted payload (alpha_s, cell) + its share of the run table */
 constexpr double HIT_SCRATCH_BYTES = 8.0 + 8.0 + 2.0 + 16.0 / 6.0;
 
+/* k_pairs<pair feature, surface-to-boundary>: same_cloud == 0 is match_S2B (the paired points come from the edge cloud) */
+static void launch_pairs(const MatchArgs& va, bool darboux, hipStream_t st) {
+  const dim3 grid(va.pair_chunks, va.n_ref), block(PAIR_BLOCK);
+  if (darboux) {
+    if (va.same_cloud) k_pairs<true, false><<<grid, block, 0, st>>>(va);
+    else k_pairs<true, true><<<grid, block, 0, st>>>(va);
+  } else {
+    if (va.same_cloud) k_pairs<false, false><<<grid, block, 0, st>>>(va);
+    else k_pairs<false, true><<<grid, block, 0, st>>>(va);
+  }
+}
+
 /* everything after A2: frames -> pairs -> group -> rank -> vote -> finalize -> cluster, on the clouds held by ws.
  * Nothing here waits for the device: the hit pools are sized from ws->hit_frac (hits per scene pair, learned from the
  * previous calls); a pool that turns out too small raises a device flag, which the first accessor of the results reads
@@ -1980,8 +1992,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     for (int base = 0; base < n_ref; base += 32768) {
       va.ref_base = base;
       va.n_ref = std::min(32768, n_ref - base);
-      if (darboux) k_pairs<true><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
-      else k_pairs<false><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+      launch_pairs(va, darboux, st);
       HIPCHK(hipGetLastError());
     }
     va.count_only = 0;
@@ -2075,8 +2086,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 0], st));
-    if (darboux) k_pairs<true><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
-    else k_pairs<false><<<dim3(va.pair_chunks, va.n_ref), dim3(PAIR_BLOCK), 0, st>>>(va);
+    launch_pairs(va, darboux, st);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 1], st));
     k_ref_hits<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va);

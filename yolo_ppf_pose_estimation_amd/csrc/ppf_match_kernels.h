@@ -281,7 +281,7 @@ __device__ __forceinline__ uint32_t pool_stripe(const uint32_t wg, const int str
 }
 
 /* grid: x = chunks of PAIR_BLOCK*PAIRS_PER_THREAD paired points, y = reference point of the batch */
-template <bool DARBOUX>
+template <bool DARBOUX, bool S2B>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   __shared__ uint2 stash[PAIRS_PER_THREAD][PAIR_BLOCK]; /* {bucket, j} of this thread's hits, one slot per iteration */
   __shared__ uint32_t wtot[PAIR_BLOCK / 64];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   /* the point of the next iteration is fetched while the current pair is hashed */
   float nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0, nx4 = 0, nx5 = 0;
   {
-    const int jc = min(j0, n - 1);
+    const uint32_t jc = (uint32_t)min(j0, n - 1); /* unsigned index: scalar base + 32-bit lane offset, no 64-bit address arithmetic */
     nx0 = a.paired.x[jc]; nx1 = a.paired.y[jc]; nx2 = a.paired.z[jc];
     nx3 = a.paired.nx[jc]; nx4 = a.paired.ny[jc]; nx5 = a.paired.nz[jc];
   }
@@ -310,18 +310,17 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
     const int j = j0 + it * PAIR_BLOCK;
     const ppf_vec3 p2 = ppf_mk3((double)nx0, (double)nx1, (double)nx2), n2 = ppf_mk3((double)nx3, (double)nx4, (double)nx5);
     {
-      const int jn = min(j + PAIR_BLOCK, n - 1);
+      const uint32_t jn = (uint32_t)min(j + PAIR_BLOCK, n - 1);
       nx0 = a.paired.x[jn]; nx1 = a.paired.y[jn]; nx2 = a.paired.z[jn];
       nx3 = a.paired.nx[jn]; nx4 = a.paired.ny[jn]; nx5 = a.paired.nz[jn];
     }
-    if (j < n && !(a.same_cloud && j == i_ref)) {
+    if (j < n && (S2B || j != i_ref)) {
       /* match_S2B: the reference point itself is never paired, even when the edge cloud contains it
        * (bit-identical row), so edge == scene reduces exactly to match().  Values came from floats, so
        * comparing the doubles compares the float bits (no NaN/-0 cases in finite clouds). */
-      const bool self_pair = !a.same_cloud && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x &&
-                             n2.y == n1.y && n2.z == n1.z;
+      const bool self_pair = S2B && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x && n2.y == n1.y && n2.z == n1.z;
       bool skip = self_pair;
-      if (a.pair_radius > 0.0) { /* PCL policy: neighbours within a radius only; the same fp64 distance the pair feature uses */
+      if (__builtin_expect(a.pair_radius > 0.0, 0)) { /* PCL policy: neighbours within a radius only; the same fp64 distance the pair feature uses */
         const double dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
         skip |= ppf_sqrt(dx * dx + dy * dy + dz * dz) > a.pair_radius;
       }
