@@ -116,7 +116,7 @@ struct KeyDims {
 PPF_HD bool key_index(const KeyDims& d, const int32_t k0, const int32_t k1, const int32_t k2, const int32_t k3, size_t* idx) {
   const uint32_t a = (uint32_t)(k0 + d.o0), b = (uint32_t)(k1 + d.o1), c = (uint32_t)(k2 + d.o2);
   if (!((a < (uint32_t)d.n0) & (b < (uint32_t)d.n1) & (c < (uint32_t)d.n2) & ((uint32_t)k3 < (uint32_t)d.nd))) return false;
-  *idx = ((size_t)(a * (uint32_t)d.n1 + b) * (uint32_t)d.n2 + c) * (uint32_t)d.nd + (uint32_t)k3;
+  *idx = (size_t)(((a * (uint32_t)d.n1 + b) * (uint32_t)d.n2 + c) * (uint32_t)d.nd + (uint32_t)k3); /* the table holds at most 2^26 keys: 32-bit arithmetic */
   return true;
 }
 PPF_HD size_t key_table_size(const KeyDims& d) { return (size_t)d.n0 * d.n1 * d.n2 * d.nd; }

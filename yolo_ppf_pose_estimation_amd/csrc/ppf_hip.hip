@@ -1681,6 +1681,8 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   m->info.distance_step = dist_step;
   m->info.diameter = diameter;
   key_lut_dims(m);
+  if (key_table_size(m->kd) > ((size_t)1 << 30)) /* k_pairs indexes the key table with 32-bit arithmetic (and 4 GiB of keys would be pointless) */
+    return fail(PPF_ERR_INVALID, "ppf_model_train: num_angles %g is too fine for the key table", params->num_angles);
   if (params->key_equality != PPF_KEY_BUCKET && params->key_equality != PPF_KEY_EXACT)
     return fail(PPF_ERR_INVALID, "ppf_model_train: key_equality must be PPF_KEY_BUCKET or PPF_KEY_EXACT");
   if (params->feature != PPF_FEATURE_PPF && params->feature != PPF_FEATURE_DARBOUX)
@@ -2730,6 +2732,7 @@ static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_
   if (m->params.key_equality != PPF_KEY_BUCKET && m->params.key_equality != PPF_KEY_EXACT) return bad("key_equality");
   if (m->params.feature != PPF_FEATURE_PPF && m->params.feature != PPF_FEATURE_DARBOUX) return bad("feature");
   key_lut_dims(m);
+  if (key_table_size(m->kd) > ((size_t)1 << 30)) return bad("angle step too fine for the key table");
   if (I.slots != table_slots(m)) return bad("slots");
   if (I.num_angles != (int)std::floor(2 * PPF_PI / I.angle_step)) return bad("num_angles");
   const int A = I.num_angles, GW = vote_guard(A);

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
     nx0 = a.paired.x[jc]; nx1 = a.paired.y[jc]; nx2 = a.paired.z[jc];
     nx3 = a.paired.nx[jc]; nx4 = a.paired.ny[jc]; nx5 = a.paired.nz[jc];
   }
-#pragma unroll 1
+#pragma unroll 2
   for (int it = 0; it < PAIRS_PER_THREAD; it++) {
     const int j = j0 + it * PAIR_BLOCK;
     const ppf_vec3 p2 = ppf_mk3((double)nx0, (double)nx1, (double)nx2), n2 = ppf_mk3((double)nx3, (double)nx4, (double)nx5);
