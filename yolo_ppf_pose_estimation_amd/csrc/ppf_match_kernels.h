@@ -702,10 +702,14 @@ __device__ __forceinline__ int vote_wrap(int t, const int A) {
   }
   return t;
 }
+/* The exact fp64 bin of a vote inside the guard band: 3e-5 of the votes, but dozens of call sites (every record group of every
+ * vote-loop instantiation).  Kept OUT OF LINE: inlined, the division sequences made up half of k_vote's code. */
+__device__ __attribute__((noinline)) int vote_bin_exact_4pi(const float am, const double as, const int A) { return ppf_alpha_bin_exact(am, as, A); }
+__device__ __attribute__((noinline)) int vote_bin_exact_2pi(const float am, const double as, const int A) { return ppf_alpha_bin_exact_2pi(am, as, A); }
 template <bool WRAP>
 __device__ __forceinline__ int vote_bin_exact(const float am, const double as, const int A) {
-  if constexpr (WRAP) return ppf_alpha_bin_exact_2pi(am, as, A);
-  else return ppf_alpha_bin_exact(am, as, A);
+  if constexpr (WRAP) return vote_bin_exact_2pi(am, as, A);
+  else return vote_bin_exact_4pi(am, as, A);
 }
 
 template <int U>
@@ -1036,10 +1040,10 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
       uint32_t za = rec.z, zb = rec.w;
       asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the loop */
       const uint32_t ha = k.ws + AGG_OFF_IDX + ((ia - base32) >> 2), hb = k.ws + AGG_OFF_IDX + ((ib - base32) >> 2);
-      if (da0 && fa0 < k.G2) ba0 = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(ha)], k.A);
-      if (da1 && fa1 < k.G2) ba1 = ppf_alpha_bin_exact(__uint_as_float(za), g_a64[lds_ld8(ha + 1u)], k.A);
-      if (db0 && fb0 < k.G2) bb0 = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(hb)], k.A);
-      if (db1 && fb1 < k.G2) bb1 = ppf_alpha_bin_exact(__uint_as_float(zb), g_a64[lds_ld8(hb + 1u)], k.A);
+      if (da0 && fa0 < k.G2) ba0 = vote_bin_exact_4pi(__uint_as_float(za), g_a64[lds_ld8(ha)], k.A);
+      if (da1 && fa1 < k.G2) ba1 = vote_bin_exact_4pi(__uint_as_float(za), g_a64[lds_ld8(ha + 1u)], k.A);
+      if (db0 && fb0 < k.G2) bb0 = vote_bin_exact_4pi(__uint_as_float(zb), g_a64[lds_ld8(hb)], k.A);
+      if (db1 && fb1 < k.G2) bb1 = vote_bin_exact_4pi(__uint_as_float(zb), g_a64[lds_ld8(hb + 1u)], k.A);
     }
     if (da0) lds_add(pa + ((uint32_t)ba0 << 2), inc_a);
     if (db0) lds_add(pb + ((uint32_t)bb0 << 2), inc_b);
