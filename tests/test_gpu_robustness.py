@@ -229,6 +229,22 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
     bad = bytearray(raw); bad[header + sampled + 8] ^= 0x01               # a slot map rank
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
+    # the row codes of the pair records (byte offset | word half in bit 0 | count-table X << 18 | cell << 23)
+    recs = np.frombuffer(bytes(raw[rec0:]), dtype=np.uint32).reshape(-1, 4)
+    halves = recs[:, 0] & 1
+    assert halves.any() and not halves.all()                               # one tile of 2 x H rows: both halves in use
+    offs = np.frombuffer(bytes(raw[header + sampled + slotmap: header + sampled + slotmap + boff]), dtype=np.uint32)
+    victim = None                                                          # a bucket whose share of high-half rows spans >= 3 records
+    for b in range(info["n_buckets"]):
+        h = np.flatnonzero(halves[offs[b]:offs[b + 1]])
+        if len(h) >= 3:
+            victim = int(offs[b] + h[1])
+            break
+    assert victim is not None
+    bad = bytearray(raw); bad[rec0 + 16 * victim] ^= 0x01                  # a low-half row in the middle of the high-half ones
+    assert load(bytes(bad)) == _capi.PPF_ERR_IO and "halves" in _capi.last_error()
+    bad = bytearray(raw); bad[rec0 + 3] |= 0x1F                            # cell 63 > 32 and a reserved bit
+    assert load(bytes(bad)) == _capi.PPF_ERR_IO and "cell" in _capi.last_error()
     bad = bytearray(raw); bad[8 + C.sizeof(_capi.TrainParams)] ^= 0x40     # n_ref in the header
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
 
