@@ -158,9 +158,21 @@ PPF_HD void ppf_transform_rt(const ppf_vec3& p, const ppf_vec3& n, double* R, do
 PPF_HD int ppf_alpha_in_frame(double qy, double qz, double* alpha) {
   double a = ppf_atan2(-qz, qy);
   if (a != a) return 0;
-  if (ppf_sin(a) * qz < 0.0) a = -a;
+  /* the library's sign fix-up: if (sin(a) * qz < 0) a = -a.  For |a| <= pi the sine has the sign of a (its true value is at
+   * least 1.2e-16 away from zero wherever a != 0), so away from the underflow range the product's sign is that of a * qz
+   * and no sine is needed; the tiny arguments keep the literal expression. */
+  const double aa = ppf_fabs(a), aq = ppf_fabs(qz);
+  const int flip = (aa > 1e-100 && aq > 1e-100) ? ((a < 0.0) != (qz < 0.0)) : (ppf_sin(a) * qz < 0.0);
+  if (flip) a = -a;
   *alpha = -a;
   return 1;
+}
+
+/* Whether ppf_alpha_in_frame has an alpha at all, without computing it: ppf_atan2 returns NaN exactly when an argument is
+ * NaN or both are infinite (every other path ends in a finite value), which finite clouds never produce. */
+PPF_HD int ppf_alpha_exists(double qy, double qz) {
+  const double big = 1.7976931348623157e308;
+  return !(qy != qy) && !(qz != qz) && !(ppf_fabs(qy) > big && ppf_fabs(qz) > big);
 }
 
 /* training-side alpha (computeAlpha): NaN -> 0 */

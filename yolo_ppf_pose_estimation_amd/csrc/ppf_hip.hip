@@ -2052,13 +2052,9 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
 
   const size_t lds = VOTE_LDS_FIXED + (size_t)vote_lds_words(m->info.tile_refs, m->info.num_angles) * 4;
   if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
-  /* k_group's dynamic LDS: counters, chunk prefix, and as many cached alpha_s as the rest holds */
-  const size_t group_fixed = (size_t)((va.round_buckets + 1) & ~1) * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
-  if (group_fixed + 2048 > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: %d paired points are more than one call can group", n_paired);
-  /* two workgroups per CU when the counters leave room: the cache takes what is left of half the LDS */
-  const size_t group_budget = group_fixed + 4096 <= (size_t)LDS_BYTES / 2 - 512 ? (size_t)LDS_BYTES / 2 - 512 : (size_t)LDS_BYTES - 1024;
-  va.group_cache = (int)std::min<size_t>((size_t)n_paired, (group_budget - group_fixed) / sizeof(double));
-  const size_t group_lds = group_fixed + (size_t)va.group_cache * sizeof(double);
+  /* k_group's dynamic LDS: one counter per bucket of a round, the prefix of the pool pieces */
+  const size_t group_lds = (size_t)((va.round_buckets + 1) & ~1) * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t);
+  if (group_lds + 2048 > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: %d paired points are more than one call can group", n_paired);
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {

@@ -247,7 +247,6 @@ struct MatchArgs {
   uint32_t* ovf_items;          /* [n_ref_all * n_tiles] != 0: a 16-bit cell of this (reference point, tile) overflowed */
   uint32_t* ovf_list;           /* [n_ref * n_tiles] the same for this batch as a list: local reference point | tile << 16 (cursors[CUR_OVFCOUNT] entries) */
   int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
-  int group_cache;              /* alpha_s values k_group keeps in LDS between its counting and its scatter pass */
   /* results, indexed by global r */
   uint2* partial;               /* [n_ref_all * n_tiles * 2] {max votes, local flat index}: slot 2*tile (16-bit cells) or 2*tile + pass (32-bit cells) */
   uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: bin A of the last low-half row; pass 1: bin 0 of the first high-half row */
@@ -425,8 +424,8 @@ __device__ __forceinline__ uint32_t hit_cell(const double alpha_s, const double 
  * table first, so the long work items of k_vote are claimed early --, then scatter the payload of every hit to its
  * sorted position through the counters (any order inside a bucket: votes commute).
  * The reference point's raw hits sit in pair_chunks pieces of the pool; the passes walk them as ONE list (thread t
- * takes hits t, t + 1024, ...) and the alpha_s of the first group_cache hits stays in LDS between the two passes.
- * Dynamic LDS: [round_buckets counters][pair_chunks + 1 prefix][group_cache doubles].
+ * takes hits t, t + 512, ...); the counting pass only needs to know that a hit HAS an alpha_s (always, for finite clouds), the
+ * scatter pass computes it.  Dynamic LDS: [round_buckets counters][pair_chunks + 1 prefix].
  */
 __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   extern __shared__ __align__(8) uint32_t gcnt[]; /* round_buckets counters, then cursors */
@@ -436,7 +435,6 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const int r = a.perm_group ? (int)a.perm_group[blockIdx.x] : (int)blockIdx.x; /* most hits first: no long block at the tail */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t* cpre = gcnt + ((a.round_buckets + 1) & ~1);                     /* pair_chunks + 1 (even offsets: the doubles behind stay 8-byte aligned) */
-  double* acache = reinterpret_cast<double*>(cpre + ((a.pair_chunks + 2) & ~1)); /* group_cache */
   const uint32_t n_raw = (uint32_t)a.hit_count[r];
   const uint2* __restrict__ desc = a.chunk_desc + (size_t)r * a.pair_chunks;
   if (tid == 0) {
@@ -472,7 +470,6 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const double s64 = (double)a.num_angles / (4 * PPF_PI);
   const uint32_t agg_min = a.agg_min_hits > 0 ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
   const uint32_t n_list = ok ? n_raw : 0u;
-  const uint32_t n_cache = (uint32_t)a.group_cache;
   unsigned long long w = 0;
   uint32_t placed = 0, runs_written = 0;
   for (int round = 0; round < a.n_rounds; round++) {
@@ -513,14 +510,11 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
           if (in[u]) {
-            const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
             const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
             const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
-            double as = 0.0;
-            if (ppf_alpha_in_frame(qy, qz, &as)) {
+            if (ppf_alpha_exists(qy, qz)) { /* alpha_s itself is computed once, by the pass that stores it */
               atomicAdd(&gcnt[key[u].x - b0], 1u);
               w += total[u];
-              if (g < n_cache) acache[g] = as;
             } else {
               a.raw[at[u]].x = 0xFFFFFFFFu; /* retired: matches no round */
             }
@@ -594,29 +588,22 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
         }
         double as[GROUP_MLP];
         ppf_vec3 p2[GROUP_MLP];
-        bool in[GROUP_MLP], cached[GROUP_MLP];
+        bool in[GROUP_MLP];
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
-          const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
           in[u] = key[u].x - b0 < nb;
-          cached[u] = g < n_cache;
           as[u] = 0.0;
           p2[u] = ppf_mk3(0.0, 0.0, 0.0);
-          if (in[u]) {
-            if (cached[u]) as[u] = acache[g];
-            else p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
-          }
+          if (in[u]) p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
         }
         uint32_t gi[GROUP_MLP];
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
           gi[u] = 0u;
           if (in[u]) {
-            if (!cached[u]) {
-              const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
-              const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
-              (void)ppf_alpha_in_frame(qy, qz, &as[u]);
-            }
+            const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
+            const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
+            (void)ppf_alpha_in_frame(qy, qz, &as[u]);
             gi[u] = hit_base + atomicAdd(&gcnt[key[u].x - b0], 1u);
           }
         }
