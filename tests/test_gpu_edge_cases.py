@@ -90,3 +90,16 @@ def test_pairs_beyond_the_key_table_take_the_hash_path(bottle):
     assert 30.0 / det.info()["distance_step"] > 1024
     got = _same(det, ora, cloud, 1.0 / 10.0)
     assert got["stats"]["n_pairs"] == got["n_ref"] * (cloud.shape[0] - 1)
+
+
+def test_absurdly_far_points_send_the_hit_grouping_through_its_checking_path(bottle):
+    """k_frames looks at the paired cloud: with ordinary numbers everywhere every hit has an alpha_s and k_group's counting
+    pass does not read the points.  A point 1e32 m away (finite, but beyond the bound that guarantees finite transformed
+    coordinates) switches that pass to checking every hit; the votes are the oracle's either way."""
+    det = PPF3DDetector(0.06, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(0.06, 0.05).train_model(bottle)
+    scene, _ = synth.make_scene(bottle, n_points=2500, seed=17)
+    cloud = scene.copy()
+    cloud[1234, :3] = np.array([1e32, -3e31, 2e30], dtype=np.float32)
+    got = _same(det, ora, cloud, 1.0 / 10.0)
+    assert got["stats"]["n_pairs"] == got["n_ref"] * (cloud.shape[0] - 1)

@@ -102,7 +102,8 @@ constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + c
 constexpr int CUR_STRIDE = 32;
 constexpr int CUR_SORTED = POOL_STRIPES * CUR_STRIDE;
 constexpr int CUR_RUNS = CUR_SORTED + CUR_STRIDE;
-constexpr int CUR_OVFCOUNT = CUR_RUNS + CUR_STRIDE; /* (reference point, tile)s of this batch whose 16-bit cells overflowed: length of ovf_list */
+constexpr int CUR_ODDVALUES = CUR_RUNS + CUR_STRIDE; /* != 0: the batch has a reference frame or a paired point that is not finite (or absurdly large): k_group checks every hit for an alpha_s */
+constexpr int CUR_OVFCOUNT = CUR_ODDVALUES + CUR_STRIDE; /* (reference point, tile)s of this batch whose 16-bit cells overflowed: length of ovf_list */
 constexpr int CUR_OVERFLOW = CUR_OVFCOUNT + CUR_STRIDE; /* bits 1, 2, 4: raw pool, sorted pool, run table too small */
 constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
 
@@ -262,15 +263,24 @@ __device__ __forceinline__ int ref_row(const MatchArgs& a, int r_local) {
 
 __global__ __launch_bounds__(64) void k_frames(MatchArgs a) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= a.n_ref) return;
-  const int i = ref_row(a, r);
-  double R[9], t[3];
-  ppf_transform_rt(ld3(a.surf.x, a.surf.y, a.surf.z, i), ld3(a.surf.nx, a.surf.ny, a.surf.nz, i), R, t);
-  double* f = a.frames + (size_t)r * 12;
+  /* on the side: are all paired points ordinary numbers?  Then (with ordinary frames) every hit has an alpha_s and
+   * k_group's counting pass need not look at the points at all. */
+  bool odd = false;
+  for (int j = r; j < a.paired.n; j += gridDim.x * blockDim.x) {
+    const float m = fmaxf(fmaxf(fabsf(a.paired.x[j]), fabsf(a.paired.y[j])), fabsf(a.paired.z[j]));
+    odd |= !(m < 1e30f); /* NaN, infinite or beyond anything a transformed coordinate could keep finite */
+  }
+  if (r < a.n_ref) {
+    const int i = ref_row(a, r);
+    double R[9], t[3];
+    ppf_transform_rt(ld3(a.surf.x, a.surf.y, a.surf.z, i), ld3(a.surf.nx, a.surf.ny, a.surf.nz, i), R, t);
+    double* f = a.frames + (size_t)r * 12;
 #pragma unroll
-  for (int k = 0; k < 9; k++) f[k] = R[k];
+    for (int k = 0; k < 9; k++) { f[k] = R[k]; odd |= !(ppf_fabs(R[k]) < 1e30); }
 #pragma unroll
-  for (int k = 0; k < 3; k++) f[9 + k] = t[k];
+    for (int k = 0; k < 3; k++) { f[9 + k] = t[k]; odd |= !(ppf_fabs(t[k]) < 1e30); }
+  }
+  if (odd) atomicOr(&a.cursors[CUR_ODDVALUES], 1u);
 }
 
 /* stripe of the raw pool a k_pairs workgroup appends to: a multiplicative hash of its linear index, so that no stripe
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const double s64 = (double)a.num_angles / (4 * PPF_PI);
   const uint32_t agg_min = a.agg_min_hits > 0 ? (uint32_t)a.agg_min_hits : 0xFFFFFFFFu;
   const uint32_t n_list = ok ? n_raw : 0u;
+  const bool check_alpha = a.cursors[CUR_ODDVALUES] != 0u;
   unsigned long long w = 0;
   uint32_t placed = 0, runs_written = 0;
   for (int round = 0; round < a.n_rounds; round++) {
@@ -504,15 +515,19 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
           p2[u] = ppf_mk3(0.0, 0.0, 0.0);
           if (in[u]) {
             total[u] = a.bucket_total[key[u].x];
-            p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
+            if (check_alpha) p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
           }
         }
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
           if (in[u]) {
-            const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
-            const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
-            if (ppf_alpha_exists(qy, qz)) { /* alpha_s itself is computed once, by the pass that stores it */
+            bool has_alpha = true; /* ordinary numbers everywhere (k_frames looked): every hit has one */
+            if (check_alpha) {
+              const double qy = ty + (R10 * p2[u].x + R11 * p2[u].y + R12 * p2[u].z);
+              const double qz = tz + (R20 * p2[u].x + R21 * p2[u].y + R22 * p2[u].z);
+              has_alpha = ppf_alpha_exists(qy, qz);
+            }
+            if (has_alpha) { /* alpha_s itself is computed once, by the pass that stores it */
               atomicAdd(&gcnt[key[u].x - b0], 1u);
               w += total[u];
             } else {
