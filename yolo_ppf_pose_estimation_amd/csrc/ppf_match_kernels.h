@@ -505,18 +505,13 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
             key[u] = a.raw[at[u]];
           }
         }
-        uint32_t total[GROUP_MLP];
         ppf_vec3 p2[GROUP_MLP];
         bool in[GROUP_MLP];
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
           in[u] = key[u].x - b0 < nb; /* retired hits (0xFFFFFFFF) and other rounds' buckets fall out here */
-          total[u] = 0u;
           p2[u] = ppf_mk3(0.0, 0.0, 0.0);
-          if (in[u]) {
-            total[u] = a.bucket_total[key[u].x];
-            if (check_alpha) p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
-          }
+          if (in[u] && check_alpha) p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
         }
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
@@ -529,7 +524,6 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
             }
             if (has_alpha) { /* alpha_s itself is computed once, by the pass that stores it */
               atomicAdd(&gcnt[key[u].x - b0], 1u);
-              w += total[u];
             } else {
               a.raw[at[u]].x = 0xFFFFFFFFu; /* retired: matches no round */
             }
@@ -583,6 +577,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
         if (c) {
           const uint32_t idx = c >= agg_min ? rh++ : rl++;
           if (okr) a.runs[rb + idx] = make_uint4(b0 + k, hit_base + placed + pos, c, 0u);
+          w += (unsigned long long)c * a.bucket_total[b0 + k]; /* votes this run will cast (the launch order of k_vote) */
         }
         pos += c;
       }
