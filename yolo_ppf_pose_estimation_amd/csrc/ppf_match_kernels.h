@@ -82,7 +82,8 @@ constexpr int VOTE_BLOCK = 1024;
 constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
 constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded per lane per batch */
 constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * 4; /* pair records per direct work item (1024 = 2048 entries) */
-constexpr int VOTE_MAX_HITS = 16;     /* hits of one run voted per direct work item */
+constexpr int VOTE_MAX_HITS = PPF_AGG_MIN_HITS; /* hits of one run voted per direct work item: a run that votes directly on a bucket of some size has fewer,
+                                                   so its records are read once (16 per item: +0.9 % on C2) */
 #ifndef PPF_AGG_CHUNK
 #define PPF_AGG_CHUNK 2048
 #endif
