@@ -5,7 +5,8 @@
 
 `--gpus N` with N > 1 starts N ranks BY ITSELF when it was not started under torch.distributed.run
 (no RANK/WORLD_SIZE in the environment): the parent process never imports torch or touches the GPU, it
-only spawns N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and relays rank 0's line.  Under
+only spawns N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, watches ALL of them (a rank that
+dies takes the others down with it instead of leaving them in a collective) and relays rank 0's line.  Under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks already exist and each
 process is one of them.  WORLD_SIZE != --gpus is an error.
 
@@ -22,18 +23,23 @@ clustering, with the crop and the model table already resident in HBM.
       device and clusters them on rank 0.
   c5  configs[4]: four resident model tables x 8 crops per rank through the batched entry.
 
-The line printed by rank 0 carries
-  value        whole-job pair-matches (accumulator increments the reference would make, exact integer) per second
-  roofline     the voting kernel against HBM: measured fabric traffic per launch (committed PMC pass) / its
-               average device time (HIP events on the launch stream); the SURVEY section 8d figure stays beside it as
-               algorithmic_bytes_per_launch
-  lds_roofline what actually bounds k_vote: LDS atomic lane-operations per second against the ds_add_u32 ceiling
-  cpu_baseline the CPU oracle (kind "port", -O3 -march=native build made on this box) on a bounded sample of the
-               same workload: median of 5 repetitions on all usable cores plus a 1-thread figure; N = 1 only
+The ONE line printed by rank 0 carries
+  value          whole-job pair-matches (accumulator increments the reference would make, exact integer) per second
+  roofline       the voting kernel against HBM: measured fabric traffic per step (committed PMC pass of THIS source
+                 tree: the pass records a hash of the kernel sources and its own kernel time; another tree or a kernel time
+                 more than 5 % away makes traffic_stale true and frac null) / its device time in this run (HIP events on
+                 the launch stream); the SURVEY section 8d figure stays beside it as algorithmic_bytes_per_launch
+  issue_roofline / lds_roofline   what actually bounds k_vote: LDS wave-instructions and atomic lane-operations per second
+  host_entry     (N = 1, c2) the call the reference really makes: ppf_match from HOST memory, upload and read-back
+                 included (SURVEY section 8d's "poses/s per crop"), on a warm context
+  other_configs  (N = 1, c2) C4 and C5 measured in the same run, 2 steps each, with the same roofline fields
+  cpu_baseline   the CPU oracle (kind "port", -O3 -march=native build made on this box) on a bounded sample of the
+                 same workload: min and median of 5 repetitions on all usable cores plus a 1-thread figure; N = 1 only
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -47,6 +53,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # LDS atomic ceilings, lane-operations per second chip-wide:
 LDS_ATOMIC_PEAK_UBENCH = 8.97e12  # profiles/r01_ubench_valu_lds.txt: ds_add_u32 14.6 lanes/clk/CU x 256 CUs x 2.4 GHz
 LDS_ATOMIC_PEAK_GUIDE = 9.83e12   # MI355X_MICROARCH.md LDS section: 16 lanes/clk/CU x 256 x 2.4 GHz
+LDS_INSTR_PEAK = 256 * 2.4e9 / 4.38  # ds_add_u32: one 64-lane wave-instruction per 4.38 cycles per CU (r01 / r02 ubench)
+STALE_KERNEL_TIME = 0.05  # a PMC pass whose own k_vote time differs by more than this from the run's is not this kernel
 
 
 def parse_args(argv=None):
@@ -65,6 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline-depth", type=int, default=1,
                     help="crops in flight: 1 (default) = strictly one after another, so the HIP-event kernel times "
                          "behind `roofline` are the kernel's own; 2-3 overlap independent crops on separate streams")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="c2 at N = 1: leave out the host-entry measurement and the C4 / C5 legs (profiling runs)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="ranks rendezvous (gloo, CPU), report RANK/WORLD_SIZE and stop before any device use")
     return ap.parse_args(argv)
@@ -73,24 +83,53 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------------
 # launcher: runs in a process that has NOT touched the GPU (no torch import up to here)
 # ---------------------------------------------------------------------------------------------------------------
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, poll_s=0.2):
+    """Spawn one child per rank and watch ALL of them: the first child that exits non-zero ends the others (they would
+    otherwise sit in init_process_group or a barrier until the collective's timeout) and its code is returned.  Rank 0's
+    stdout is relayed when everything has ended; the other ranks' stderr goes to this process's stderr."""
     import socket
+    import tempfile
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for ln in out.decode().splitlines():  # the contract is ONE JSON line on stdout; library chatter goes to stderr
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(args.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+                for o in sorted(live):
+                    procs[o].terminate()
+        if live:
+            time.sleep(poll_s)
+            if rc:  # give terminated ranks a moment, then make sure
+                deadline = time.time() + 10.0
+                while live and time.time() < deadline:
+                    live = {o for o in live if procs[o].poll() is None}
+                    time.sleep(poll_s)
+                for o in live:
+                    procs[o].kill()
+                for o in live:
+                    procs[o].wait()
+                live = set()
+    out0.seek(0)
+    for ln in out0.read().decode().splitlines():  # the contract is ONE JSON line on stdout; library chatter goes to stderr
         (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return rc
 
 
 def usable_cpus():
@@ -119,11 +158,25 @@ def algorithmic_bytes(n_ref, n_model, num_angles, n_pairs, n_votes):
     return n_ref * (24 + 2 * 4 * n_model * num_angles + 12) + n_pairs * 32 + n_votes * 16
 
 
-def committed_counters(n_votes_per_step):
-    """The committed PMC summary (profiles/*_pmc_*.json, tools/pmc_summary.py) taken on this exact workload (same
-    vote count per step), newest file first; None when there is none.  bench.py cannot collect PMC counters on itself."""
+def kernel_source_hash():
+    """sha256 over the sources libppf_hip.so is built from (the kernels and their launch code): what a PMC summary must have
+    been collected on to describe the kernels of this run (tools/pmc_summary.py stores the same hash)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_*.json")), reverse=True):
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "yolo_ppf_pose_estimation_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "yolo_ppf_pose_estimation_amd", "csrc", "*.hip")) +
+                   [os.path.join(ROOT, "include", "ppf_hip.h"), os.path.join(ROOT, "include", "ppf_detmath.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def committed_counters(workload, n_votes_per_step):
+    """The newest committed PMC summary (profiles/*_pmc_<workload>.json, tools/pmc_summary.py) of this workload (same
+    vote count per step), or None.  bench.py cannot collect PMC counters on itself."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{workload}.json")), reverse=True):
         try:
             t = json.load(open(f))
             if t.get("n_votes_per_step", t.get("n_votes_per_launch")) == n_votes_per_step:
@@ -134,9 +187,76 @@ def committed_counters(n_votes_per_step):
     return None
 
 
+def counter_rooflines(workload, n_votes_per_step, k_vote_ms, abytes, atomics_per_step, src_hash):
+    """roofline / issue_roofline / lds_roofline of k_vote from the committed counter pass of this workload, refused when the
+    pass does not describe the kernel that just ran (other source tree, or a kernel time more than 5 % away)."""
+    pmc = committed_counters(workload, n_votes_per_step)
+    k_vote_s = k_vote_ms * 1e-3
+    stale, why = False, None
+    if pmc is None:
+        stale, why = True, "no committed counter pass for this workload and vote count"
+    else:
+        at = pmc.get("k_vote_ms_per_step_at_collection")
+        if pmc.get("source_hash") != src_hash:
+            stale, why = True, "the counter pass was collected on another source tree"
+        elif not at or abs(at - k_vote_ms) > STALE_KERNEL_TIME * k_vote_ms:
+            stale, why = True, f"k_vote took {at} ms when the counters were collected, {k_vote_ms:.3f} ms now"
+    traffic = pmc.get("hbm_bytes_per_step_k_vote") if pmc and not stale else None
+    achieved = traffic / k_vote_s / 1e9 if traffic else None
+    roofline = {
+        "bound": "hbm", "kernel": "k_vote",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS if achieved else None,
+        "traffic": traffic, "traffic_source": pmc["file"] if pmc else None,
+        "traffic_stale": stale, "traffic_stale_reason": why,
+        "avg_kernel_ms": k_vote_ms,
+        "algorithmic_bytes_per_launch": abytes,
+        "note": "achieved = measured fabric bytes of k_vote per step (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC pass, "
+                "tied to this source tree by source_hash and to this run by the kernel time) / its HIP-event time of this "
+                "run.  The section 8d figure (16 B per vote) is kept as algorithmic_bytes_per_launch only: the accumulator "
+                "lives in LDS and a model entry is read once per run of hits.  What bounds the kernel is the LDS "
+                "instruction rate, see issue_roofline / lds_roofline",
+    }
+    issue = pmc.get("k_vote_issue") if pmc and not stale else None
+    issue_roofline = None if not issue else {
+        "kernel": "k_vote", "source": pmc["file"],
+        "valu_busy_frac_of_simd_time": issue["valu_busy_frac_of_simd_time"],
+        "any_inst_busy_frac_of_simd_time": issue["any_inst_busy_frac_of_simd_time"],
+        "lds_busy_frac_of_simd_time": issue["lds_busy_frac_of_simd_time"],
+        "lds_wave_instr_per_s": issue["lds_wave_instructions_sampled"] / k_vote_s,
+        "lds_wave_instr_peak_per_s": LDS_INSTR_PEAK,
+        "frac_of_lds_instr_peak": issue["lds_wave_instructions_sampled"] / k_vote_s / LDS_INSTR_PEAK,
+        "lds_array_cycles_per_instr": issue.get("lds_array_cycles_per_instr"),
+        "lds_bank_conflict_frac_of_lds_cycles": issue["lds_bank_conflict_frac_of_lds_cycles"],
+        "valu_wave_instr_per_s": issue["valu_wave_instructions_sampled"] / k_vote_s,
+        "valu_wave_instr_peak_per_s": 1024 * 2.4e9 / 4.45,
+        "frac_of_valu_issue_peak": issue["valu_wave_instructions_sampled"] / k_vote_s / (1024 * 2.4e9 / 4.45),
+        "note": "SQ_INSTS_LDS of one step / k_vote time against one 64-lane LDS wave-instruction per 4.38 cycles per CU "
+                "(the cost of ds_add_u32 / ds_write_b32 whatever the lanes do, as long as the LDS array needs no more: two "
+                "32-lane halves, 32 banks, one array cycle per distinct address on the fullest bank of a half; "
+                "profiles/r03_ubench_lds_counters.md).  lds_array_cycles_per_instr = SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS.  "
+                "VALU: SQ_INSTS_VALU against 1024 SIMDs x 2.4 GHz / 4.45 cycles; busy fractions = SQ_ACTIVE_INST_* / "
+                "(SQ_WAVE_CYCLES / 4)",
+    }
+    atom = atomics_per_step or None
+    lds_roofline = {
+        "kernel": "k_vote", "unit": "LDS atomic lane-ops/s",
+        "lds_atomics_per_launch": atom,
+        "achieved": atom / k_vote_s if atom else None,
+        "peak_ubench": LDS_ATOMIC_PEAK_UBENCH, "peak_guide": LDS_ATOMIC_PEAK_GUIDE,
+        "frac_ubench": atom / k_vote_s / LDS_ATOMIC_PEAK_UBENCH if atom else None,
+        "frac_guide": atom / k_vote_s / LDS_ATOMIC_PEAK_GUIDE if atom else None,
+        "votes_per_lds_atomic": n_votes_per_step / atom if atom else None,
+        "votes_per_s_kernel": n_votes_per_step / k_vote_s,
+        "source": "profiles/r01_ubench_valu_lds.txt; MI355X_MICROARCH.md (ds_write-class op: 16 lanes/clk/CU)",
+    }
+    return roofline, issue_roofline, lds_roofline
+
+
 def cpu_baseline(model_step, bottle, scene, n_ref_total, seconds_per_rep, reps=5):
     """The oracle (CPU restatement, -O3 -march=native build made on this machine) on an evenly spaced sample of the
-    step's reference points: median of `reps` runs on every usable core, and one 1-thread run."""
+    step's reference points: `reps` runs on every usable core (min and median reported: the box's cores are shared and
+    single runs swing), and one 1-thread run."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -163,11 +283,13 @@ def cpu_baseline(model_step, bottle, scene, n_ref_total, seconds_per_rep, reps=5
     refs = spaced(n_sample)
     runs = [timed(refs, threads) for _ in range(reps)]
     votes = runs[0][1]
-    med = float(np.median([d for d, _ in runs]))
+    secs = [d for d, _ in runs]
+    med, best = float(np.median(secs)), float(min(secs))
     n1 = max(2, n_sample // threads)
     d1, v1 = timed(spaced(n1), 1)
     return {
         "value": votes / med,
+        "value_best_repetition": votes / best,
         "unit": "pair-matches/s",
         "cores": threads,
         "host_cpus_visible": os.cpu_count(),
@@ -175,13 +297,53 @@ def cpu_baseline(model_step, bottle, scene, n_ref_total, seconds_per_rep, reps=5
         "build": "-O3 -march=native (oracle/Makefile target native, compiled on this box)" if native
                  else "-O2 (portable build; the native build failed on this box)",
         "repetitions": reps,
-        "seconds_per_repetition": [round(d, 3) for d, _ in runs],
+        "seconds_per_repetition": [round(d, 3) for d in secs],
+        "seconds_median": med, "seconds_min": best,
         "sample": f"{n_sample} of {n_ref_total} reference points (evenly spaced) of the same crop, all "
-                  f"{scene.shape[0]} paired points each, {votes} pair-matches, median of {reps} runs {med:.2f} s, "
-                  f"{n_sample / med:.2f} poses/s",
+                  f"{scene.shape[0]} paired points each, {votes} pair-matches; value = median of {reps} runs ({med:.2f} s, "
+                  f"{n_sample / med:.2f} poses/s), value_best_repetition = the fastest ({best:.2f} s); the box's cores are shared",
         "poses_per_s": n_sample / med,
         "one_thread": {"value": v1 / d1, "unit": "pair-matches/s", "cores": 1,
                        "sample": f"{n1} reference points, {v1} pair-matches in {d1:.2f} s"},
+    }
+
+
+def host_entry(det, scene, n_ref, resident_ms, reps=12, warm=3):
+    """The call the reference makes (detector.match, /root/reference/include/CloudProcessing.h:441-446: its own "PPF Elapsed
+    Time" bracket): ppf_match on the crop in HOST memory -- staging, upload, the whole path, read-back of every clustered
+    pose -- timed around the C call alone (pre-built ctypes arguments; the Python wrapper's object construction is not the
+    library's).  Warm context: the second and later calls of a detector, which is every call but the first of a session."""
+    import ctypes as C
+    import numpy as np
+    from yolo_ppf_pose_estimation_amd import workloads as W
+    from yolo_ppf_pose_estimation_amd._capi import Pose, check, lib
+
+    sc = np.ascontiguousarray(scene, dtype=np.float32)
+    mp = det._params(W.SCENE_STEP, W.REL_DISTANCE, True)
+    cap = n_ref + 8
+    out = (Pose * cap)()
+    n = C.c_int(0)
+    f = lib().ppf_match
+    argv = (det._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1], 3, None, 0, 6, 3, C.byref(mp), out, cap, C.byref(n))
+    t0 = time.perf_counter()
+    check(f(*argv))
+    first = time.perf_counter() - t0
+    for _ in range(warm):
+        check(f(*argv))
+    secs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        check(f(*argv))
+        secs.append(time.perf_counter() - t0)
+    med = float(np.median(secs))
+    return {
+        "entry": "ppf_match (what PPF3DDetector::match / match_S2B bind to): host rows in, clustered poses out",
+        "ms_per_match": med * 1e3, "ms_min": float(min(secs)) * 1e3, "ms_first_call": first * 1e3,
+        "poses_per_s": n_ref / med, "clustered_poses_returned": n.value,
+        "bytes_in": int(sc.nbytes), "bytes_out": int(n.value) * C.sizeof(Pose),
+        "resident_step_ms": resident_ms, "over_resident_step": med * 1e3 / resident_ms - 1.0 if resident_ms else None,
+        "sample": f"median of {reps} calls after {1 + warm} warm-up calls on the same crop; first call of the detector "
+                  f"(cold context: counting pass + scratch allocation) {first * 1e3:.2f} ms",
     }
 
 
@@ -201,9 +363,12 @@ def main(argv=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     if args.dry_launch:
+        import datetime
         import torch.distributed as dist
+        if os.environ.get("PPF_BENCH_DRY_FAIL_RANK") == str(rank):  # launcher test: a rank that dies before the rendezvous
+            sys.exit(7)
         if world > 1:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
             dist.barrier()
         print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world,
                           "dist_world": dist.get_world_size() if world > 1 else 1}), flush=True)
@@ -211,6 +376,7 @@ def main(argv=None):
             dist.destroy_process_group()
         return
 
+    import datetime
     import numpy as np
     import torch
 
@@ -221,94 +387,59 @@ def main(argv=None):
     one_device = os.environ.get("PPF_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("PPF_BENCH_BACKEND", "nccl")
     device_index = 0 if one_device else local_rank
+    if device_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{device_index}, the box shows {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # a short rendezvous timeout: a rank that never arrives must not hold the others for the default ten minutes
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index),
+                                    timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=180))
 
     from yolo_ppf_pose_estimation_amd import _capi, parallel, workloads as W
     from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
     from yolo_ppf_pose_estimation_amd.device import BatchMatcher, Workspace
 
+    assert torch.cuda.current_device() == device_index, "the rank's current device is not its own"
     bottle = W.bottle()
-    shard_refs = args.config == "c4" and args.shard == "refs" and world > 1
-    if args.config == "c2":
-        model_step = W.C2["model_step"]
-        scene = W.c2_scene() if world == 1 else W.c3_scene(rank)
-        scaling = "weak"
-        workload = ("C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
-                    "(presampled, every point paired), reference stride 20 -> 2,500 reference points, 30 alpha bins"
-                    + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"))
-    elif args.config == "c4":
-        model_step = W.C4["model_step"]
-        scene = W.c4_scene()
-        scaling = "strong" if shard_refs else "weak"
-        workload = ("C4: bottle model sampled at 0.0135 (~10k pts) vs one 200,000-pt synthetic scene (presampled), "
-                    "reference stride 20 -> 10,000 reference points, 30 alpha bins"
-                    + (f"; reference points strided over {world} ranks, raw poses all_gathered, clustered on rank 0"
-                       if shard_refs else ("" if world == 1 else f"; {world} replicas")))
-        args.no_cpu_baseline = True
-    else:
-        model_step = W.C5_MODEL_STEP
-        scaling = "weak"
-        workload = (f"C5: 4 resident model tables (bottle, box, cylinder, torus at step 0.036) x "
-                    f"{W.C5_CROPS_PER_RANK} crops of 50,000 pts per GPU, every crop matched against every table "
-                    f"through ppf_batch_run (32 matches per step per GPU)")
-        args.no_cpu_baseline = True
+    step_stride = int(1.0 / W.SCENE_STEP)
+    src_hash = kernel_source_hash()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    tally = {"votes": 0, "pairs": 0, "atomics": 0}
-    vote_ms, pair_ms, group_ms, dev_ms = [], [], [], []
-    last = {}
-    n_scene = scene.shape[0] if args.config != "c5" else W.C2["n_points"]
-    step_stride = int(1.0 / W.SCENE_STEP)
-
-    if args.config == "c5":
-        models = W.c5_models()
-        dets = [PPF3DDetector(model_step, W.REL_DISTANCE).trainModel(m) for m in models]
-        info = dets[0].info()
-        crops = W.c5_crops(rank, models=models)
-        d_crops = [torch.from_numpy(c).cuda() for c in crops]
-        bm = BatchMatcher(lanes=int(os.environ.get("PPF_BATCH_LANES", "4")))
-
-        def run(n_steps, timed):
-            for _ in range(n_steps):
-                res = bm.run_device(dets, [t.data_ptr() for t in d_crops], [c.shape[0] for c in crops], 6, W.SCENE_STEP,
-                                    W.REL_DISTANCE, presampled=True, top_k=W.TOP_K)
-                if world > 1:
-                    parallel.gather_device(res["d_top"], dist)
-                if timed:
-                    tally["votes"] += res["n_votes"]
-                    tally["pairs"] += res["n_pairs"]
-                    tally["atomics"] += res.get("n_lds_atomics", 0)
-                    last.update(res)
-    else:
+    def run_single(config, n_steps, n_warm, cells="auto", depth_arg=1, shard=False, scene=None):
+        """C2 / C3 / C4: one crop per rank through ppf_match_device, `depth` crops in flight.  Returns the raw figures."""
+        model_step = W.C2["model_step"] if config == "c2" else W.C4["model_step"]
+        if scene is None:
+            scene = (W.c2_scene() if world == 1 else W.c3_scene(rank)) if config == "c2" else W.c4_scene()
+        n_scene = scene.shape[0]
         det = PPF3DDetector(model_step, W.REL_DISTANCE,
                             max_tile_refs=int(os.environ.get("PPF_TILE_REFS", "0"))).trainModel(bottle)
         info = det.info()
+        assert det.device() == device_index, "the trained model does not live on this rank's device"
         d_scene = torch.from_numpy(scene).cuda()
         # Crops are independent, so consecutive steps CAN be software-pipelined like a serving loop would do.  The
         # default is depth 1: with overlap the per-kernel HIP-event times `roofline` is computed from are stretched.
-        depth = max(1, min(args.pipeline_depth, max(args.warmup, 1)))
+        depth = max(1, min(depth_arg, max(n_warm, 1)))
         streams = [torch.cuda.Stream() for _ in range(depth)]
         wss = [Workspace(timing=True) for _ in range(depth)]
-        if args.cells == "32":
+        if cells == "32":
             for w_ in wss:
                 w_.set_option(_capi.PPF_OPT_ACC32, 1)
         n_ref_total = (n_scene + step_stride - 1) // step_stride
-        ref_kw = {"ref_offset": rank, "ref_stride": world, "skip_clustering": True} if shard_refs else {}
-        n_ref_rank = len(range(rank, n_ref_total, world)) if shard_refs else n_ref_total
+        ref_kw = {"ref_offset": rank, "ref_stride": world, "skip_clustering": True} if shard else {}
         n_ref_max = (n_ref_total + world - 1) // world
-        gathered = {}
-        ws_cluster = Workspace() if shard_refs else None  # rank 0 clusters the merged list here
+        ws_cluster = Workspace() if shard else None  # rank 0 clusters the merged list here
+        tally = {"votes": 0, "pairs": 0, "atomics": 0}
+        ms = {"k_pairs": [], "k_group": [], "k_vote": [], "device_total": []}
+        last, gathered = {}, {}
 
         def enqueue(i):
             s = streams[i % depth]
@@ -320,7 +451,7 @@ def main(argv=None):
             ws, s = wss[i % depth], streams[i % depth]
             with torch.cuda.stream(s):
                 st = ws.stats()  # waits for that step's stream (and re-runs a step whose scratch estimate was too small)
-                if shard_refs:
+                if shard:
                     # the path's only collective: all_gather of each rank's raw per-reference poses (216 B each),
                     # device to device; rank 0 clusters the merged list (ppf_cluster_poses_device)
                     blk = ws.device_pose_block(n_ref_max, s.cuda_stream)
@@ -328,37 +459,106 @@ def main(argv=None):
                     if rank == 0:
                         merged = parallel.merge_reference_shards_device(allp, world, n_ref_total)
                         gathered["poses"] = ws_cluster.cluster_device(det, merged.data_ptr(), n_ref_total, n_scene // step_stride,
-                                                              stream=s.cuda_stream, top_k=W.TOP_K)
+                                                                      stream=s.cuda_stream, top_k=W.TOP_K)
                 else:
                     blk = ws.device_top_block(W.TOP_K, s.cuda_stream)  # top-5 clustered poses, still in HBM
-                    if world > 1:
-                        gathered["poses"] = parallel.gather_device(blk, dist)  # 5 x 216 B per rank
-                    else:
-                        gathered["poses"] = blk
+                    gathered["poses"] = parallel.gather_device(blk, dist) if world > 1 else blk  # 5 x 216 B per rank
             if timed:
-                vote_ms.append(st["ms_vote_kernel"]); pair_ms.append(st["ms_pair_kernel"])
-                group_ms.append(st.get("ms_group_kernel", 0.0)); dev_ms.append(st["ms_total_device"])
+                ms["k_vote"].append(st["ms_vote_kernel"]); ms["k_pairs"].append(st["ms_pair_kernel"])
+                ms["k_group"].append(st.get("ms_group_kernel", 0.0)); ms["device_total"].append(st["ms_total_device"])
                 tally["votes"] += st["n_votes"]; tally["pairs"] += st["n_pairs"]
                 tally["atomics"] += st.get("n_lds_atomics", 0)
                 last.update(st)
 
-        def run(n_steps, timed):
-            for i in range(n_steps + depth - 1):
-                if i < n_steps:
+        def run(n, timed):
+            for i in range(n + depth - 1):
+                if i < n:
                     enqueue(i)
                 if i >= depth - 1:
                     collect(i - (depth - 1), timed)
 
-    run(args.warmup, False)
-    sync()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    sync()
-    elapsed = time.perf_counter() - t0
+        run(n_warm, False)
+        sync()
+        t0 = time.perf_counter()
+        run(n_steps, True)
+        sync()
+        elapsed = time.perf_counter() - t0
+        return {"elapsed": elapsed, "tally": tally, "kernel_ms": {k: float(np.mean(v)) for k, v in ms.items()}, "st": dict(last),
+                "info": info, "n_scene": n_scene, "n_ref_total": n_ref_total, "depth": depth, "det": det, "scene": scene,
+                "model_step": model_step}
+
+    def run_c5(n_steps, n_warm):
+        """C5: four resident tables x 8 crops per rank through ppf_batch_run (timing on: kernel times summed over the matches)."""
+        models = W.c5_models()
+        dets = [PPF3DDetector(W.C5_MODEL_STEP, W.REL_DISTANCE).trainModel(m) for m in models]
+        crops = W.c5_crops(rank, models=models)
+        d_crops = [torch.from_numpy(c).cuda() for c in crops]
+        bm = BatchMatcher(lanes=int(os.environ.get("PPF_BATCH_LANES", "4")), timing=True)
+        tally = {"votes": 0, "pairs": 0, "atomics": 0}
+        ms = {"k_pairs": [], "k_group": [], "k_vote": []}
+
+        def run(n, timed):
+            for _ in range(n):
+                res = bm.run_device(dets, [t.data_ptr() for t in d_crops], [c.shape[0] for c in crops], 6, W.SCENE_STEP,
+                                    W.REL_DISTANCE, presampled=True, top_k=W.TOP_K)
+                if world > 1:
+                    parallel.gather_device(res["d_top"], dist)
+                if timed:
+                    tally["votes"] += res["n_votes"]; tally["pairs"] += res["n_pairs"]
+                    tally["atomics"] += res.get("n_lds_atomics", 0)
+                    ms["k_vote"].append(res["ms_vote_kernel"]); ms["k_pairs"].append(res["ms_pair_kernel"])
+                    ms["k_group"].append(res["ms_group_kernel"])
+
+        run(n_warm, False)
+        sync()
+        t0 = time.perf_counter()
+        run(n_steps, True)
+        sync()
+        elapsed = time.perf_counter() - t0
+        return {"elapsed": elapsed, "tally": tally, "kernel_ms": {k: float(np.mean(v)) for k, v in ms.items()},
+                "info": dets[0].info(), "n_models": len(dets), "n_crops": len(crops), "lanes": bm.lanes,
+                "n_scene": W.C2["n_points"]}
+
+    def describe(config, shard=False):
+        if config == "c2":
+            return ("C2: bottle model (2,000 sampled pts, step 0.036) vs one 50,000-pt synthetic crop per GPU "
+                    "(presampled, every point paired), reference stride 20 -> 2,500 reference points, 30 alpha bins"
+                    + ("" if world == 1 else f"; C3: {world} crops, one per GPU, seeds 1000+rank"))
+        if config == "c4":
+            return ("C4: bottle model sampled at 0.0135 (~10k pts) vs one 200,000-pt synthetic scene (presampled), "
+                    "reference stride 20 -> 10,000 reference points, 30 alpha bins"
+                    + (f"; reference points strided over {world} ranks, raw poses all_gathered, clustered on rank 0"
+                       if shard else ("" if world == 1 else f"; {world} replicas")))
+        return (f"C5: 4 resident model tables (bottle, box, cylinder, torus at step 0.036) x "
+                f"{W.C5_CROPS_PER_RANK} crops of 50,000 pts per GPU, every crop matched against every table "
+                f"through ppf_batch_run (32 matches per step per GPU)")
+
+    def leg_fields(config, r, n_steps):
+        """The per-configuration figures shared by the main line and other_configs: times, rates, kernel times, rooflines."""
+        votes_step = r["tally"]["votes"] // n_steps
+        pairs_step = r["tally"]["pairs"] // n_steps
+        atom_step = r["tally"]["atomics"] / n_steps if r["tally"]["atomics"] else None
+        info = r["info"]
+        n_ref = r["st"]["n_ref"] if "st" in r else r["n_models"] * r["n_crops"] * ((r["n_scene"] + step_stride - 1) // step_stride)
+        abytes = algorithmic_bytes(n_ref, info["n_ref"], info["num_angles"], pairs_step, votes_step)
+        roof, issue, ldsr = counter_rooflines(config, votes_step, r["kernel_ms"]["k_vote"], abytes, atom_step, src_hash)
+        return {"ms_per_step": r["elapsed"] / n_steps * 1e3, "steps": n_steps,
+                "pair_matches_per_s": r["tally"]["votes"] / r["elapsed"], "scene_pairs_per_s": r["tally"]["pairs"] / r["elapsed"],
+                "votes_per_step_per_gpu": votes_step, "kernel_ms": r["kernel_ms"],
+                "roofline": roof, "issue_roofline": issue, "lds_roofline": ldsr}
+
+    shard_refs = args.config == "c4" and args.shard == "refs" and world > 1
+    scaling = "strong" if shard_refs else "weak"
+    if args.config == "c5":
+        res = run_c5(args.steps, args.warmup)
+    else:
+        res = run_single(args.config, args.steps, args.warmup, cells=args.cells, depth_arg=args.pipeline_depth, shard=shard_refs)
+    if args.config != "c2":
+        args.no_cpu_baseline = True
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    tot = torch.tensor([float(tally["votes"]), float(tally["pairs"])], dtype=torch.float64, device=red_dev)
+    t = torch.tensor([res["elapsed"]], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(res["tally"]["votes"]), float(res["tally"]["pairs"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -366,6 +566,7 @@ def main(argv=None):
     all_votes, all_pairs = float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
+        info = res["info"]
         line = {
             "metric": "PPF pair-matches/sec (accumulator votes) per cropped scene",
             "value": all_votes / elapsed,
@@ -379,90 +580,61 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "u32 votes / f64 pair features",
             "data": "synthetic",
-            "config": {"workload": workload, "n_model": info["n_ref"], "n_scene": n_scene,
+            "config": {"workload": describe(args.config, shard_refs), "n_model": info["n_ref"], "n_scene": res["n_scene"],
                        "n_tiles": info["n_tiles"], "tile_refs": info["tile_refs"], "table_buckets": info["n_buckets"],
                        "table_entries": info["n_entries"],
                        "parallelism": (f"reference points strided over {world} ranks, RCCL all_gather of raw poses"
                                        if shard_refs else
                                        f"crops sharded 1/GPU x{world}, RCCL all_gather of top-{W.TOP_K} poses only")},
             "scene_pairs_per_s": all_pairs / elapsed,
+            "kernel_source_hash": src_hash,
         }
+        leg = leg_fields(args.config, res, args.steps)
+        line["votes_per_step_per_gpu"] = leg["votes_per_step_per_gpu"]
+        line["kernel_ms"] = leg["kernel_ms"]
+        if world == 1:
+            line["roofline"], line["issue_roofline"], line["lds_roofline"] = leg["roofline"], leg["issue_roofline"], leg["lds_roofline"]
+        else:  # counter passes are single-GPU runs
+            line["roofline"], line["issue_roofline"], line["lds_roofline"] = None, None, leg["lds_roofline"]
         if args.config == "c5":
-            n_match = len(dets) * len(crops)
-            line["crops_per_s"] = world * len(crops) * args.steps / elapsed
+            n_match = res["n_models"] * res["n_crops"]
+            line["crops_per_s"] = world * res["n_crops"] * args.steps / elapsed
             line["matches_per_s"] = world * n_match * args.steps / elapsed
-            line["votes_per_step_per_gpu"] = tally["votes"] // args.steps
-            line["config"]["batch_lanes"] = bm.lanes
-            line["roofline"] = None
+            line["config"]["batch_lanes"] = res["lanes"]
             line["cpu_baseline"] = None
         else:
-            st = last
+            st = res["st"]
             line["config"]["n_ref"] = st["n_ref"]
-            line["config"]["pipeline_depth"] = depth
+            line["config"]["pipeline_depth"] = res["depth"]
             line["poses_per_s"] = world * st["n_ref"] * args.steps / elapsed
-            line["votes_per_step_per_gpu"] = st["n_votes"]
             line["clustered_poses"] = st.get("n_poses", 0)
             line["scratch_bytes"] = st.get("scratch_bytes", None)
             line["batches_per_step"] = st.get("n_batches", None)
             line["acc32_items_per_step"] = st.get("n_acc32_items", None)  # (reference point, tile)s voted with 32-bit cells (0: all 16-bit)
-            avg_vote_s = float(np.mean(vote_ms)) * 1e-3
-            line["kernel_ms"] = {"k_pairs": float(np.mean(pair_ms)), "k_group": float(np.mean(group_ms)),
-                                 "k_vote": float(np.mean(vote_ms)), "device_total": float(np.mean(dev_ms))}
-            abytes = algorithmic_bytes(st["n_ref"], info["n_ref"], info["num_angles"], st["n_pairs"], st["n_votes"])
-            pmc = committed_counters(st["n_votes"]) if world == 1 else None
-            traffic = (pmc.get("hbm_bytes_per_step_k_vote") or pmc.get("hbm_bytes_per_launch_k_vote", {}).get("gfx950_corrected_2xFETCH")) if pmc else None
-            src = pmc["file"] if pmc else None
-            achieved = traffic / avg_vote_s / 1e9 if traffic else None
-            line["roofline"] = {
-                "bound": "hbm", "kernel": "k_vote",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                "traffic": traffic, "traffic_source": src,
-                "avg_kernel_ms": avg_vote_s * 1e3,
-                "algorithmic_bytes_per_launch": abytes,
-                "note": "achieved = measured fabric bytes of k_vote per step (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC "
-                        "pass) / its HIP-event time of this run.  The section 8d figure (16 B per vote) is kept as "
-                        "algorithmic_bytes_per_launch only: the accumulator lives in LDS and a model entry is read once "
-                        "per run of hits.  What bounds the kernel is the LDS instruction rate, see issue_roofline / lds_roofline",
-            }
-            # instruction issue: what the kernel is actually bound by (SQ counters of the committed pass)
-            issue = (pmc or {}).get("k_vote_issue")
-            lds_instr_peak = 256 * 2.4e9 / 4.38  # ds_add_u32: one 64-lane wave-instruction per 4.38 cycles per CU (r01 ubench)
-            line["issue_roofline"] = None if not issue else {
-                "kernel": "k_vote", "source": src,
-                "valu_busy_frac_of_simd_time": issue["valu_busy_frac_of_simd_time"],
-                "any_inst_busy_frac_of_simd_time": issue["any_inst_busy_frac_of_simd_time"],
-                "lds_busy_frac_of_simd_time": issue["lds_busy_frac_of_simd_time"],
-                "lds_wave_instr_per_s": issue["lds_wave_instructions_sampled"] / avg_vote_s,
-                "lds_wave_instr_peak_per_s": lds_instr_peak,
-                "frac_of_lds_instr_peak": issue["lds_wave_instructions_sampled"] / avg_vote_s / lds_instr_peak,
-                "lds_bank_conflict_frac_of_lds_cycles": issue["lds_bank_conflict_frac_of_lds_cycles"],
-                "valu_wave_instr_per_s": issue["valu_wave_instructions_sampled"] / avg_vote_s,
-                "valu_wave_instr_peak_per_s": 1024 * 2.4e9 / 4.45,
-                "frac_of_valu_issue_peak": issue["valu_wave_instructions_sampled"] / avg_vote_s / (1024 * 2.4e9 / 4.45),
-                "note": "SQ_INSTS_LDS of one step / k_vote time against one 64-lane LDS wave-instruction per 4.38 cycles per CU "
-                        "(conflict-free ds_add_u32, profiles/r01_ubench_valu_lds.txt; with scattered addresses an atomic or a "
-                        "read costs the pipe about 7 cycles, profiles/r02_ubench_lds_ops.txt, so the kernel's mix sits closer to "
-                        "the pipe's limit than this fraction says; lds_bank_conflict_frac_of_lds_cycles = SQ_LDS_BANK_CONFLICT / "
-                        "SQ_LDS_IDX_ACTIVE).  VALU: SQ_INSTS_VALU against 1024 SIMDs x 2.4 GHz / 4.45 cycles; busy fractions = "
-                        "SQ_ACTIVE_INST_* / (SQ_WAVE_CYCLES / 4)",
-            }
-            atom = tally["atomics"] / args.steps if tally["atomics"] else None
-            line["lds_roofline"] = {
-                "kernel": "k_vote", "unit": "LDS atomic lane-ops/s",
-                "lds_atomics_per_launch": atom,
-                "achieved": atom / avg_vote_s if atom else None,
-                "peak_ubench": LDS_ATOMIC_PEAK_UBENCH, "peak_guide": LDS_ATOMIC_PEAK_GUIDE,
-                "frac_ubench": atom / avg_vote_s / LDS_ATOMIC_PEAK_UBENCH if atom else None,
-                "frac_guide": atom / avg_vote_s / LDS_ATOMIC_PEAK_GUIDE if atom else None,
-                "votes_per_lds_atomic": st["n_votes"] / atom if atom else None,
-                "votes_per_s_kernel": st["n_votes"] / avg_vote_s,
-                "source": "profiles/r01_ubench_valu_lds.txt; MI355X_MICROARCH.md (ds_write-class op: 16 lanes/clk/CU)",
-            }
+            if world == 1 and args.config == "c2" and not args.no_other_configs:
+                # the entry the reference's detector.match() binds to, from host memory, on the same crop
+                line["host_entry"] = host_entry(res["det"], res["scene"], st["n_ref"], line["ms_per_step"])
             if world == 1 and not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(model_step, bottle, scene, n_ref_total, args.cpu_seconds)
+                line["cpu_baseline"] = cpu_baseline(res["model_step"], bottle, res["scene"], res["n_ref_total"], args.cpu_seconds)
             else:
                 line["cpu_baseline"] = None
+            if world == 1 and args.config == "c2" and not args.no_other_configs:
+                # the other single-GPU configurations of BASELINE.json under the same clock: 2 steps each
+                del res
+                torch.cuda.empty_cache()
+                other = {}
+                r4 = run_single("c4", 2, 1)
+                other["c4"] = dict(leg_fields("c4", r4, 2), workload=describe("c4"), n_model=r4["info"]["n_ref"],
+                                   n_ref=r4["st"]["n_ref"], batches_per_step=r4["st"].get("n_batches"),
+                                   acc32_items_per_step=r4["st"].get("n_acc32_items"),
+                                   poses_per_s=r4["st"]["n_ref"] * 2 / r4["elapsed"])
+                del r4
+                r5 = run_c5(2, 1)
+                other["c5"] = dict(leg_fields("c5", r5, 2), workload=describe("c5"), batch_lanes=r5["lanes"],
+                                   crops_per_s=r5["n_crops"] * 2 / r5["elapsed"],
+                                   matches_per_s=r5["n_models"] * r5["n_crops"] * 2 / r5["elapsed"],
+                                   kernel_ms_note="sums over the 32 matches of a step; the lanes overlap, so they exceed ms_per_step")
+                line["other_configs"] = other
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

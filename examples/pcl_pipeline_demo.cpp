@@ -28,7 +28,13 @@ int main(int argc, char** argv) {
     PPFEstimation<PointNormal, PointNormal, PPFSignature> ppf_estimator;
     ppf_estimator.setInputCloud(cloud_model);
     ppf_estimator.setInputNormals(cloud_model);
-    ppf_estimator.compute(*cloud_model_ppf);
+    ppf_estimator.compute(*cloud_model_ppf); /* N x N PPFSignature rows, as PCL materialises them */
+    {
+      const size_t N = cloud_model->size();
+      const PPFSignature& s01 = cloud_model_ppf->points[1]; /* pair (0, 1) */
+      std::cout << "FEATURES rows=" << cloud_model_ppf->size() << " n=" << N << " pair01=" << s01.f1 << "," << s01.f2 << "," << s01.f3 << ","
+                << s01.f4 << "," << s01.alpha_m << " diag_nan=" << (cloud_model_ppf->points[0].f1 != cloud_model_ppf->points[0].f1) << std::endl;
+    }
     PPFHashMapSearch::Ptr hashmap_search(new PPFHashMapSearch(12.0f / 180.0f * 3.14159265f, 0.012f));
     hashmap_search->setInputFeatureCloud(cloud_model_ppf);
     PPFRegistration<PointNormal, PointNormal> ppf_registration;

@@ -30,7 +30,7 @@ class Cloud {
   /* rows of `cols` (3 or 6) floats, `strideFloats` apart */
   static Cloud fromRows(const float* rows, int n, int strideFloats, int cols) {
     ppf_cloud* c = nullptr;
-    ppf_match_3d::check(ppf_cloud_upload(rows, n, strideFloats, cols, &c));
+    ppf_match_3d::check(ppf_cloud_upload(rows, n, strideFloats, PPF_NOFF_MAT, cols, &c));
     return Cloud(c);
   }
   static Cloud fromXYZ(const float* xyz, int n, int strideFloats = 3) { return fromRows(xyz, n, strideFloats, 3); }

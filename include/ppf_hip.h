@@ -22,6 +22,7 @@
  *                                   explicit HIP stream: the entry bench.py times
  *   ppf_match_batch                 the per-object loop around Matching (CloudProcessing.h:41-45 holds one cloud
  *                                   per detected object, :58 one detector per model): crops x models
+ *   ppf_pair_features               pcl::PPFEstimation::compute (north_star's PCL names; the reference never calls it)
  *   ppf_sample_cloud                samplePCByQuantization inside trainModel/match (A2)
  *   ppf_transform_pc_pose           transformPCPose, src/YOLO_cropping_ppf_test.cpp:125
  *   ppf_icp_refine (+_device)       ICP icp(100, 0.005f, 2.5f, 8); icp.registerModelToScene(model, scene, poses)
@@ -32,9 +33,11 @@
  *   _edges / _to_mat (+ppf_cloud_*) (the PCL stages that produce the matcher's input)
  *
  * Conventions
- *   - Clouds are float32 rows `x y z nx ny nz` (the N x 6 CV_32FC1 Mat that
- *     CloudProcessing.h:163-190 builds); `stride` is the row pitch in floats (6 for a Mat,
- *     12 for pcl::PointNormal), so both host layouts pass without a copy.
+ *   - A cloud argument is (pointer, rows, stride, normal_offset): float32 rows whose first three floats
+ *     are x y z and whose normal sits `normal_offset` floats into the row; `stride` is the row pitch in
+ *     floats.  The N x 6 CV_32FC1 Mat that CloudProcessing.h:163-190 builds is (6, PPF_NOFF_MAT = 3);
+ *     a pcl::PointCloud<pcl::PointNormal> -- x y z 1 | nx ny nz 0 | curvature pad pad pad, the input of
+ *     that function -- is (12, PPF_NOFF_PCL = 4).  Both host layouts pass without a repack.
  *   - Every function returns a ppf_status; no exception crosses this boundary.
  *     ppf_last_error() returns the calling thread's last message.
  *   - "No pose found" is not an error: *n_out = 0 (the wrapper handles it, :450-454).
@@ -56,7 +59,10 @@
 extern "C" {
 #endif
 
-#define PPF_ABI_VERSION 3
+#define PPF_ABI_VERSION 4 /* 4: every cloud argument carries its normal offset (pcl::PointNormal without a repack) */
+
+#define PPF_NOFF_MAT 3 /* x y z nx ny nz */
+#define PPF_NOFF_PCL 4 /* pcl::PointNormal: x y z pad nx ny nz pad curvature pad pad pad (stride 12) */
 
 typedef enum ppf_status {
   PPF_OK = 0,
@@ -181,6 +187,10 @@ typedef struct ppf_batch_stats {
   int32_t n_retries;
   int32_t lanes;
   float ms_wall;     /* host wall clock of the call */
+  /* with ppf_batch_enable_timing: device time of the kernels summed over all matches of the run (HIP events on each lane's
+   * stream; lanes overlap, so the sums exceed the wall clock) */
+  float ms_vote_kernel, ms_pair_kernel, ms_group_kernel;
+  int32_t reserved;
 } ppf_batch_stats;
 
 /* cv::ppf_match_3d::ICP constructor arguments (uniform sampling, one correspondence per point) */
@@ -206,10 +216,12 @@ int ppf_last_error(char* buf, int cap);
 int ppf_device_count(void);
 
 /* ---- model ------------------------------------------------------------------------------ */
-ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train_params* params, ppf_model** out);
+ppf_status ppf_model_train(const float* xyzn, int n, int stride, int normal_offset, const ppf_train_params* params, ppf_model** out);
 ppf_status ppf_model_retain(ppf_model* m);
 ppf_status ppf_model_release(ppf_model* m);
 ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info);
+/* HIP device the model's table lives on (the current device of the thread that trained or loaded it) */
+ppf_status ppf_model_get_device(const ppf_model* m, int* device);
 /* sampled model cloud (n_ref x 6 floats) */
 ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows);
 /* CSR dump for inspection/tests: any pointer may be NULL. bucket_off has n_tiles*(n_buckets+1) u32,
@@ -222,26 +234,34 @@ ppf_status ppf_model_load(const char* path, ppf_model** out);
 /* the same validation without a device (host only): PPF_OK or PPF_ERR_IO */
 ppf_status ppf_model_check_file(const char* path);
 
+/* pcl::PPFEstimation::compute: the n x n pair features of a cloud as float32 rows of five, row i*n + j =
+ * {f1, f2, f3, f4, alpha_m} of the pair (i, j) -- `feature` PPF_FEATURE_PPF: the three acos angles and the distance of the
+ * reference's library; PPF_FEATURE_DARBOUX: pcl::computePairFeatures' values; alpha_m in the engine's frame convention.
+ * Rows i == j and degenerate pairs are NaN.  cap_rows: rows `out` can hold (>= n*n).  Computed on the device. */
+ppf_status ppf_pair_features(const float* xyzn, int n, int stride, int normal_offset, int feature, float* out, size_t cap_rows);
+
 /* ---- matching, host buffers ------------------------------------------------------------- */
-ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                     int estride, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
-ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                         int estride, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
+ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                     int estride, int enoff, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
+ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                         int estride, int enoff, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
                          int* n_ref, ppf_match_stats* stats);
 
 /* Many crops x many models (BASELINE config C5): every scene is uploaded and sampled once and matched against
  * every model.  out holds n_scenes x n_models blocks of `cap` poses (best first), n_out the count of each block.
  * (= ppf_batch_create(min(4, n_scenes)) + ppf_batch_run + ppf_batch_destroy) */
 ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
-                           int sstride, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
+                           int sstride, int snoff, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out);
 /* The reusable form: `lanes` HIP streams, each with its own workspace and pinned staging.  Crop c runs on lane c mod
  * lanes, its matches against all models back to back without host involvement; one synchronisation at the end.
  * scenes_on_device != 0: `scenes` are device pointers (no staging).  out / n_out / stats may be NULL. */
 ppf_status ppf_batch_create(int lanes, ppf_batch** out);
 ppf_status ppf_batch_destroy(ppf_batch* b);
+/* record HIP events around the kernels of every match of the following runs (ppf_batch_stats.ms_*_kernel) */
+ppf_status ppf_batch_enable_timing(ppf_batch* b, int on);
 ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
-                         int sstride, int n_scenes, int scenes_on_device, const ppf_match_params* params, ppf_pose* out, int cap,
-                         int* n_out, ppf_batch_stats* stats);
+                         int sstride, int snoff, int n_scenes, int scenes_on_device, const ppf_match_params* params, ppf_pose* out,
+                         int cap, int* n_out, ppf_batch_stats* stats);
 /* device block of the last run: n_scenes * n_models * cap pose records (zero rows past each count), e.g. for a gather */
 ppf_status ppf_batch_device_block(ppf_batch* b, void** d_poses, int* n_records);
 /* device-to-device copy of the first n_records of that block into d_dst, enqueued on `stream` */
@@ -264,8 +284,8 @@ ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);
 /* Enqueue sampling + voting + pose assembly (+ clustering) on `stream` (a hipStream_t, NULL = default
  * stream).  d_scene/d_edge are DEVICE pointers.  Returns after enqueueing when everything could be
  * sized without a host round trip (presampled clouds); results stay in the workspace. */
-ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride,
-                            const float* d_edge, int ne, int estride, const ppf_match_params* params, void* stream);
+ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride, int snoff,
+                            const float* d_edge, int ne, int estride, int enoff, const ppf_match_params* params, void* stream);
 /* Wait for the workspace's last call and copy results out (any pointer may be NULL). */
 ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* raw_poses, int cap_ref, int* n_ref,
                                  ppf_pose* poses, int cap_poses, int* n_poses, ppf_match_stats* stats);
@@ -273,8 +293,8 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
 ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref, uint64_t* pairs_per_ref, int cap);
 /* Full accumulators (n_ref x n_model*num_angles u32, the reference's `accumulator` array before its
  * argmax scan) of the voted reference points; presampled clouds only.  Debug / parity surface. */
-ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                                  int estride, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
+ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                                  int estride, int enoff, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
                                   int* n_ref);
 /* Size of the cached device block a request of `bytes` is served from (host only, no device needed): classes of 1/8
  * octave, so at most 12.5 % more than asked for.  Test surface of the block cache's keying. */
@@ -300,28 +320,29 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
 
 /* ---- helpers on the path's edges --------------------------------------------------------- */
 /* samplePCByQuantization: returns rows through *n_out (out may be NULL to query) */
-ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
+ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, int normal_offset, double relative_step, float* out, int cap_rows,
                             int* n_out);
-ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* pose16, float* out);
+/* out: n x 6 packed rows */
+ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, int normal_offset, const double* pose16, float* out);
 
 
 /* ---- ICP refinement of matched poses (the step right after the path) ---------------------- */
 /* registerModelToScene(model, scene, poses): every pose moves the model, a multi-level point-to-plane ICP registers
  * the moved model to the scene, and the pose becomes poseICP * pose (pose/q/t/angle/residual are rewritten, votes
  * and model_index kept).  iterations_out (optional) receives the iterations spent per pose.  Host clouds. */
-ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, const float* scene, int n_scene, int sstride,
-                          const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out);
+ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, int mnoff, const float* scene, int n_scene, int sstride,
+                          int snoff, const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out);
 /* same with DEVICE-resident clouds and an explicit hipStream_t (poses_io stays on the host) */
-ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, const float* d_scene, int n_scene, int sstride,
-                                 const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out,
-                                 void* stream);
+ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, int mnoff, const float* d_scene, int n_scene,
+                                 int sstride, int snoff, const ppf_icp_params* params, ppf_pose* poses_io, int n_poses,
+                                 int* iterations_out, void* stream);
 /* registerModelToScene(src, dst, residual, pose): one registration without an initial pose */
-ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const float* dst, int n_dst, int dstride,
+ppf_status ppf_icp_register(const float* src, int n_src, int sstride, int snoff, const float* dst, int n_dst, int dstride, int dnoff,
                             const ppf_icp_params* params, double* pose16_out, double* residual_out, int* iterations_out);
 
 /* ---- the producers of the N x 6 input (CloudProcessing.h:263-427), device-resident between stages ---------- */
-/* cols = 3 (xyz; normals zero) or 6 (xyz + normal) floats per row, `stride` floats between rows */
-ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int cols, ppf_cloud** out);
+/* cols = 3 (xyz; normals zero; normal_offset ignored) or 6 (xyz + the normal at normal_offset), `stride` floats between rows */
+ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int normal_offset, int cols, ppf_cloud** out);
 ppf_status ppf_cloud_release(ppf_cloud* c);
 ppf_status ppf_cloud_size(const ppf_cloud* c, int* n);
 /* rows6: n x 6 floats, curvature: n floats; either may be NULL */

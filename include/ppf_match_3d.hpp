@@ -155,19 +155,22 @@ class PPF3DDetector {
   }
   bool isTrained() const { return model_ != nullptr; }
 
-  void trainModel(const float* xyzn, int rows, int strideFloats) {
+  /* raw rows: x y z first, the normal `normalOffset` floats into each row of `strideFloats` floats (PPF_NOFF_MAT for the
+   * N x 6 Mat, PPF_NOFF_PCL with stride 12 for pcl::PointNormal storage) */
+  void trainModel(const float* xyzn, int rows, int strideFloats, int normalOffset = PPF_NOFF_MAT) {
     ppf_model* m = nullptr;
-    check(ppf_model_train(xyzn, rows, strideFloats, &tp_, &m));
+    check(ppf_model_train(xyzn, rows, strideFloats, normalOffset, &tp_, &m));
     if (model_) ppf_model_release(model_);
     model_ = m;
   }
   void match(const float* scene, int rows, int stride, std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 1.0 / 5.0,
-             double relativeSceneDistance = 0.03) {
-    run(scene, rows, stride, nullptr, 0, 6, results, relativeSceneSampleStep, relativeSceneDistance);
+             double relativeSceneDistance = 0.03, int normalOffset = PPF_NOFF_MAT) {
+    run(scene, rows, stride, normalOffset, nullptr, 0, 6, PPF_NOFF_MAT, results, relativeSceneSampleStep, relativeSceneDistance);
   }
   void match_S2B(const float* scene, int rows, int stride, const float* edge, int erows, int estride,
-                 std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 0.05, double relativeSceneDistance = 0.05) {
-    run(scene, rows, stride, edge, erows, estride, results, relativeSceneSampleStep, relativeSceneDistance);
+                 std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 0.05, double relativeSceneDistance = 0.05,
+                 int normalOffset = PPF_NOFF_MAT, int edgeNormalOffset = PPF_NOFF_MAT) {
+    run(scene, rows, stride, normalOffset, edge, erows, estride, edgeNormalOffset, results, relativeSceneSampleStep, relativeSceneDistance);
   }
 
   /* anything with rows / cols / ptr<float>(i): ppf_match_3d::Mat, cv::Mat */
@@ -248,15 +251,17 @@ class PPF3DDetector {
   void require_trained() const {
     if (!model_) throw Error(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
   }
-  void run(const float* scene, int rows, int stride, const float* edge, int erows, int estride, std::vector<Pose3DPtr>& results,
-           double step, double dist) {
+  void run(const float* scene, int rows, int stride, int noff, const float* edge, int erows, int estride, int enoff,
+           std::vector<Pose3DPtr>& results, double step, double dist) {
     require_trained();
     ppf_match_params p = mp_;
     p.relative_scene_sample_step = step;
     p.relative_scene_distance = dist;
-    int cap = rows + 8, n = 0;
+    /* one clustered pose per voted reference point at most: every (int)(1/step)-th (sampled) scene row */
+    const int every = step > 0 && step <= 1 ? (int)(1.0 / step) : 1;
+    int cap = rows / (every > 0 ? every : 1) + 8, n = 0;
     std::vector<ppf_pose> out((size_t)cap);
-    check(ppf_match(model_, scene, rows, stride, edge, erows, estride, &p, out.data(), cap, &n));
+    check(ppf_match(model_, scene, rows, stride, noff, edge, erows, estride, enoff, &p, out.data(), cap, &n));
     results.clear();
     results.reserve((size_t)n);
     for (int i = 0; i < n; i++) results.push_back(std::make_shared<Pose3D>(out[(size_t)i]));
@@ -290,7 +295,7 @@ class ICP {
   /* one registration from the identity: returns 0, fills residual and the 4x4 src -> dst */
   template <class M> int registerModelToScene(const M& srcPC, const M& dstPC, double& residual, Matx44d& pose) {
     require_cloud(srcPC); require_cloud(dstPC);
-    check(ppf_icp_register(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC),
+    check(ppf_icp_register(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), PPF_NOFF_MAT, dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC), PPF_NOFF_MAT,
                            &prm_, pose.data(), &residual, nullptr));
     return 0;
   }
@@ -306,7 +311,7 @@ class ICP {
       std::memcpy(r.t, p.t, sizeof(r.t));
       r.angle = p.angle; r.alpha = p.alpha; r.residual = p.residual; r.model_index = p.modelIndex; r.num_votes = p.numVotes;
     }
-    check(ppf_icp_refine(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC), &prm_,
+    check(ppf_icp_refine(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), PPF_NOFF_MAT, dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC), PPF_NOFF_MAT, &prm_,
                          recs.data(), (int)recs.size(), nullptr));
     for (size_t i = 0; i < poses.size(); i++) *poses[i] = Pose3D(recs[i]);
     return 0;
@@ -368,15 +373,15 @@ inline void writePLY(const Mat& pc, const char* fileName) {
 inline Mat transformPCPose(const Mat& pc, const Matx44d& pose) {
   if (pc.cols < 6) throw Error(PPF_ERR_INVALID, "transformPCPose: expected an N x 6 cloud");
   Mat out(pc.rows, 6);
-  check(ppf_transform_pc_pose(pc.ptr<float>(0), pc.rows, pc.cols, pose.data(), out.ptr<float>(0)));
+  check(ppf_transform_pc_pose(pc.ptr<float>(0), pc.rows, pc.cols, PPF_NOFF_MAT, pose.data(), out.ptr<float>(0)));
   return out;
 }
 
 inline Mat samplePCByQuantization(const Mat& pc, float sampleStep) {
   int n = 0;
-  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, sampleStep, nullptr, 0, &n));
+  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, PPF_NOFF_MAT, sampleStep, nullptr, 0, &n));
   Mat out(n, 6);
-  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, sampleStep, out.ptr<float>(0), n, &n));
+  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, PPF_NOFF_MAT, sampleStep, out.ptr<float>(0), n, &n));
   return out;
 }
 

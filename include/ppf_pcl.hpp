@@ -25,14 +25,18 @@
  * rounding of a bin edge can land in the neighbouring bin), and the engine's reference frame / alpha convention (the
  * reference's library's, applied to model and scene alike, so alpha differences agree).  Point types only need members
  * x, y, z, normal_x, normal_y, normal_z (pcl::PointNormal qualifies); clouds only need `.points` or to be a
- * std::vector of such points.  Compiles without PCL and without Eigen.
+ * std::vector of such points, and are handed to the engine WHERE THEY ARE (stride 12 floats, normals at float 4 for
+ * pcl::PointNormal): no host-side repack.  Normals are used as given, as PCL does (the reference's Mat adaptor
+ * re-normalises them; ppf_prep_to_mat is that step on the device).  Compiles without PCL and without Eigen.
  */
 #ifndef PPF_PCL_HPP
 #define PPF_PCL_HPP
 
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "ppf_match_3d.hpp"
@@ -40,8 +44,15 @@
 namespace ppfhip {
 namespace pcl_shaped {
 
-struct PointNormal { /* layout-compatible subset of pcl::PointNormal for builds without PCL */
-  float x, y, z, normal_x, normal_y, normal_z;
+/* pcl::PointNormal's storage for builds without PCL: 48 bytes, x y z 1 | normal_x normal_y normal_z 0 | curvature pad pad pad
+ * (PCL aligns the struct to 16 bytes; the float positions are what matters here) */
+struct PointNormal {
+  float x, y, z, pad0;
+  float normal_x, normal_y, normal_z, pad1;
+  float curvature, pad2[3];
+  PointNormal() : x(0), y(0), z(0), pad0(1.f), normal_x(0), normal_y(0), normal_z(0), pad1(0), curvature(0), pad2{0, 0, 0} {}
+  PointNormal(float x_, float y_, float z_, float nx, float ny, float nz)
+      : x(x_), y(y_), z(z_), pad0(1.f), normal_x(nx), normal_y(ny), normal_z(nz), pad1(0), curvature(0), pad2{0, 0, 0} {}
 };
 
 struct PPFSignature {
@@ -60,39 +71,75 @@ namespace detail {
 template <class C> auto pts(const C& c) -> decltype(c.points) const& { return c.points; }
 template <class P> const std::vector<P>& pts(const std::vector<P>& v) { return v; }
 
-/* N x 6 row-major float rows from any cloud of PointNormal-like points (what PointCloudXYZNormalToMat does,
- * CloudProcessing.h:163-190, including the re-normalisation of the normals) */
-template <class CloudT>
-std::vector<float> to_rows(const CloudT& cloud) {
-  const auto& p = pts(cloud);
-  std::vector<float> rows(p.size() * 6);
+/* A cloud of PointNormal-like points as the C-ABI's (pointer, rows, stride, normal_offset): the caller's storage itself
+ * when the point type keeps x y z and normal_x normal_y normal_z as two runs of three consecutive floats (pcl::PointNormal
+ * does: stride 12, normal offset 4), so nothing is repacked on the host -- unlike the reference's
+ * PointCloudXYZNormalToMat (CloudProcessing.h:163-190), which copies every point into an N x 6 Mat first.  Any other
+ * point type is copied into N x 6 rows once.  `keep` holds the caller's cloud (or the copy) alive. */
+struct RowsView {
+  const float* p = nullptr;
+  int n = 0, stride = 6, noff = PPF_NOFF_MAT;
+  std::shared_ptr<void> keep;
+};
+
+template <class CloudPtr>
+RowsView view_of(const CloudPtr& cloud) {
+  RowsView v;
+  const auto& p = pts(*cloud);
+  typedef typename std::decay<decltype(p[0])>::type PointT;
+  v.n = (int)p.size();
+  if (p.empty()) return v;
+  const float* base = &p[0].x;
+  const std::ptrdiff_t oy = &p[0].y - base, oz = &p[0].z - base, nx = &p[0].normal_x - base, ny = &p[0].normal_y - base,
+                       nz = &p[0].normal_z - base;
+  if (sizeof(PointT) % sizeof(float) == 0 && oy == 1 && oz == 2 && nx >= 3 && ny == nx + 1 && nz == nx + 2 &&
+      (std::size_t)(nz + 1) * sizeof(float) <= sizeof(PointT)) {
+    v.p = base;
+    v.stride = (int)(sizeof(PointT) / sizeof(float));
+    v.noff = (int)nx;
+    v.keep = std::make_shared<CloudPtr>(cloud); /* a copy of the caller's smart pointer: the points stay where they are */
+    return v;
+  }
+  auto rows = std::make_shared<std::vector<float>>(p.size() * 6);
   for (std::size_t i = 0; i < p.size(); i++) {
-    float* d = &rows[i * 6];
+    float* d = &(*rows)[i * 6];
     d[0] = p[i].x; d[1] = p[i].y; d[2] = p[i].z;
     d[3] = p[i].normal_x; d[4] = p[i].normal_y; d[5] = p[i].normal_z;
-    const double a = std::sqrt((double)d[3] * d[3] + (double)d[4] * d[4] + (double)d[5] * d[5]);
-    if (a > 0.00001) { d[3] /= (float)a; d[4] /= (float)a; d[5] /= (float)a; }
   }
-  return rows;
+  v.p = rows->data();
+  v.keep = rows;
+  return v;
 }
 }  // namespace detail
 
-/* The "feature cloud" of the PCL pipeline.  PCL materialises N^2 PPFSignature rows here; the engine builds the
- * pair features on the device while training, so this object only carries the model rows to PPFHashMapSearch. */
+/* The feature cloud of the PCL pipeline: PPFEstimation::compute fills `points` with the N x N PPFSignature rows PCL
+ * materialises (row i*N + j = pair (i, j): pcl::computePairFeatures' f1..f4 and alpha_m; rows i == j are NaN), computed on
+ * the device (ppf_pair_features).  PPFHashMapSearch trains from the model rows, which travel along as a view. */
 struct PPFFeatureCloud {
-  std::vector<float> model_rows; /* N x 6 */
+  std::vector<PPFSignature> points;
+  detail::RowsView model;
+  std::size_t size() const { return points.size(); }
   typedef std::shared_ptr<PPFFeatureCloud> Ptr;
 };
 
 template <class PointInT, class PointNT, class PointOutT = PPFSignature>
 class PPFEstimation {
  public:
-  template <class CloudPtr> void setInputCloud(const CloudPtr& cloud) { rows_ = detail::to_rows(*cloud); }
+  template <class CloudPtr> void setInputCloud(const CloudPtr& cloud) { model_ = detail::view_of(cloud); }
   template <class CloudPtr> void setInputNormals(const CloudPtr&) {} /* normals travel with the points */
-  void compute(PPFFeatureCloud& out) { out.model_rows = rows_; }
+  void compute(PPFFeatureCloud& out) {
+    out.model = model_;
+    const std::size_t n = (std::size_t)model_.n;
+    out.points.assign(n * n, PPFSignature());
+    if (n) {
+      static_assert(sizeof(PPFSignature) == 5 * sizeof(float), "PPFSignature must be five packed floats");
+      ppf_match_3d::check(ppf_pair_features(model_.p, model_.n, model_.stride, model_.noff, PPF_FEATURE_DARBOUX,
+                                            reinterpret_cast<float*>(out.points.data()), n * n));
+    }
+  }
 
  private:
-  std::vector<float> rows_;
+  detail::RowsView model_;
 };
 
 class PPFHashMapSearch {
@@ -105,11 +152,14 @@ class PPFHashMapSearch {
   /* trains the device table: the model rows are used as they are (PCL does not resample the model), the distance
    * step is PCL's absolute step expressed relative to the model's bbox diagonal */
   void setInputFeatureCloud(const PPFFeatureCloud::Ptr& features) {
-    const std::vector<float>& r = features->model_rows;
-    const int n = (int)(r.size() / 6);
+    const detail::RowsView& mv = features->model;
+    if (!mv.p || mv.n < 2) throw ppf_match_3d::Error(PPF_ERR_INVALID, "PPFHashMapSearch: empty feature cloud");
+    const float* r = mv.p;
+    const int n = mv.n;
+    const std::size_t st = (std::size_t)mv.stride;
     float lo[3] = {r[0], r[1], r[2]}, hi[3] = {r[0], r[1], r[2]};
     for (int i = 0; i < n; i++)
-      for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], r[(size_t)i * 6 + k]); hi[k] = std::max(hi[k], r[(size_t)i * 6 + k]); }
+      for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], r[(size_t)i * st + k]); hi[k] = std::max(hi[k], r[(size_t)i * st + k]); }
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     diameter_ = std::sqrt(dx * dx + dy * dy + dz * dz);
     ppf_train_params tp;
@@ -122,7 +172,7 @@ class PPFHashMapSearch {
     tp.relative_sampling_step = tp.relative_distance_step; /* only feeds the default clustering threshold */
     tp.num_angles = 2.0 * 3.14159265358979311600 / angle_step_;
     ppf_model* m = nullptr;
-    ppf_match_3d::check(ppf_model_train(r.data(), n, 6, &tp, &m));
+    ppf_match_3d::check(ppf_model_train(r, n, mv.stride, mv.noff, &tp, &m)); /* pcl::PointNormal storage as it is: stride 12, normals at 4 */
     model_.reset(m, [](ppf_model* p) { ppf_model_release(p); });
   }
   float getAngleDiscretizationStep() const { return angle_step_; }
@@ -149,7 +199,7 @@ class PPFRegistration {
   void setPositionClusteringThreshold(float t) { pos_thr_ = t; }
   void setRotationClusteringThreshold(float t) { rot_thr_ = t; }
   template <class CloudPtr> void setInputSource(const CloudPtr&) {} /* the model lives in the search method */
-  template <class CloudPtr> void setInputTarget(const CloudPtr& scene) { scene_rows_ = detail::to_rows(*scene); }
+  template <class CloudPtr> void setInputTarget(const CloudPtr& scene) { scene_ = detail::view_of(scene); }
 
   /* computeTransformation(): votes, clusters; keeps every clustered pose, best first */
   template <class CloudT> void align(CloudT& output) {
@@ -163,10 +213,12 @@ class PPFRegistration {
     mp.pair_radius = 0.5 * (double)search_->getModelDiameter(); /* the radius search of computeTransformation() */
     mp.rot_metric_relative = 1;                                 /* posesWithinErrorBounds(): angle of the relative rotation */
     mp.alpha_range_2pi = 1;                                     /* alpha wrapped into [-pi, pi], bins of the angle discretisation step */
-    const int n = (int)(scene_rows_.size() / 6);
+    const int n = scene_.n;
+    if (!scene_.p || n <= 0) throw ppf_match_3d::Error(PPF_ERR_INVALID, "PPFRegistration: no target cloud");
     std::vector<ppf_pose> out((size_t)n / rate_ + 8);
     int n_out = 0;
-    ppf_match_3d::check(ppf_match(search_->handle(), scene_rows_.data(), n, 6, nullptr, 0, 6, &mp, out.data(), (int)out.size(), &n_out));
+    ppf_match_3d::check(ppf_match(search_->handle(), scene_.p, n, scene_.stride, scene_.noff, nullptr, 0, 6, PPF_NOFF_MAT, &mp, out.data(),
+                                  (int)out.size(), &n_out));
     results_.clear();
     for (int i = 0; i < n_out; i++) {
       PoseWithVotes p;
@@ -188,7 +240,7 @@ class PPFRegistration {
   PPFHashMapSearch::Ptr search_;
   unsigned rate_ = 5;
   float pos_thr_ = -1.f, rot_thr_ = -1.f;
-  std::vector<float> scene_rows_;
+  detail::RowsView scene_;
   std::vector<PoseWithVotes> results_;
   bool converged_ = false;
 };

@@ -22,6 +22,19 @@ def test_plain_invocation_launches_two_ranks():
     assert lines == [{"dry_launch": True, "rank": 0, "local_rank": 0, "world": 2, "dist_world": 2}]
 
 
+def test_a_rank_that_dies_early_ends_the_launch():
+    """Rank 1 exits before the rendezvous: the launcher must notice, stop rank 0 (which would otherwise wait in
+    init_process_group) and return the failing rank's code, well inside the collective's own timeout."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, env=dict(_env(), PPF_BENCH_DRY_FAIL_RANK="1"), timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
+    assert "rank 1 exited with 7" in r.stderr
+    assert time.time() - t0 < 100
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_world_size_mismatch_is_an_error():
     env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"libppf_hip.so lacks {n}"
     assert sorted(_capi._SIGNATURES) == names, "python binding table and header disagree"
-    assert lib().ppf_abi_version() == 3
+    assert lib().ppf_abi_version() == _capi.PPF_ABI_VERSION == 4
 
 
 def test_struct_layouts_match_the_header(tmp_path):
@@ -84,7 +84,7 @@ def test_argument_validation_precedes_any_device_work(bottle):
     out = C.c_void_p()
     tp = TrainParams()
     lib().ppf_default_train_params(C.byref(tp))
-    assert lib().ppf_model_train(None, 10, 6, C.byref(tp), C.byref(out)) == _capi.PPF_ERR_INVALID
+    assert lib().ppf_model_train(None, 10, 6, 3, C.byref(tp), C.byref(out)) == _capi.PPF_ERR_INVALID
     assert "bad argument" in _capi.last_error()
 
 

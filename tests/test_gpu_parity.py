@@ -9,6 +9,7 @@ import pytest
 
 import oracle_lib as O
 from yolo_ppf_pose_estimation_amd import synth
+from yolo_ppf_pose_estimation_amd._capi import PPF_ERR_INVALID, PPFError
 from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector, samplePCByQuantization
 
 pytestmark = pytest.mark.gpu
@@ -201,10 +202,68 @@ def test_edge_helpers_match_the_oracle(bottle):
     from yolo_ppf_pose_estimation_amd.ply import transform_pc_pose
     for step in (0.05, 0.0714, 0.036):
         np.testing.assert_array_equal(samplePCByQuantization(bottle, step), O.sample(bottle, step))
-    # pcl::PointNormal-like pitch (12 floats per row) gives the same result as the packed Mat layout
-    wide = np.zeros((bottle.shape[0], 12), np.float32)
-    wide[:, :6] = bottle
-    np.testing.assert_array_equal(samplePCByQuantization(wide, 0.05), O.sample(bottle, 0.05))
+    # pcl::PointNormal storage (x y z 1 | nx ny nz 0 | curvature pad pad pad: 12 floats per row, the normal at float 4)
+    # gives the same result as the packed Mat layout; the pad and curvature floats hold junk that must never be read
+    wide = point_normal_rows(bottle)
+    np.testing.assert_array_equal(samplePCByQuantization(wide, 0.05, normal_offset=4), O.sample(bottle, 0.05))
     T = np.eye(4); T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]; T[:3, 3] = [0.1, -0.2, 0.3]
     np.testing.assert_allclose(transformPCPose(bottle[:100], T), transform_pc_pose(bottle[:100], T), atol=1e-6)
-    np.testing.assert_allclose(transformPCPose(wide[:100], T), transform_pc_pose(bottle[:100], T), atol=1e-6)
+    np.testing.assert_array_equal(transformPCPose(wide[:100], T, normal_offset=4), transformPCPose(bottle[:100], T))
+
+
+def point_normal_rows(rows6):
+    """rows laid out like pcl::PointNormal: x y z 1 | normal_x normal_y normal_z 0 | curvature and three pad floats (junk here)"""
+    rng = np.random.default_rng(5)
+    wide = rng.normal(size=(rows6.shape[0], 12)).astype(np.float32) * 1e3
+    wide[:, 0:3] = rows6[:, 0:3]
+    wide[:, 3] = 1.0
+    wide[:, 4:7] = rows6[:, 3:6]
+    wide[:, 7] = 0.0
+    return wide
+
+
+def test_point_normal_storage_passes_without_a_repack(bottle):
+    """What /root/reference/include/CloudProcessing.h:163-190 copies point by point into an N x 6 Mat can be handed over
+    where it is: (stride 12, normal_offset 4) through training, match, match_S2B and the raw votes gives bit-identical
+    results to the packed rows, sampled and presampled."""
+    scene, _ = synth.make_scene(bottle, n_points=6000, seed=21)
+    edge = scene[::3].copy()
+    det6 = PPF3DDetector(0.05, 0.05).trainModel(bottle)
+    det12 = PPF3DDetector(0.05, 0.05).trainModel(point_normal_rows(bottle), normal_offset=4)
+    np.testing.assert_array_equal(det6.sampled_model(), det12.sampled_model())
+    for presampled in (True, False):
+        a = det6.raw_votes(scene, 1.0 / 20.0, 0.05, presampled=presampled, edge=edge)
+        b = det12.raw_votes(point_normal_rows(scene), 1.0 / 20.0, 0.05, presampled=presampled, edge=point_normal_rows(edge),
+                            normal_offset=4)
+        np.testing.assert_array_equal(a["triples"], b["triples"])
+        assert a["stats"]["n_votes"] == b["stats"]["n_votes"] and a["stats"]["n_pairs"] == b["stats"]["n_pairs"]
+    pa = det6.match(scene, 1.0 / 20.0, 0.05, presampled=True)
+    pb = det12.match(point_normal_rows(scene), 1.0 / 20.0, 0.05, presampled=True, normal_offset=4)
+    assert len(pa) == len(pb) and all(np.array_equal(x.pose, y.pose) and x.numVotes == y.numVotes for x, y in zip(pa, pb))
+    with pytest.raises(PPFError) as e:  # a normal that would lie outside the row
+        det6.match(point_normal_rows(scene), 1.0 / 20.0, 0.05, presampled=True, normal_offset=10)
+    assert e.value.status == PPF_ERR_INVALID
+
+
+def test_pair_features_equal_the_oracle(bottle):
+    """ppf_pair_features (pcl::PPFEstimation::compute): both feature kinds against the oracle's per-pair functions, from packed
+    rows and from PointNormal storage; diagonal rows are NaN."""
+    from yolo_ppf_pose_estimation_amd.detector import pairFeatures
+    rows = O.sample(bottle, 0.12)
+    n = rows.shape[0]
+    assert 20 < n < 400
+    for feature in (0, 1):
+        got = pairFeatures(rows, feature)
+        np.testing.assert_array_equal(got, pairFeatures(point_normal_rows(rows), feature, normal_offset=4))
+        assert np.isnan(got[np.arange(n), np.arange(n)]).all()
+        rng = np.random.default_rng(feature)
+        for i, j in rng.integers(0, n, size=(60, 2)):
+            if i == j:
+                continue
+            p1, n1, p2, n2 = rows[i, :3], rows[i, 3:], rows[j, :3], rows[j, 3:]
+            r = O.pair_feature_darboux(p1, n1, p2, n2, 0.2, 0.01) if feature else O.pair_feature(p1, n1, p2, n2, 0.2, 0.01)
+            if r is None:
+                assert np.isnan(got[i, j]).all()
+                continue
+            np.testing.assert_array_equal(got[i, j, :4], r[0].astype(np.float32))
+            assert got[i, j, 4] == np.float32(O.alpha(p1, n1, p2))

@@ -10,7 +10,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_hash  # noqa: E402  (the same hash bench.py checks a summary against)
 
 
 STEPS_PROFILED = 3  # tools/pmc_vote.sh runs bench.py --steps 2 --warmup 1: three identical steps
@@ -43,6 +47,7 @@ def main():
         "n_votes_per_step": n_votes,
         "k_vote_launches_per_step": launches,
         "k_vote_ms_per_step_at_collection": kvote_ms,
+        "source_hash": kernel_source_hash(),  # of the tree the passes ran on: bench.py refuses the summary on any other
         "counters": keep,
     }
     if "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
@@ -62,6 +67,7 @@ def main():
             "wave_time_waiting_frac": kv.get("SQ_WAIT_ANY", 0) / kv["SQ_WAVE_CYCLES"],
             "wave_time_issue_stalled_frac": kv.get("SQ_WAIT_INST_ANY", 0) / kv["SQ_WAVE_CYCLES"],
             "lds_bank_conflict_frac_of_lds_cycles": kv.get("SQ_LDS_BANK_CONFLICT", 0) / max(kv.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+            "lds_array_cycles_per_instr": kv.get("SQ_LDS_IDX_ACTIVE", 0) / max(kv.get("SQ_INSTS_LDS", 1), 1),
             "waves_sampled": kv.get("SQ_WAVES"),
             "valu_wave_instructions_sampled": kv.get("SQ_INSTS_VALU"),
             "lds_wave_instructions_sampled": kv.get("SQ_INSTS_LDS"),

@@ -74,7 +74,9 @@ class MatchStats(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("n_votes", C.c_uint64), ("n_hits", C.c_uint64), ("n_lds_atomics", C.c_uint64),
-                ("n_matches", C.c_int32), ("n_retries", C.c_int32), ("lanes", C.c_int32), ("ms_wall", C.c_float)]
+                ("n_matches", C.c_int32), ("n_retries", C.c_int32), ("lanes", C.c_int32), ("ms_wall", C.c_float),
+                ("ms_vote_kernel", C.c_float), ("ms_pair_kernel", C.c_float), ("ms_group_kernel", C.c_float),
+                ("reserved", C.c_int32)]
 
 
 # every symbol include/ppf_hip.h declares (tests/test_capi_symbols.py checks the header against this)
@@ -85,39 +87,42 @@ _SIGNATURES = {
     "ppf_abi_version": (C.c_int, []),
     "ppf_last_error": (C.c_int, [C.c_char_p, C.c_int]),
     "ppf_device_count": (C.c_int, []),
-    "ppf_model_train": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(TrainParams), C.POINTER(C.c_void_p)]),
+    "ppf_model_train": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TrainParams), C.POINTER(C.c_void_p)]),
+    "ppf_pair_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "ppf_model_retain": (C.c_int, [C.c_void_p]),
     "ppf_model_release": (C.c_int, [C.c_void_p]),
     "ppf_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
+    "ppf_model_get_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ppf_model_get_sampled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_model_get_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppf_model_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ppf_model_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ppf_model_check_file": (C.c_int, [C.c_char_p]),
-    "ppf_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+    "ppf_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                             C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_match_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
-                                  C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
+                                  C.c_int, C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_batch_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ppf_batch_destroy": (C.c_int, [C.c_void_p]),
+    "ppf_batch_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ppf_batch_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int,
-                                C.c_int, C.c_int, C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int),
+                                C.c_int, C.c_int, C.c_int, C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(BatchStats)]),
     "ppf_batch_device_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "ppf_batch_copy_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "ppf_raw_votes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+    "ppf_raw_votes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(MatchParams), C.POINTER(Vote), C.POINTER(Pose), C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(MatchStats)]),
     "ppf_workspace_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppf_workspace_destroy": (C.c_int, [C.c_void_p]),
     "ppf_workspace_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ppf_workspace_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
-    "ppf_match_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                   C.POINTER(MatchParams), C.c_void_p]),
+    "ppf_match_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.POINTER(MatchParams), C.c_void_p]),
     "ppf_workspace_results": (C.c_int, [C.c_void_p, C.POINTER(Vote), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int),
                                         C.POINTER(Pose), C.c_int, C.POINTER(C.c_int), C.POINTER(MatchStats)]),
     "ppf_workspace_ref_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
-    "ppf_debug_accumulators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+    "ppf_debug_accumulators": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(MatchParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "ppf_debug_block_size": (C.c_size_t, [C.c_size_t]),
     "ppf_debug_device_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -128,14 +133,14 @@ _SIGNATURES = {
                                            C.c_void_p]),
     "ppf_cluster_poses": (C.c_int, [C.c_void_p, C.POINTER(Pose), C.c_int, C.c_int, C.POINTER(MatchParams),
                                     C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
-    "ppf_sample_cloud": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+    "ppf_sample_cloud": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_int)]),
-    "ppf_transform_pc_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
-    "ppf_icp_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
+    "ppf_transform_pc_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "ppf_icp_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams),
                                  C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
-    "ppf_icp_refine_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
+    "ppf_icp_refine_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams),
                                         C.POINTER(Pose), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
-    "ppf_cloud_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ppf_cloud_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ppf_cloud_release": (C.c_int, [C.c_void_p]),
     "ppf_cloud_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ppf_cloud_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -152,9 +157,14 @@ _SIGNATURES = {
     "ppf_icp_refine_clouds": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(IcpParams), C.POINTER(Pose), C.c_int,
                                         C.POINTER(C.c_int)]),
     "ppf_prep_knn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "ppf_icp_register": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(IcpParams),
+    "ppf_icp_register": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams),
                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
+
+PPF_FEATURE_PPF, PPF_FEATURE_DARBOUX = 0, 1
+PPF_ABI_VERSION = 4   # include/ppf_hip.h
+PPF_NOFF_MAT = 3      # x y z nx ny nz rows (the N x 6 Mat of CloudProcessing.h:163-190)
+PPF_NOFF_PCL = 4      # pcl::PointNormal rows: x y z 1 | nx ny nz 0 | curvature pad pad pad (stride 12)
 
 _lib = None
 
@@ -194,7 +204,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.ppf_abi_version() != 3:
+        if L.ppf_abi_version() != PPF_ABI_VERSION:
             raise ImportError("libppf_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -24,13 +24,13 @@ class DeviceCloud:
         self._ptr = ptr
 
     @classmethod
-    def upload(cls, rows: np.ndarray) -> "DeviceCloud":
+    def upload(cls, rows: np.ndarray, normal_offset: int = 3) -> "DeviceCloud":
         a = np.ascontiguousarray(rows, dtype=np.float32)
         if a.ndim != 2 or a.shape[1] < 3:
             raise PPFError(_capi.PPF_ERR_INVALID, "cloud must be N x 3 (xyz) or N x 6 (xyz + normal) float32")
         cols = 6 if a.shape[1] >= 6 else 3
         out = C.c_void_p()
-        check(lib().ppf_cloud_upload(a.ctypes.data, a.shape[0], a.shape[1], cols, C.byref(out)))
+        check(lib().ppf_cloud_upload(a.ctypes.data, a.shape[0], a.shape[1], normal_offset, cols, C.byref(out)))
         return cls(out)
 
     def __del__(self):

@@ -26,6 +26,7 @@ struct ppf_batch {
   DevBuf<uint32_t> d_meta;
   DevBuf<unsigned long long> d_tot;
   int last_records = 0;
+  bool timing = false; /* ppf_batch_enable_timing: HIP events around the kernels of every match */
 };
 
 ppf_status ppf_batch_create(int lanes, ppf_batch** out) {
@@ -54,6 +55,16 @@ ppf_status ppf_batch_create(int lanes, ppf_batch** out) {
   return PPF_OK;
 }
 
+ppf_status ppf_batch_enable_timing(ppf_batch* b, int on) {
+  if (!b) return fail(PPF_ERR_INVALID, "ppf_batch_enable_timing: NULL");
+  for (auto* w : b->ws) {
+    ppf_status s = ppf_workspace_enable_timing(w, on);
+    if (s != PPF_OK) return s;
+  }
+  b->timing = on != 0;
+  return PPF_OK;
+}
+
 ppf_status ppf_batch_destroy(ppf_batch* b) {
   if (!b) return PPF_OK;
   sync_device(b->device);
@@ -67,8 +78,8 @@ ppf_status ppf_batch_destroy(ppf_batch* b) {
 }
 
 ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
-                         int sstride, int n_scenes, int scenes_on_device, const ppf_match_params* params, ppf_pose* out, int cap,
-                         int* n_out, ppf_batch_stats* stats) {
+                         int sstride, int snoff, int n_scenes, int scenes_on_device, const ppf_match_params* params, ppf_pose* out,
+                         int cap, int* n_out, ppf_batch_stats* stats) {
   if (!b || !models || n_models <= 0 || !scenes || !ns || n_scenes <= 0 || !params || cap <= 0)
     return fail(PPF_ERR_INVALID, "ppf_batch_run: bad argument");
   for (int k = 0; k < n_models; k++)
@@ -76,9 +87,12 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
   ppf_match_params p = *params;
   if (p.skip_clustering) return fail(PPF_ERR_INVALID, "ppf_batch_run: a batch returns clustered poses");
   for (int c = 0; c < n_scenes; c++) {
-    ppf_status s = check_match_args(models[0], scenes[c], ns[c], sstride, nullptr, 0, 6, &p);
+    ppf_status s = check_match_args(models[0], scenes[c], ns[c], sstride, snoff, nullptr, 0, 6, 3, &p);
     if (s != PPF_OK) return s;
   }
+  for (int k = 1; k < n_models; k++) /* every table must live on the device the batch runs on */
+    if (models[k]->device != models[0]->device)
+      return fail(PPF_ERR_INVALID, "ppf_batch_run: model %d lives on device %d, model 0 on device %d", k, models[k]->device, models[0]->device);
   const auto t_start = std::chrono::steady_clock::now();
   const size_t n_match = (size_t)n_scenes * n_models;
   HIPCHK(b->d_out.reserve(n_match * cap));
@@ -87,12 +101,19 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
   b->last_records = (int)(n_match * cap);
   const int words = cap * (int)(sizeof(ppf_pose) / 8);
 
+  struct TimedCall { int lane; size_t ev_base; int n_batches; };
+  std::vector<TimedCall> timed; /* the event sets of this run's matches (timing on): read after the lanes have drained */
+  for (auto* w : b->ws) w->ev_base = 0;
   /* one (crop, model) match on a lane, results saved to the block */
   auto enqueue_pair = [&](int lane, int c, int k) -> ppf_status {
     ppf_workspace* ws = b->ws[lane];
     hipStream_t st = b->streams[lane];
     ppf_status s = match_prepared(models[k], ws, &p, st);
     if (s != PPF_OK) return s;
+    if (b->timing && ws->n_ref > 0) {
+      timed.push_back({lane, ws->ev_base, ws->n_batches});
+      ws->ev_base += (size_t)ws->n_batches * 4; /* the next match on this lane records into its own events */
+    }
     const size_t idx = (size_t)c * n_models + k;
     if (ws->n_ref == 0) {
       HIPCHK(hipMemsetAsync(b->d_out.p + idx * cap, 0, (size_t)cap * sizeof(ppf_pose), st));
@@ -127,7 +148,7 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
       HIPCHK(hipEventRecord(b->pinned_ev[slot], st));
       d_src = b->d_scene[lane]->p;
     }
-    return prepare_scene(b->ws[lane], d_src, ns[c], sstride, nullptr, 0, 6, &p, st);
+    return prepare_scene(b->ws[lane], d_src, ns[c], sstride, snoff, nullptr, 0, 6, 3, &p, st);
   };
 
   std::vector<int> uses(b->lanes, 0);
@@ -163,10 +184,7 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
         /* bigger pools than this (crop, model) match had (the flag says which one was short): match_prepared looks the
          * model's fractions up itself */
         workspace_hold_model(ws, nullptr);
-        ppf_workspace::Learned* fm = nullptr;
-        for (auto& e : ws->frac_by_model)
-          if (e.model == models[k]) fm = &e;
-        if (!fm) { ws->frac_by_model.push_back({models[k], 0.25, 0.4}); fm = &ws->frac_by_model.back(); }
+        ppf_workspace::Learned* fm = workspace_learned(ws, models[k], true);
         const uint32_t flags = meta[idx * 2 + 1];
         at_full = fm->hit >= 1.0;
         if (flags & 3u) fm->hit = std::min(1.0, 2.0 * fm->hit);
@@ -196,15 +214,25 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
       const double fh = lane_hit[(size_t)l * n_models + k], fr = lane_run[(size_t)l * n_models + k];
       if (!(fh > 0)) continue;
       const double hit = std::min(1.0, std::max(1e-3, 1.06 * fh)), run = std::min(1.0, std::max(0.02, 1.10 * fr));
-      bool found = false;
-      for (auto& fm : ws->frac_by_model)
-        if (fm.model == models[k]) { fm.hit = hit; fm.run = run; found = true; }
-      if (!found) ws->frac_by_model.push_back({models[k], hit, run});
+      ppf_workspace::Learned* fm = workspace_learned(ws, models[k], true);
+      fm->hit = hit; fm->run = run;
     }
   }
   if (out) HIPCHK(hipMemcpy(out, b->d_out.p, n_match * cap * sizeof(ppf_pose), hipMemcpyDeviceToHost));
   if (n_out)
     for (size_t idx = 0; idx < n_match; idx++) n_out[idx] = (int)std::min<uint32_t>(meta[idx * 2], (uint32_t)cap);
+  for (const TimedCall& tc : timed) { /* kernel times of every match (retries after an overflow included) */
+    ppf_workspace* ws = b->ws[tc.lane];
+    for (int bi = 0; bi < tc.n_batches; bi++) {
+      const size_t e0 = tc.ev_base + (size_t)bi * 4;
+      float t0 = 0, t1 = 0, t2 = 0;
+      HIPCHK(hipEventElapsedTime(&t0, ws->batch_ev[e0 + 0], ws->batch_ev[e0 + 1]));
+      HIPCHK(hipEventElapsedTime(&t1, ws->batch_ev[e0 + 1], ws->batch_ev[e0 + 2]));
+      HIPCHK(hipEventElapsedTime(&t2, ws->batch_ev[e0 + 2], ws->batch_ev[e0 + 3]));
+      st.ms_pair_kernel += t0; st.ms_group_kernel += t1; st.ms_vote_kernel += t2;
+    }
+  }
+  for (auto* w : b->ws) w->ev_base = 0;
   st.n_matches = (int)n_match;
   st.n_retries = retries;
   st.lanes = b->lanes;
@@ -228,7 +256,7 @@ ppf_status ppf_batch_copy_block(ppf_batch* b, void* d_dst, int n_records, void* 
 }
 
 ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const float* const* scenes, const int* ns,
-                           int sstride, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
+                           int sstride, int snoff, int n_scenes, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
   if (!models || n_models <= 0 || !scenes || !ns || n_scenes <= 0 || !params || !out || cap <= 0 || !n_out)
     return fail(PPF_ERR_INVALID, "ppf_match_batch: bad argument");
   for (int k = 0; k < n_models; k++)
@@ -237,7 +265,7 @@ ppf_status ppf_match_batch(const ppf_model* const* models, int n_models, const f
   ppf_batch* b = nullptr;
   ppf_status s = ppf_batch_create(std::min(4, n_scenes), &b);
   if (s != PPF_OK) return s;
-  s = ppf_batch_run(b, models, n_models, scenes, ns, sstride, n_scenes, 0, params, out, cap, n_out, nullptr);
+  s = ppf_batch_run(b, models, n_models, scenes, ns, sstride, snoff, n_scenes, 0, params, out, cap, n_out, nullptr);
   (void)ppf_batch_destroy(b);
   return s;
 }

@@ -10,6 +10,9 @@
 /* ============================================================================================ */
 namespace {
 
+/* a cloud argument's layout: x y z at floats 0..2, the normal at noff..noff+2, inside rows of `stride` floats */
+bool bad_layout(int stride, int noff) { return stride < 6 || noff < 3 || noff + 3 > stride; }
+
 uint32_t next_pow2(uint32_t v) {
   v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
   return v;
@@ -61,12 +64,12 @@ struct CloudDev {
     return c;
   }
   /* from a device AoS cloud */
-  ppf_status load_device(const float* d_src, int rows, int stride, hipStream_t st) {
+  ppf_status load_device(const float* d_src, int rows, int stride, int noff, hipStream_t st) {
     n = rows;
     pitch = (rows + 63) & ~63;
     HIPCHK(buf.reserve((size_t)6 * std::max(pitch, 64)));
     if (rows > 0) {
-      k_aos_to_soa<<<dim3((rows + 255) / 256), dim3(256), 0, st>>>(d_src, rows, stride, buf.p, pitch);
+      k_aos_to_soa<<<dim3((rows + 255) / 256), dim3(256), 0, st>>>(d_src, rows, stride, noff, buf.p, pitch);
       HIPCHK(hipGetLastError());
     }
     return PPF_OK;
@@ -127,7 +130,7 @@ ppf_status sort_segments(DevBuf<uint32_t>& keys, DevBuf<uint32_t>& vals, DevBuf<
 
 /* Row A2 on the device: d_src is a device AoS cloud; the sampled rows land in `dst` (SoA) and, when asked for,
  * in `host_rows` (N' x 6).  One 4-byte read-back sizes the output. */
-ppf_status device_sample_cloud(const float* d_src, int n, int stride, float step, CloudDev& dst,
+ppf_status device_sample_cloud(const float* d_src, int n, int stride, int noff, float step, CloudDev& dst,
                                std::vector<float>* host_rows, hipStream_t st) {
   const int ns = (int)(1.0 / step);
   DevBuf<uint32_t> bbox, keys, vals, keys2, vals2, starts;
@@ -151,7 +154,7 @@ ppf_status device_sample_cloud(const float* d_src, int n, int stride, float step
   DevBuf<float> aos;
   if (host_rows) HIPCHK(aos.reserve((size_t)std::max<uint32_t>(n_rows, 1) * 6));
   if (n_rows) {
-    k_seg_sum<<<dim3((n_rows + 63) / 64), dim3(64), 0, st>>>(d_src, stride, va, starts.p, (int)n_rows, n, dst.buf.p, dst.pitch,
+    k_seg_sum<<<dim3((n_rows + 63) / 64), dim3(64), 0, st>>>(d_src, stride, noff, va, starts.p, (int)n_rows, n, dst.buf.p, dst.pitch,
                                                           host_rows ? aos.p : nullptr);
     HIPCHK(hipGetLastError());
   }
@@ -165,8 +168,16 @@ ppf_status device_sample_cloud(const float* d_src, int n, int stride, float step
 
 }  // namespace
 
+struct HostCtx; /* warm context of the host-buffer entries (ppf_match_host.h) */
+
+inline uint64_t next_model_serial() {
+  static std::atomic<uint64_t> n{0};
+  return ++n;
+}
+
 struct ppf_model {
   std::atomic<int> refcount{1};
+  const uint64_t serial = next_model_serial(); /* what workspaces remember a model by (an address can be reused by a later model) */
   ppf_train_params params{};
   ppf_model_info info{};
   std::vector<float> sampled; /* host copy, n_ref x 6 */
@@ -181,6 +192,11 @@ struct ppf_model {
   KeyDims kd{};
   uint64_t n_records = 0;
   int device = 0;
+  /* Idle contexts of ppf_match / ppf_raw_votes / ppf_match_clouds on this model: workspace (learned pool sizes, scratch),
+   * stream, pinned staging.  The table itself stays immutable; this list is the only state calls share, under its mutex. */
+  mutable std::mutex ctx_mu;
+  mutable std::vector<HostCtx*> ctx_idle;
+  ~ppf_model();
 };
 
 struct ppf_workspace {
@@ -214,12 +230,14 @@ struct ppf_workspace {
   bool clustered = false;
   ppf_match_stats stats{};
   ppf_model* model = nullptr;           /* retained while the workspace may still read it */
+  bool model_owns_me = false;           /* a context workspace of model->ctx_idle: lives inside its model, holds no reference to it */
   ppf_match_params params{};
   int n_ref = 0, n_ref_total = 0, rows = 0;
   hipStream_t stream = nullptr;
   bool timing = false;
   hipEvent_t ev[2] = {nullptr, nullptr}; /* first kernel start, last kernel end */
   std::vector<hipEvent_t> batch_ev;      /* 4 per batch: k_pairs start / end, k_vote start / end */
+  size_t ev_base = 0;                    /* first event of the current call in batch_ev (a batch context keeps one set per match of a run) */
   int n_batches = 0;
   bool pending = false;
   bool checked = false;                  /* the overflow flag of the pending call has been read */
@@ -227,8 +245,8 @@ struct ppf_workspace {
   double hit_frac = 0.25;                /* expected hits per scene pair: sizes the hit pools, learned from every call */
   bool frac_known = false;               /* false: the next call first COUNTS its hits (one extra pair pass and one wait) */
   double run_frac = 0.4;                 /* expected runs (distinct buckets hit by a reference point) per hit, learned likewise */
-  struct Learned { const ppf_model* model; double hit, run; };
-  std::vector<Learned> frac_by_model;    /* the two fractions remembered per model (batches alternate models) */
+  struct Learned { uint64_t model_serial; double hit, run; };
+  std::vector<Learned> frac_by_model;    /* the two fractions remembered per model, at most 16 (batches alternate models): workspace_learned() */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
   bool acc32 = false;                    /* a 16-bit accumulator cell overflowed with this model: 32-bit cells until the model changes */
   bool force_acc32 = false;              /* PPF_OPT_ACC32 */

@@ -41,7 +41,7 @@ struct IcpJob {
  * once (init_poses[j] may be NULL: register from the identity).  The registrations are independent chains of small
  * kernels, so each runs on its own stream and the host walks them in lock-step: same level, one batch of iterations
  * enqueued on every stream, then one read of every done flag. */
-ppf_status icp_register_many(const float* d_src, int n, int sstride, const float* d_dst, int nd_all, int dstride,
+ppf_status icp_register_many(const float* d_src, int n, int sstride, int snoff, const float* d_dst, int nd_all, int dstride, int dnoff,
                              const ppf_icp_params& prm, const double* const* init_poses, std::vector<IcpJob*>& jobs,
                              double* poses_out /* jobs x 16 */, double* residuals, int* iters_total) {
   const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
@@ -72,11 +72,11 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
       IcpMat44 T0;
       memcpy(T0.m, init_poses[j], sizeof(T0.m));
       k_icp_set_pose<<<dim3(1), dim3(1), 0, st>>>(d_st, T0);
-      k_icp_transform<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, d_st->T, sc.src0.p, nullptr, nullptr, nullptr);
+      k_icp_transform<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, snoff, 1, n, d_st->T, sc.src0.p, nullptr, nullptr, nullptr);
     } else {
-      k_icp_sample<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, 1, n, sc.src0.p, nullptr);
+      k_icp_sample<<<grid(n, 256), dim3(256), 0, st>>>(d_src, sstride, snoff, 1, n, sc.src0.p, nullptr);
     }
-    k_icp_sample<<<grid(nd_all, 256), dim3(256), 0, st>>>(d_dst, dstride, 1, nd_all, sc.dst0.p, nullptr);
+    k_icp_sample<<<grid(nd_all, 256), dim3(256), 0, st>>>(d_dst, dstride, dnoff, 1, nd_all, sc.dst0.p, nullptr);
     /* centre on the average of the two means, scale to unit average distance from the origin */
     for (int mode = 0; mode < 2; mode++) {
       k_icp_chunk_sums<<<grid(chunks_src, 64), dim3(64), 0, st>>>(sc.src0.p, n, mode, sc.sum_src.p);
@@ -111,8 +111,8 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
       IcpMat44 T;
       memcpy(T.m, J.pose, sizeof(T.m));
       k_icp_set_pose<<<dim3(1), dim3(1), 0, J.st>>>(d_st, T);
-      k_icp_transform<<<grid(ns, 256), dim3(256), 0, J.st>>>(sc.src0.p, 6, step, ns, d_st->T, sc.src_pct.p, sc.moved.p, sc.best.p, nullptr);
-      k_icp_sample<<<grid(nd, 256), dim3(256), 0, J.st>>>(sc.dst0.p, 6, step, nd, sc.dst_pcs.p, sc.q4.p);
+      k_icp_transform<<<grid(ns, 256), dim3(256), 0, J.st>>>(sc.src0.p, 6, 3, step, ns, d_st->T, sc.src_pct.p, sc.moved.p, sc.best.p, nullptr);
+      k_icp_sample<<<grid(nd, 256), dim3(256), 0, J.st>>>(sc.dst0.p, 6, 3, step, nd, sc.dst_pcs.p, sc.q4.p);
       k_icp_level_init<<<dim3(1), dim3(1), 0, J.st>>>(d_st, tol_p, max_iter, robust);
       J.launched = 0;
       J.active = true;
@@ -145,7 +145,7 @@ ppf_status icp_register_many(const float* d_src, int n, int sstride, const float
             k_icp_compact<<<dim3(1), dim3(1024), 0, st>>>(sc.owner.p, nd, sc.sel.p, d_st);
             k_icp_chunks<<<dim3(n_chunks), dim3(64), 0, st>>>(sc.sel.p, sc.src_pct.p, sc.dst_pcs.p, sc.parts.p, d_st);
             k_icp_solve<<<dim3(1), dim3(64), 0, st>>>(sc.parts.p, ns, d_st);
-            k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
+            k_icp_transform<<<grid(ns, 256), dim3(256), 0, st>>>(sc.src_pct.p, 6, 3, 1, ns, d_st->PoseX, sc.moved.p, nullptr, sc.best.p, d_st);
           }
           J.launched += std::max(batch, 0);
         }
@@ -251,8 +251,10 @@ ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<IcpJob*>& jobs
   return PPF_OK;
 }
 
-ppf_status icp_check(const char* who, const void* src, int n, int sstride, const void* dst, int nd, int dstride, const ppf_icp_params* prm) {
-  if (!src || !dst || !prm || n <= 0 || nd <= 0 || sstride < 6 || dstride < 6) return fail(PPF_ERR_INVALID, "%s: bad argument", who);
+ppf_status icp_check(const char* who, const void* src, int n, int sstride, int snoff, const void* dst, int nd, int dstride, int dnoff,
+                     const ppf_icp_params* prm) {
+  if (!src || !dst || !prm || n <= 0 || nd <= 0 || bad_layout(sstride, snoff) || bad_layout(dstride, dnoff))
+    return fail(PPF_ERR_INVALID, "%s: bad argument", who);
   if (prm->iterations < 0 || prm->num_levels < 0 || prm->num_levels > 30 || !(prm->tolerance >= 0))
     return fail(PPF_ERR_INVALID, "%s: bad ICP parameters", who);
   if (!have_device()) return fail(PPF_ERR_HIP, "%s: no HIP device (this engine has no CPU fallback)", who);
@@ -271,7 +273,7 @@ void icp_append_pose(ppf_pose* p, const double* inc, double residual) {
   p->residual = residual;
 }
 
-ppf_status icp_refine_device(const float* d_model, int n, int mstride, const float* d_scene, int nd, int sstride,
+ppf_status icp_refine_device(const float* d_model, int n, int mstride, int mnoff, const float* d_scene, int nd, int sstride, int snoff,
                              const ppf_icp_params* prm, ppf_pose* poses, int n_poses, int* iters, hipStream_t st) {
   for (int k0 = 0; k0 < n_poses; k0 += ICP_MAX_JOBS) {
     const int cnt = std::min(ICP_MAX_JOBS, n_poses - k0);
@@ -284,7 +286,7 @@ ppf_status icp_refine_device(const float* d_model, int n, int mstride, const flo
     double inc[ICP_MAX_JOBS * 16], res[ICP_MAX_JOBS];
     int it[ICP_MAX_JOBS];
     for (int j = 0; j < cnt; j++) init[j] = poses[k0 + j].pose;
-    s = icp_register_many(d_model, n, mstride, d_scene, nd, sstride, *prm, init, jobs, inc, res, it);
+    s = icp_register_many(d_model, n, mstride, mnoff, d_scene, nd, sstride, snoff, *prm, init, jobs, inc, res, it);
     if (s != PPF_OK) return s;
     for (int j = 0; j < cnt; j++) {
       icp_append_pose(&poses[k0 + j], inc + j * 16, res[j]);
@@ -294,9 +296,15 @@ ppf_status icp_refine_device(const float* d_model, int n, int mstride, const flo
   return PPF_OK;
 }
 
-ppf_status icp_upload(const float* h, int n, int stride, DevBuf<float>& d) {
+/* host rows (x y z at 0, normal at noff) -> packed device rows of 6 */
+ppf_status icp_upload(const float* h, int n, int stride, int noff, DevBuf<float>& d) {
   HIPCHK(d.reserve((size_t)n * 6));
-  HIPCHK(hipMemcpy2D(d.p, 6 * sizeof(float), h, (size_t)stride * sizeof(float), 6 * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+  if (noff == 3) {
+    HIPCHK(hipMemcpy2D(d.p, 6 * sizeof(float), h, (size_t)stride * sizeof(float), 6 * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMemcpy2D(d.p, 6 * sizeof(float), h, (size_t)stride * sizeof(float), 3 * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy2D(d.p + 3, 6 * sizeof(float), h + noff, (size_t)stride * sizeof(float), 3 * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+  }
   return PPF_OK;
 }
 
@@ -313,52 +321,53 @@ void ppf_default_icp_params(ppf_icp_params* p) {
   p->num_levels = 8;
 }
 
-ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, const float* scene, int n_scene, int sstride,
-                          const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out) {
-  ppf_status s = icp_check("ppf_icp_refine", model, n_model, mstride, scene, n_scene, sstride, params);
+ppf_status ppf_icp_refine(const float* model, int n_model, int mstride, int mnoff, const float* scene, int n_scene, int sstride,
+                          int snoff, const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out) {
+  ppf_status s = icp_check("ppf_icp_refine", model, n_model, mstride, mnoff, scene, n_scene, sstride, snoff, params);
   if (s != PPF_OK) return s;
   if (n_poses < 0 || (n_poses > 0 && !poses_io)) return fail(PPF_ERR_INVALID, "ppf_icp_refine: bad pose list");
   DevBuf<float> dm, ds;
-  if ((s = icp_upload(model, n_model, mstride, dm)) != PPF_OK) return s;
-  if ((s = icp_upload(scene, n_scene, sstride, ds)) != PPF_OK) return s;
-  return icp_refine_device(dm.p, n_model, 6, ds.p, n_scene, 6, params, poses_io, n_poses, iterations_out, nullptr);
+  if ((s = icp_upload(model, n_model, mstride, mnoff, dm)) != PPF_OK) return s;
+  if ((s = icp_upload(scene, n_scene, sstride, snoff, ds)) != PPF_OK) return s;
+  return icp_refine_device(dm.p, n_model, 6, 3, ds.p, n_scene, 6, 3, params, poses_io, n_poses, iterations_out, nullptr);
 }
 
-ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, const float* d_scene, int n_scene, int sstride,
-                                 const ppf_icp_params* params, ppf_pose* poses_io, int n_poses, int* iterations_out, void* stream) {
-  ppf_status s = icp_check("ppf_icp_refine_device", d_model, n_model, mstride, d_scene, n_scene, sstride, params);
+ppf_status ppf_icp_refine_device(const float* d_model, int n_model, int mstride, int mnoff, const float* d_scene, int n_scene,
+                                 int sstride, int snoff, const ppf_icp_params* params, ppf_pose* poses_io, int n_poses,
+                                 int* iterations_out, void* stream) {
+  ppf_status s = icp_check("ppf_icp_refine_device", d_model, n_model, mstride, mnoff, d_scene, n_scene, sstride, snoff, params);
   if (s != PPF_OK) return s;
   if (n_poses < 0 || (n_poses > 0 && !poses_io)) return fail(PPF_ERR_INVALID, "ppf_icp_refine_device: bad pose list");
-  return icp_refine_device(d_model, n_model, mstride, d_scene, n_scene, sstride, params, poses_io, n_poses, iterations_out,
-                           (hipStream_t)stream);
+  return icp_refine_device(d_model, n_model, mstride, mnoff, d_scene, n_scene, sstride, snoff, params, poses_io, n_poses,
+                           iterations_out, (hipStream_t)stream);
 }
 
-ppf_status ppf_icp_register(const float* src, int n_src, int sstride, const float* dst, int n_dst, int dstride,
+ppf_status ppf_icp_register(const float* src, int n_src, int sstride, int snoff, const float* dst, int n_dst, int dstride, int dnoff,
                             const ppf_icp_params* params, double* pose16_out, double* residual_out, int* iterations_out) {
-  ppf_status s = icp_check("ppf_icp_register", src, n_src, sstride, dst, n_dst, dstride, params);
+  ppf_status s = icp_check("ppf_icp_register", src, n_src, sstride, snoff, dst, n_dst, dstride, dnoff, params);
   if (s != PPF_OK) return s;
   if (!pose16_out) return fail(PPF_ERR_INVALID, "ppf_icp_register: pose16_out is NULL");
   DevBuf<float> dsrc, ddst;
-  if ((s = icp_upload(src, n_src, sstride, dsrc)) != PPF_OK) return s;
-  if ((s = icp_upload(dst, n_dst, dstride, ddst)) != PPF_OK) return s;
+  if ((s = icp_upload(src, n_src, sstride, snoff, dsrc)) != PPF_OK) return s;
+  if ((s = icp_upload(dst, n_dst, dstride, dnoff, ddst)) != PPF_OK) return s;
   std::vector<IcpJob*> jobs;
   std::vector<std::unique_ptr<IcpJob>> owned;
   std::unique_lock<std::mutex> pool_lock;
   if ((s = icp_make_jobs(1, nullptr, jobs, owned, pool_lock)) != PPF_OK) return s;
-  return icp_register_many(dsrc.p, n_src, 6, ddst.p, n_dst, 6, *params, nullptr, jobs, pose16_out, residual_out, iterations_out);
+  return icp_register_many(dsrc.p, n_src, 6, 3, ddst.p, n_dst, 6, 3, *params, nullptr, jobs, pose16_out, residual_out, iterations_out);
 }
 
 /* ---- helpers on the path's edges, on the device like everything else ---------------------------------------- */
-ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relative_step, float* out, int cap_rows,
+ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, int noff, double relative_step, float* out, int cap_rows,
                             int* n_out) {
-  if (!xyzn || n <= 0 || stride < 6 || !(relative_step > 0)) return fail(PPF_ERR_INVALID, "ppf_sample_cloud: bad argument");
+  if (!xyzn || n <= 0 || bad_layout(stride, noff) || !(relative_step > 0)) return fail(PPF_ERR_INVALID, "ppf_sample_cloud: bad argument");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_sample_cloud: no HIP device (this engine has no CPU fallback)");
   DevBuf<float> d_raw;
   HIPCHK(d_raw.reserve((size_t)n * stride));
   HIPCHK(hipMemcpy(d_raw.p, xyzn, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
   CloudDev sampled;
   std::vector<float> rows_host;
-  ppf_status s = device_sample_cloud(d_raw.p, n, stride, (float)relative_step, sampled, &rows_host, nullptr);
+  ppf_status s = device_sample_cloud(d_raw.p, n, stride, noff, (float)relative_step, sampled, &rows_host, nullptr);
   if (s != PPF_OK) return s;
   const int rows = (int)(rows_host.size() / 6);
   if (n_out) *n_out = rows;
@@ -369,18 +378,18 @@ ppf_status ppf_sample_cloud(const float* xyzn, int n, int stride, double relativ
   return PPF_OK;
 }
 
-ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, const double* T, float* out) {
-  if (!xyzn || !T || !out || n < 0 || stride < 6) return fail(PPF_ERR_INVALID, "ppf_transform_pc_pose: bad argument");
+ppf_status ppf_transform_pc_pose(const float* xyzn, int n, int stride, int noff, const double* T, float* out) {
+  if (!xyzn || !T || !out || n < 0 || bad_layout(stride, noff)) return fail(PPF_ERR_INVALID, "ppf_transform_pc_pose: bad argument");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_transform_pc_pose: no HIP device (this engine has no CPU fallback)");
   if (n == 0) return PPF_OK;
   DevBuf<float> d_in, d_out;
   DevBuf<double> d_T;
-  ppf_status s = icp_upload(xyzn, n, stride, d_in);
+  ppf_status s = icp_upload(xyzn, n, stride, noff, d_in);
   if (s != PPF_OK) return s;
   HIPCHK(d_out.reserve((size_t)n * 6));
   HIPCHK(d_T.reserve(16));
   HIPCHK(hipMemcpy(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice));
-  k_icp_transform<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_in.p, 6, 1, n, d_T.p, d_out.p, nullptr, nullptr, nullptr);
+  k_icp_transform<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_in.p, 6, 3, 1, n, d_T.p, d_out.p, nullptr, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, d_out.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
   return PPF_OK;

@@ -42,7 +42,7 @@ constexpr unsigned long long ICP_NONE = ~0ull;
 constexpr uint32_t ICP_FLT_MAX_BITS = 0x7f7fffffu;
 
 /* one row through a 4x4 (homogeneous divide) and its rotation block, normal re-normalised: transformPCPose */
-__device__ __forceinline__ void icp_transform_row(const float* __restrict__ p, const double* __restrict__ T, float* __restrict__ o) {
+__device__ __forceinline__ void icp_transform_row(const float* __restrict__ p, const float* __restrict__ pn, const double* __restrict__ T, float* __restrict__ o) {
   double v[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) v[r] = T[r * 4] * (double)p[0] + T[r * 4 + 1] * (double)p[1] + T[r * 4 + 2] * (double)p[2] + T[r * 4 + 3];
@@ -50,7 +50,7 @@ __device__ __forceinline__ void icp_transform_row(const float* __restrict__ p, c
   o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2];
   double nn[3];
 #pragma unroll
-  for (int r = 0; r < 3; r++) nn[r] = T[r * 4] * (double)p[3] + T[r * 4 + 1] * (double)p[4] + T[r * 4 + 2] * (double)p[5];
+  for (int r = 0; r < 3; r++) nn[r] = T[r * 4] * (double)pn[0] + T[r * 4 + 1] * (double)pn[1] + T[r * 4 + 2] * (double)pn[2];
   const double nrm = ppf_sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
   if (nrm > PPF_EPS) { nn[0] /= nrm; nn[1] /= nrm; nn[2] /= nrm; }
   o[3] = (float)nn[0]; o[4] = (float)nn[1]; o[5] = (float)nn[2];
@@ -58,7 +58,7 @@ __device__ __forceinline__ void icp_transform_row(const float* __restrict__ p, c
 
 /* out[i] = T * src[i*step] (transformPCPose followed by samplePCUniform), optional second copy, optional reset of
  * the NN keys of the rows written.  T is read from device memory; `st` (optional) gates on the done flag. */
-__global__ __launch_bounds__(256) void k_icp_transform(const float* __restrict__ src, int stride, int step, int n_out,
+__global__ __launch_bounds__(256) void k_icp_transform(const float* __restrict__ src, int stride, int noff, int step, int n_out,
                                                        const double* __restrict__ T, float* __restrict__ out,
                                                        float* __restrict__ out2, unsigned long long* __restrict__ best,
                                                        const IcpState* __restrict__ st) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_icp_transform(const float* __restrict__
 #pragma unroll
   for (int k = 0; k < 16; k++) M[k] = T[k];
   float o[6];
-  icp_transform_row(src + (size_t)i * step * stride, M, o);
+  icp_transform_row(src + (size_t)i * step * stride, src + (size_t)i * step * stride + noff, M, o);
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     out[(size_t)i * 6 + k] = o[k];
@@ -79,13 +79,13 @@ __global__ __launch_bounds__(256) void k_icp_transform(const float* __restrict__
 }
 
 /* plain strided copy into packed rows (samplePCUniform without a transform) + float4 xyz pack for the NN search */
-__global__ __launch_bounds__(256) void k_icp_sample(const float* __restrict__ src, int stride, int step, int n_out,
+__global__ __launch_bounds__(256) void k_icp_sample(const float* __restrict__ src, int stride, int noff, int step, int n_out,
                                                     float* __restrict__ out, float4* __restrict__ q4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
   const float* p = src + (size_t)i * step * stride;
 #pragma unroll
-  for (int k = 0; k < 6; k++) out[(size_t)i * 6 + k] = p[k];
+  for (int k = 0; k < 3; k++) { out[(size_t)i * 6 + k] = p[k]; out[(size_t)i * 6 + 3 + k] = p[noff + k]; }
   if (q4) q4[i] = make_float4(p[0], p[1], p[2], 0.f);
 }
 

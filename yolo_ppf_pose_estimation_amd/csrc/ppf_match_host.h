@@ -49,11 +49,11 @@ ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on) {
   return PPF_OK;
 }
 
-static ppf_status check_match_args(const ppf_model* m, const void* scene, int ns, int sstride, const void* edge, int ne,
-                                   int estride, const ppf_match_params* p) {
+static ppf_status check_match_args(const ppf_model* m, const void* scene, int ns, int sstride, int snoff, const void* edge, int ne,
+                                   int estride, int enoff, const ppf_match_params* p) {
   if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
-  if (!scene || ns <= 0 || sstride < 6 || !p) return fail(PPF_ERR_INVALID, "match: bad scene argument");
-  if (edge && (ne <= 0 || estride < 6)) return fail(PPF_ERR_INVALID, "match: bad edge argument");
+  if (!scene || ns <= 0 || bad_layout(sstride, snoff) || !p) return fail(PPF_ERR_INVALID, "match: bad scene argument");
+  if (edge && (ne <= 0 || bad_layout(estride, enoff))) return fail(PPF_ERR_INVALID, "match: bad edge argument");
   if (!(p->relative_scene_sample_step <= 1 && p->relative_scene_sample_step > 0))
     return fail(PPF_ERR_INVALID, "match: relativeSceneSampleStep must be in (0, 1]");
   if (!p->presampled && !(p->relative_scene_distance > 0)) return fail(PPF_ERR_INVALID, "match: relativeSceneDistance must be > 0");
@@ -66,48 +66,59 @@ static ppf_status check_match_args(const ppf_model* m, const void* scene, int ns
 }
 
 /* A2: sample the scene (and edge) cloud into the workspace, or take the rows as they are */
-static ppf_status prepare_scene(ppf_workspace* ws, const float* d_scene, int ns, int sstride, const float* d_edge, int ne,
-                                int estride, const ppf_match_params* params, hipStream_t st) {
-  auto load = [&](CloudDev& dst, const float* d_src, int rows, int stride) -> ppf_status {
-    if (params->presampled) return dst.load_device(d_src, rows, stride, st);
-    return device_sample_cloud(d_src, rows, stride, (float)params->relative_scene_distance, dst, nullptr, st);
+static ppf_status prepare_scene(ppf_workspace* ws, const float* d_scene, int ns, int sstride, int snoff, const float* d_edge, int ne,
+                                int estride, int enoff, const ppf_match_params* params, hipStream_t st) {
+  auto load = [&](CloudDev& dst, const float* d_src, int rows, int stride, int noff) -> ppf_status {
+    if (params->presampled) return dst.load_device(d_src, rows, stride, noff, st);
+    return device_sample_cloud(d_src, rows, stride, noff, (float)params->relative_scene_distance, dst, nullptr, st);
   };
-  ppf_status s = load(ws->surf, d_scene, ns, sstride);
+  ppf_status s = load(ws->surf, d_scene, ns, sstride, snoff);
   if (s != PPF_OK) return s;
-  if (d_edge) s = load(ws->edge, d_edge, ne, estride);
+  if (d_edge) s = load(ws->edge, d_edge, ne, estride, enoff);
   ws->has_edge = d_edge != nullptr;
   return s;
 }
 
 static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const ppf_match_params* params, hipStream_t st, bool retry = false);
 
-ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride,
-                            const float* d_edge, int ne, int estride, const ppf_match_params* params, void* stream) {
+ppf_status ppf_match_device(const ppf_model* m, ppf_workspace* ws, const float* d_scene, int ns, int sstride, int snoff,
+                            const float* d_edge, int ne, int estride, int enoff, const ppf_match_params* params, void* stream) {
   if (!ws) return fail(PPF_ERR_INVALID, "ppf_match_device: workspace is NULL");
   if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_device: no HIP device (this engine has no CPU fallback)");
-  ppf_status s = check_match_args(m, d_scene, ns, sstride, d_edge, ne, estride, params);
+  ppf_status s = check_match_args(m, d_scene, ns, sstride, snoff, d_edge, ne, estride, enoff, params);
   if (s != PPF_OK) return s;
   hipStream_t st = (hipStream_t)stream;
-  s = prepare_scene(ws, d_scene, ns, sstride, d_edge, ne, estride, params, st);
+  s = prepare_scene(ws, d_scene, ns, sstride, snoff, d_edge, ne, estride, enoff, params, st);
   if (s != PPF_OK) return s;
   return match_prepared(m, ws, params, st);
 }
 
-/* store the current model's learned hit fraction (at most 16 models are remembered) */
-static void workspace_remember_frac(ppf_workspace* ws) {
-  if (!ws->model || !ws->frac_known) return;
+/* The fractions a workspace has learned for a model (hits per scene pair, runs per hit), keyed by the model's serial
+ * number; create = true makes room for a model it has not met (at most 16 are remembered, the oldest goes). */
+static ppf_workspace::Learned* workspace_learned(ppf_workspace* ws, const ppf_model* m, bool create) {
   for (auto& fm : ws->frac_by_model)
-    if (fm.model == ws->model) { fm.hit = ws->hit_frac; fm.run = ws->run_frac; return; }
+    if (fm.model_serial == m->serial) return &fm;
+  if (!create) return nullptr;
   if (ws->frac_by_model.size() >= 16) ws->frac_by_model.erase(ws->frac_by_model.begin());
-  ws->frac_by_model.push_back({ws->model, ws->hit_frac, ws->run_frac});
+  ws->frac_by_model.push_back({m->serial, 0.25, 0.4});
+  return &ws->frac_by_model.back();
 }
 
-/* the workspace keeps the model alive until its next call (or its destruction): results are fetched later */
+/* store the current model's learned hit fraction */
+static void workspace_remember_frac(ppf_workspace* ws) {
+  if (!ws->model || !ws->frac_known) return;
+  ppf_workspace::Learned* fm = workspace_learned(ws, ws->model, true);
+  fm->hit = ws->hit_frac; fm->run = ws->run_frac;
+}
+
+/* the workspace keeps the model alive until its next call (or its destruction): results are fetched later.  A context
+ * workspace (model_owns_me) lives inside its model and takes no reference. */
 static void workspace_hold_model(ppf_workspace* ws, const ppf_model* m) {
   if (ws->model == m) return;
   ppf_model* old = ws->model;
   ws->model = const_cast<ppf_model*>(m);
+  if (ws->model_owns_me) return;
   if (ws->model) ws->model->refcount.fetch_add(1);
   if (old) (void)ppf_model_release(old);
 }
@@ -118,7 +129,7 @@ ppf_workspace::~ppf_workspace() {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : batch_ev)
     if (e) (void)hipEventDestroy(e);
-  if (model) (void)ppf_model_release(model);
+  if (model && !model_owns_me) (void)ppf_model_release(model);
 }
 
 /* bytes of hit scratch one hit costs: raw {bucket, j} + sorted payload (alpha_s, cell) + its share of the run table */
@@ -146,11 +157,12 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   if (ws->model != m) { /* another model: its own hit density (remembered if it has been here before) */
     workspace_remember_frac(ws);
     ws->acc32 = false;
-    bool found = false;
-    for (auto& fm : ws->frac_by_model)
-      if (fm.model == m) { ws->hit_frac = fm.hit; ws->run_frac = fm.run; found = true; }
-    if (found) ws->frac_known = true;
-    else if (!ws->frac_by_model.empty()) ws->frac_known = false; /* a model this workspace has not met: count first */
+    if (const ppf_workspace::Learned* fm = workspace_learned(ws, m, false)) {
+      ws->hit_frac = fm->hit; ws->run_frac = fm->run;
+      ws->frac_known = true;
+    } else if (!ws->frac_by_model.empty()) {
+      ws->frac_known = false; /* a model this workspace has not met: count first */
+    }
   }
   workspace_hold_model(ws, m);
   HIPCHK(hipGetDevice(&ws->device));
@@ -308,7 +320,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   ws->n_batches = n_batches;
   ws->stats.n_batches = n_batches;
   if (ws->timing)
-    while (ws->batch_ev.size() < (size_t)n_batches * 4) {
+    while (ws->batch_ev.size() < ws->ev_base + (size_t)n_batches * 4) {
       hipEvent_t e = nullptr;
       HIPCHK(hipEventCreate(&e));
       ws->batch_ev.push_back(e);
@@ -321,10 +333,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     if (bi) HIPCHK(hipMemsetAsync(ws->cursors.p, 0, CUR_OVERFLOW * sizeof(uint32_t), st)); /* the overflow word lives on */
     k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
     HIPCHK(hipGetLastError());
-    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 0], st));
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[ws->ev_base + bi * 4 + 0], st));
     launch_pairs(va, darboux, st);
     HIPCHK(hipGetLastError());
-    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 1], st));
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[ws->ev_base + bi * 4 + 1], st));
     k_ref_hits<<<dim3((va.n_ref + 255) / 256), dim3(256), 0, st>>>(va);
     /* k_group takes the reference points with the most hits first */
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.hit_count, va.n_ref, nullptr, ws->perm_group.p, nullptr);
@@ -333,7 +345,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     /* k_vote takes the reference points that will cast the most votes first */
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
-    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 2], st));
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[ws->ev_base + bi * 4 + 2], st));
     const dim3 grid16((unsigned)((size_t)va.n_ref * T)), grid32((unsigned)((size_t)va.n_ref * T * 2));
     if (!acc32_all) {
       va.acc32 = 0;
@@ -347,7 +359,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     else k_vote<false, true><<<g32, dim3(VOTE_BLOCK), lds, st>>>(va);
     va.acc32 = 0;
     HIPCHK(hipGetLastError());
-    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[bi * 4 + 3], st));
+    if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[ws->ev_base + bi * 4 + 3], st));
   }
 
   FinalArgs fa;
@@ -409,9 +421,10 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
         float pr = 0, gr = 0, vo = 0;
         for (int b = 0; b < ws->n_batches; b++) {
           float t0 = 0, t1 = 0, t2 = 0;
-          HIPCHK(hipEventElapsedTime(&t0, ws->batch_ev[b * 4 + 0], ws->batch_ev[b * 4 + 1]));
-          HIPCHK(hipEventElapsedTime(&t1, ws->batch_ev[b * 4 + 1], ws->batch_ev[b * 4 + 2]));
-          HIPCHK(hipEventElapsedTime(&t2, ws->batch_ev[b * 4 + 2], ws->batch_ev[b * 4 + 3]));
+          const size_t e0 = ws->ev_base + (size_t)b * 4;
+          HIPCHK(hipEventElapsedTime(&t0, ws->batch_ev[e0 + 0], ws->batch_ev[e0 + 1]));
+          HIPCHK(hipEventElapsedTime(&t1, ws->batch_ev[e0 + 1], ws->batch_ev[e0 + 2]));
+          HIPCHK(hipEventElapsedTime(&t2, ws->batch_ev[e0 + 2], ws->batch_ev[e0 + 3]));
           pr += t0; gr += t1; vo += t2;
         }
         ws->stats.ms_pair_kernel = pr; ws->stats.ms_group_kernel = gr; ws->stats.ms_vote_kernel = vo;
@@ -465,8 +478,8 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
   return PPF_OK;
 }
 
-static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                           int estride, const ppf_match_params* params, ppf_workspace* ws);
+static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                           int estride, int enoff, const ppf_match_params* params, ppf_workspace* ws);
 
 ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref, uint64_t* pairs_per_ref, int cap) {
   if (!ws || !ws->pending) return fail(PPF_ERR_INVALID, "ppf_workspace_ref_counters: no call in this workspace");
@@ -487,8 +500,8 @@ ppf_status ppf_workspace_ref_counters(ppf_workspace* ws, uint64_t* votes_per_ref
   return PPF_OK;
 }
 
-ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                                  int estride, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
+ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                                  int estride, int enoff, const ppf_match_params* params, uint32_t* acc, size_t cap_words,
                                   int* n_ref) {
   if (!m || !acc || !params) return fail(PPF_ERR_INVALID, "ppf_debug_accumulators: bad argument");
   ppf_match_params p = *params;
@@ -504,7 +517,7 @@ ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns
   ppf_workspace ws;
   ws.acc_dump = dump.p;
   p.skip_clustering = 1;
-  ppf_status s = run_host(m, scene, ns, sstride, edge, ne, estride, &p, &ws);
+  ppf_status s = run_host(m, scene, ns, sstride, snoff, edge, ne, estride, enoff, &p, &ws);
   if (s != PPF_OK) return s;
   HIPCHK(hipMemcpy(acc, dump.p, per_ref * nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (n_ref) *n_ref = nr;
@@ -636,12 +649,106 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
   return PPF_OK;
 }
 
-/* host-buffer conveniences: upload, run on the default stream, download */
-static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                           int estride, const ppf_match_params* params, ppf_workspace* ws) {
+/* ---- host-buffer entries (what detector.match / match_S2B bind to) --------------------------------------------------
+ * The reference calls match() once per detected object, again and again on the same detector
+ * (/root/reference/include/CloudProcessing.h:441-446, :494-499 -- its own "PPF Elapsed Time" bracket).  A call therefore
+ * borrows a WARM context from its model: a workspace that has already sized its hit pools and learned this scene
+ * family's hit density (no counting pass, no scratch allocation), a non-blocking stream, pinned staging for the upload.
+ * Contexts are handed out under the model's mutex, one per call in flight, so concurrent calls on one model from several
+ * host threads stay independent; up to HOST_CTX_KEEP idle ones are kept, the rest are destroyed on return. */
+constexpr size_t HOST_CTX_KEEP = 2;
+
+struct HostCtx {
+  ppf_workspace ws;
+  hipStream_t stream = nullptr;
+  float* pinned[2] = {nullptr, nullptr}; /* scene, edge */
+  size_t pinned_cap[2] = {0, 0};
+  DevBuf<float> d_rows[2];
+  int device = -1;
+  ~HostCtx() {
+    sync_device(device);
+    for (float* p : pinned)
+      if (p) (void)hipHostFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+ppf_model::~ppf_model() {
+  for (HostCtx* c : ctx_idle) delete c;
+}
+
+namespace {
+
+/* RAII loan of a context: returned to the model's idle list when the call succeeded, destroyed otherwise (a failed call
+ * leaves pools and flags in an unknown state; fail() has already drained the device) */
+struct HostLoan {
+  const ppf_model* m;
+  HostCtx* c = nullptr;
+  bool ok = false;
+  explicit HostLoan(const ppf_model* model) : m(model) {}
+  ppf_status open() {
+    {
+      std::lock_guard<std::mutex> g(m->ctx_mu);
+      if (!m->ctx_idle.empty()) { c = m->ctx_idle.back(); m->ctx_idle.pop_back(); }
+    }
+    if (c) return PPF_OK;
+    std::unique_ptr<HostCtx> n(new (std::nothrow) HostCtx());
+    if (!n) return fail(PPF_ERR_NOMEM, "match: out of memory");
+    n->ws.model_owns_me = true;
+    HIPCHK(hipGetDevice(&n->device));
+    HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    c = n.release();
+    return PPF_OK;
+  }
+  ~HostLoan() {
+    if (!c) return;
+    if (ok) {
+      std::lock_guard<std::mutex> g(m->ctx_mu);
+      if (m->ctx_idle.size() < HOST_CTX_KEEP) { m->ctx_idle.push_back(c); c = nullptr; }
+    }
+    delete c;
+  }
+  /* host rows -> pinned staging -> device, all on the context's stream */
+  ppf_status upload(int which, const float* rows, int n, int stride, const float** d_out) {
+    const size_t floats = (size_t)n * stride;
+    if (c->pinned_cap[which] < floats) {
+      if (c->pinned[which]) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->pinned[which])); }
+      c->pinned[which] = nullptr; c->pinned_cap[which] = 0;
+      const size_t want = floats + floats / 4; /* some slack: crops of one camera differ by a few percent */
+      HIPCHK(hipHostMalloc((void**)&c->pinned[which], want * sizeof(float), hipHostMallocDefault));
+      c->pinned_cap[which] = want;
+    }
+    memcpy(c->pinned[which], rows, floats * sizeof(float));
+    HIPCHK(c->d_rows[which].reserve(floats));
+    HIPCHK(hipMemcpyAsync(c->d_rows[which].p, c->pinned[which], floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    *d_out = c->d_rows[which].p;
+    return PPF_OK;
+  }
+};
+
+/* upload + enqueue on a borrowed context; the caller fetches through ppf_workspace_results(&loan.c->ws, ...) */
+ppf_status run_host_warm(HostLoan& loan, const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                         int estride, int enoff, const ppf_match_params* params, bool timing) {
   if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
   if (!have_device()) return fail(PPF_ERR_HIP, "match: no HIP device (this engine has no CPU fallback)");
-  ppf_status s = check_match_args(m, scene, ns, sstride, edge, ne, estride, params);
+  ppf_status s = check_match_args(m, scene, ns, sstride, snoff, edge, ne, estride, enoff, params);
+  if (s != PPF_OK) return s;
+  if ((s = loan.open()) != PPF_OK) return s;
+  if ((s = ppf_workspace_enable_timing(&loan.c->ws, timing ? 1 : 0)) != PPF_OK) return s;
+  const float *d_scene = nullptr, *d_edge = nullptr;
+  if ((s = loan.upload(0, scene, ns, sstride, &d_scene)) != PPF_OK) return s;
+  if (edge && (s = loan.upload(1, edge, ne, estride, &d_edge)) != PPF_OK) return s;
+  return ppf_match_device(m, &loan.c->ws, d_scene, ns, sstride, snoff, d_edge, ne, estride, enoff, params, loan.c->stream);
+}
+
+}  // namespace
+
+/* cold variant on the caller's own workspace and the default stream (debug entry only) */
+static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                           int estride, int enoff, const ppf_match_params* params, ppf_workspace* ws) {
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  if (!have_device()) return fail(PPF_ERR_HIP, "match: no HIP device (this engine has no CPU fallback)");
+  ppf_status s = check_match_args(m, scene, ns, sstride, snoff, edge, ne, estride, enoff, params);
   if (s != PPF_OK) return s;
   DevBuf<float> d_scene, d_edge;
   HIPCHK(d_scene.reserve((size_t)ns * sstride));
@@ -650,29 +757,32 @@ static ppf_status run_host(const ppf_model* m, const float* scene, int ns, int s
     HIPCHK(d_edge.reserve((size_t)ne * estride));
     HIPCHK(hipMemcpy(d_edge.p, edge, (size_t)ne * estride * sizeof(float), hipMemcpyHostToDevice));
   }
-  s = ppf_match_device(m, ws, d_scene.p, ns, sstride, edge ? d_edge.p : nullptr, ne, estride, params, nullptr);
+  s = ppf_match_device(m, ws, d_scene.p, ns, sstride, snoff, edge ? d_edge.p : nullptr, ne, estride, enoff, params, nullptr);
   if (s != PPF_OK) return s;
   HIPCHK(hipStreamSynchronize(nullptr));
   return PPF_OK;
 }
 
-ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                     int estride, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
+ppf_status ppf_match(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                     int estride, int enoff, const ppf_match_params* params, ppf_pose* out, int cap, int* n_out) {
   if (!n_out) return fail(PPF_ERR_INVALID, "ppf_match: n_out is NULL");
   *n_out = 0;
-  ppf_workspace ws;
-  ppf_status s = run_host(m, scene, ns, sstride, edge, ne, estride, params, &ws);
-  if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  HostLoan loan(m);
+  ppf_status s = run_host_warm(loan, m, scene, ns, sstride, snoff, edge, ne, estride, enoff, params, false);
+  if (s == PPF_OK) s = ppf_workspace_results(&loan.c->ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
+  loan.ok = s == PPF_OK || s == PPF_ERR_CAPACITY; /* a too small output buffer leaves the context in order */
   return s;
 }
 
-ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, const float* edge, int ne,
-                         int estride, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
+ppf_status ppf_raw_votes(const ppf_model* m, const float* scene, int ns, int sstride, int snoff, const float* edge, int ne,
+                         int estride, int enoff, const ppf_match_params* params, ppf_vote* votes, ppf_pose* raw_poses, int cap,
                          int* n_ref, ppf_match_stats* stats) {
-  ppf_workspace ws;
-  ppf_status s = ppf_workspace_enable_timing(&ws, 1);
-  if (s == PPF_OK) s = run_host(m, scene, ns, sstride, edge, ne, estride, params, &ws);
-  if (s == PPF_OK) s = ppf_workspace_results(&ws, votes, raw_poses, cap, n_ref, nullptr, 0, nullptr, stats);
+  if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
+  HostLoan loan(m);
+  ppf_status s = run_host_warm(loan, m, scene, ns, sstride, snoff, edge, ne, estride, enoff, params, true);
+  if (s == PPF_OK) s = ppf_workspace_results(&loan.c->ws, votes, raw_poses, cap, n_ref, nullptr, 0, nullptr, stats);
+  loan.ok = s == PPF_OK || s == PPF_ERR_CAPACITY;
   return s;
 }
 

@@ -72,6 +72,30 @@
 #ifndef PPF_AGG_MIN_RECORDS
 #define PPF_AGG_MIN_RECORDS 32 /* ... when the (tile, bucket) holds at least this many pair records */
 #endif
+/* Attribution builds (tools/build_variant.sh + tools/vote_classes.sh, never the product): PPF_ABL_<class>=0 leaves one class of
+ * k_vote's work out, =2 does it twice (table builds: leaving them out would leave loop bounds undefined); the votes are then
+ * wrong and the 16-bit overflow check is off, only times and counters of such a build mean anything.  The difference to the
+ * product build is what the class costs, with the latency it exposes included (profiles/r03_vote_classes.md). */
+#ifndef PPF_ABL_COUNTED
+#define PPF_ABL_COUNTED 1      /* count-table items: the 17 counted atomics per entry and the table-row reads behind them */
+#endif
+#ifndef PPF_ABL_OWNCELL
+#define PPF_ABL_OWNCELL 1      /* count-table items: the one-by-one votes of an entry's own cell */
+#endif
+#ifndef PPF_ABL_BUILD
+#define PPF_ABL_BUILD 1        /* count-table items: the table build (2 = twice) */
+#endif
+#ifndef PPF_ABL_DIRECT_SMALL
+#define PPF_ABL_DIRECT_SMALL 1 /* direct items on at most 32 records (one entry per lane) */
+#endif
+#ifndef PPF_ABL_DIRECT_BIG
+#define PPF_ABL_DIRECT_BIG 1   /* direct items on more than 32 records: 0 = neither loads nor votes, 2 = the record loads without the votes */
+#endif
+#define PPF_ABL_ANY (PPF_ABL_COUNTED != 1 || PPF_ABL_OWNCELL != 1 || PPF_ABL_BUILD != 1 || PPF_ABL_DIRECT_SMALL != 1 || PPF_ABL_DIRECT_BIG != 1)
+
+#ifndef PPF_TWO_QUEUES
+#define PPF_TWO_QUEUES 0 /* 1: k_vote claims count-table items and direct items from two queues, half of the waves preferring each (measured: +2 %, profiles/r03_vote_variants.md) */
+#endif
 #ifndef PPF_PIPE_VALU
 #define PPF_PIPE_VALU 4 /* VALU instructions scheduled between two LDS atomics of the pipelined direct loop */
 #endif
@@ -1013,11 +1037,13 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) { sa[jj] = sa0 + (uint32_t)jj * sta; sb[jj] = sb0 + (uint32_t)jj * stb; }
   }
+#if PPF_ABL_COUNTED
 #pragma unroll
   for (int j = 0; j <= AGG_NY; j++) {
     lds_add(va + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wa[j >> 2], sa[j & 3]));
     lds_add(vb + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wb[j >> 2], sb[j & 3]));
   }
+#endif
   votes += (ca.y - ca.x) + (cb.y - cb.x);
   /* byte addresses into the cell-sorted offsets; reads past a lane's own range stay inside the workgroup's LDS and
    * are never used */
@@ -1026,7 +1052,7 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   const uint32_t ea = base32 + ca.y * 4, eb = base32 + cb.y * 4;
   /* two hits of each entry's cell per step: one ds_read2_b32 fetches both offsets (the LDS pipe is what this kernel runs
    * out of, and a read with scattered addresses costs it as much as an atomic) */
-  while (__any((ia < ea) | (ib < eb))) {
+  while (PPF_ABL_OWNCELL && __any((ia < ea) | (ib < eb))) {
     const bool da0 = ia < ea, da1 = ia + 4u < ea, db0 = ib < eb, db1 = ib + 4u < eb;
     const uint2 oa = lds_ld2(ia), ob = lds_ld2(ib);
     const float xa0 = __builtin_fmaf(am_a, k.S, __uint_as_float(oa.x)), xa1 = __builtin_fmaf(am_a, k.S, __uint_as_float(oa.y));
@@ -1206,6 +1232,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       __syncthreads(); /* previous segment fully consumed (and the accumulator clear, first time) */
       const uint32_t n_seg = min((uint32_t)RUN_SEG, rb.y - seg0);
       uint32_t items = 0;
+      bool heavy_run = false; /* a run k_group filed under "many hits": those come first in every round's run list */
       if (tid < RUN_SEG) {
         uint32_t off = 0, cnt = 0, hs = 0, mm = 0;
         if ((uint32_t)tid < n_seg) {
@@ -1219,6 +1246,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           }
           hs = run.y;
           mm = run.z;
+          heavy_run = run.z >= agg_min;
           if (cnt) {
             if (run.z >= agg_min && cnt >= PPF_AGG_MIN_RECORDS) {
               items = ((run.z + AGG_SUB - 1) / AGG_SUB) * ((cnt + AGG_CHUNK - 1) / AGG_CHUNK);
@@ -1237,6 +1265,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         if (lane >= o) incl += y;
       }
       if (lane == 63) red[wave] = incl;
+#if PPF_TWO_QUEUES
+      { const uint32_t nh = (uint32_t)__popcll(__ballot(heavy_run)); if (lane == 0) red[16 + wave] = nh; }
+#endif
       __syncthreads();
       uint32_t woff = 0, total = 0;
 #pragma unroll
@@ -1247,7 +1278,21 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       }
       if (tid < RUN_SEG) seg_prefix[tid] = woff + incl - items; /* exclusive */
       if (tid < 64) seg_prefix[RUN_SEG + tid] = total;           /* sentinel + padding for the 64-wide look-ahead */
+#if PPF_TWO_QUEUES
+      /* Two queues: the items of the many-hit runs (count tables: LDS-bound) and those of the few-hit runs behind them
+       * (direct votes over whole buckets: bound by the latency of the record loads).  `split` = first item of the second. */
+      {
+        uint32_t n_heavy = 0;
+#pragma unroll
+        for (int kk = 0; kk < RUN_SEG / 64; kk++) n_heavy += red[16 + kk];
+        if (tid == (int)n_heavy && n_heavy < RUN_SEG) red[56] = woff + incl - items;
+        if (tid == 0) { if (n_heavy >= RUN_SEG) red[56] = total; red[48] = 0u; }
+      }
+      __syncthreads();
+      if (tid == 0) red[49] = red[56];
+#else
       if (tid == 0) red[48] = VOTE_WAVES; /* next unclaimed work item (each wave starts with item == its id) */
+#endif
       __syncthreads();
 
       /* Work items are claimed from an LDS counter as waves become free (items differ by orders of magnitude in
@@ -1256,8 +1301,35 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
        * TWO items: while it votes one, the first loads of the next (its hits' alpha_s, its first records) are in
        * flight -- most items are small (a bucket's share of one tile: median 14 records) and would otherwise spend
        * their time waiting for those loads. */
-      int h = 0;
       VoteItem cur, nxt;
+#if PPF_TWO_QUEUES
+      /* Half of the waves (two per SIMD) take from the first queue while it lasts, the other half from the second, so a CU
+       * runs its LDS-bound and its load-bound work side by side instead of one after the other; a wave whose queue is
+       * empty helps with the other one.  Inside a queue the order is k_group's: heaviest first.  A wave's items of ONE
+       * queue still come in increasing order: one look-ahead cursor per queue. */
+      const uint32_t split = red[56];
+      int hq[2] = {0, 0};
+      const int pref = (wave >> 2) & 1; /* waves w, w + 4, w + 8, w + 12 share a SIMD: every SIMD gets two of each kind */
+      auto claim = [&](uint32_t& it_out, int& q_out) -> bool {
+        int q = pref;
+#pragma unroll
+        for (int attempt = 0; attempt < 2; attempt++, q ^= 1) {
+          const uint32_t lim = q == 0 ? split : total;
+          /* an empty queue is left alone once its counter has passed the end (the counter may overshoot by one per wave) */
+          const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48 + q], 1u) : 0u));
+          if (it < lim) { it_out = it; q_out = q; return true; }
+        }
+        return false;
+      };
+      uint32_t item = 0;
+      int q_item = 0;
+      bool have = claim(item, q_item);
+      if (have) vote_locate(cur, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+      while (have) {
+        const bool have_next = claim(item, q_item);
+        if (have_next) vote_locate(nxt, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+#else
+      int h = 0;
       uint32_t item = (uint32_t)wave;
       bool have = item < total;
       if (have) vote_locate(cur, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
@@ -1265,6 +1337,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u));
         const bool have_next = item < total;
         if (have_next) vote_locate(nxt, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+#endif
 #if PPF_PREFETCH < 1
         vote_fetch_hits(cur, lane, a);
 #endif
@@ -1277,6 +1350,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint4* __restrict__ src = cur.src;
           uint4 rec_cur = cur.rec0;
           agg_build(ak, a.s_a64 + cur.g0, a.s_cell + cur.g0, cur.nh, lane);
+#if PPF_ABL_BUILD == 2
+          agg_build(ak, a.s_a64 + cur.g0, a.s_cell + cur.g0, cur.nh, lane);
+#endif
           const double* __restrict__ g_a64 = a.s_a64 + cur.g0;
           for (uint32_t e0 = 0; e0 < c; e0 += 64) {
             const uint32_t e = e0 + (uint32_t)lane;
@@ -1311,6 +1387,20 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = src[u * 64 + lane];
           }
           uint32_t b = 0;
+#if PPF_ABL_DIRECT_BIG != 1
+          if (c > 32) { /* attribution build: these items without their votes (2: the record loads stay) */
+#if PPF_ABL_DIRECT_BIG == 2
+            for (uint32_t e0 = 0; e0 < c; e0 += 64 * VOTE_UNROLL) {
+              load_records<VOTE_UNROLL>(eb, src, min(e0, c > 64u * VOTE_UNROLL ? c - 64u * VOTE_UNROLL : 0u), lane);
+#pragma unroll
+              for (int u = 0; u < VOTE_UNROLL; u++) asm volatile("" ::"v"(eb[u].x), "v"(eb[u].y), "v"(eb[u].z), "v"(eb[u].w));
+            }
+#endif
+            cur = nxt;
+            have = have_next;
+            continue;
+          }
+#endif
           while (b < nfull) {
             load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
             vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
@@ -1325,7 +1415,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             const uint4 rr = cur.rec0;
             const bool second = (lane & 1) != 0;
             const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            vote_hits_single<WRAP>(acc_base, vi, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            if (PPF_ABL_DIRECT_SMALL) vote_hits_single<WRAP>(acc_base, vi, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
             issued += 64ull * (uint32_t)nh;
           } else if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
             const uint32_t e = e0 + ((uint32_t)lane >> 1);
@@ -1422,7 +1512,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       unsigned long long total = *reinterpret_cast<unsigned long long*>(&red[58]);
       /* 16-bit cells: a cell that wrapped or carried into its neighbour makes the votes found differ from the votes issued;
        * the (reference point, tile) is then voted again with 32-bit cells, and nothing of this attempt counts */
-      const bool overflow = !acc32 && (red[50] != red[52] || red[51] != red[53]);
+      const bool overflow = !PPF_ABL_ANY && !acc32 && (red[50] != red[52] || red[51] != red[53]);
       if (overflow) {
         a.ovf_items[item] = 1u;
         a.ovf_list[atomicAdd(&a.cursors[CUR_OVFCOUNT], 1u)] = (uint32_t)r | ((uint32_t)tile << 16);

@@ -231,10 +231,10 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   return PPF_OK;
 }
 
-ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train_params* params, ppf_model** out) {
+ppf_status ppf_model_train(const float* xyzn, int n, int stride, int noff, const ppf_train_params* params, ppf_model** out) {
   if (!out) return fail(PPF_ERR_INVALID, "ppf_model_train: out is NULL");
   *out = nullptr;
-  if (!xyzn || n <= 1 || stride < 6 || !params) return fail(PPF_ERR_INVALID, "ppf_model_train: bad argument");
+  if (!xyzn || n <= 1 || bad_layout(stride, noff) || !params) return fail(PPF_ERR_INVALID, "ppf_model_train: bad argument");
   if (!(params->relative_sampling_step > 0) || !(params->num_angles >= 1))
     return fail(PPF_ERR_INVALID, "ppf_model_train: bad parameters");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_train: no HIP device (this engine has no CPU fallback)");
@@ -252,7 +252,10 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
                                                                                   : params->relative_sampling_step));
   if (params->presampled) {
     m->sampled.resize((size_t)n * 6);
-    for (int i = 0; i < n; i++) memcpy(&m->sampled[(size_t)i * 6], xyzn + (size_t)i * stride, 24);
+    for (int i = 0; i < n; i++) {
+      memcpy(&m->sampled[(size_t)i * 6], xyzn + (size_t)i * stride, 12);
+      memcpy(&m->sampled[(size_t)i * 6 + 3], xyzn + (size_t)i * stride + noff, 12);
+    }
   }
   hipStream_t st = nullptr;
   {
@@ -263,7 +266,7 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
       DevBuf<float> d_raw;
       hipError_t e = d_raw.reserve((size_t)n * stride);
       if (e == hipSuccess) e = hipMemcpy(d_raw.p, xyzn, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice);
-      s0 = e == hipSuccess ? device_sample_cloud(d_raw.p, n, stride, (float)params->relative_sampling_step, m->cloud, &m->sampled, st)
+      s0 = e == hipSuccess ? device_sample_cloud(d_raw.p, n, stride, noff, (float)params->relative_sampling_step, m->cloud, &m->sampled, st)
                            : fail(PPF_ERR_HIP, "ppf_model_train: upload failed: %s", hipGetErrorString(e));
     }
     if (s0 != PPF_OK) return s0;
@@ -305,6 +308,25 @@ ppf_status ppf_model_train(const float* xyzn, int n, int stride, const ppf_train
   return PPF_OK;
 }
 
+ppf_status ppf_pair_features(const float* xyzn, int n, int stride, int noff, int feature, float* out, size_t cap_rows) {
+  if (!xyzn || n <= 0 || bad_layout(stride, noff) || !out || (feature != PPF_FEATURE_PPF && feature != PPF_FEATURE_DARBOUX))
+    return fail(PPF_ERR_INVALID, "ppf_pair_features: bad argument");
+  const size_t rows = (size_t)n * (size_t)n;
+  if (cap_rows < rows) return fail(PPF_ERR_CAPACITY, "ppf_pair_features: need room for %zu rows", rows);
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_pair_features: no HIP device (this engine has no CPU fallback)");
+  DevBuf<float> d_raw, d_out;
+  CloudDev cloud;
+  HIPCHK(d_raw.reserve((size_t)n * stride));
+  HIPCHK(hipMemcpy(d_raw.p, xyzn, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
+  ppf_status s = cloud.load_device(d_raw.p, n, stride, noff, nullptr);
+  if (s != PPF_OK) return s;
+  HIPCHK(d_out.reserve(rows * 5));
+  k_pair_features<<<dim3((unsigned)n), dim3(256)>>>(cloud.view(), feature == PPF_FEATURE_DARBOUX ? 1 : 0, d_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_out.p, rows * 5 * sizeof(float), hipMemcpyDeviceToHost));
+  return PPF_OK;
+}
+
 ppf_status ppf_model_retain(ppf_model* m) {
   if (!m) return fail(PPF_ERR_INVALID, "ppf_model_retain: NULL");
   m->refcount.fetch_add(1);
@@ -321,6 +343,11 @@ ppf_status ppf_model_release(ppf_model* m) {
 ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info) {
   if (!m || !info) return fail(PPF_ERR_INVALID, "ppf_model_get_info: NULL");
   *info = m->info;
+  return PPF_OK;
+}
+ppf_status ppf_model_get_device(const ppf_model* m, int* device) {
+  if (!m || !device) return fail(PPF_ERR_INVALID, "ppf_model_get_device: NULL");
+  *device = m->device;
   return PPF_OK;
 }
 ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows) {

@@ -61,7 +61,7 @@ ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>
   HIPCHK(d2.reserve((size_t)n * k));
   DevBuf<float> scratch;
   HIPCHK(scratch.reserve((size_t)n * 6));
-  k_icp_sample<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, 6, 1, n, scratch.p, q4.p);
+  k_icp_sample<<<grid_for(n, 256), dim3(256)>>>(in->rows.p, 6, 3, 1, n, scratch.p, q4.p);
   /* grid over the bounding box: about sqrt(n)/6 cells along the longest side (a 3x3x3 cube of a surface-like cloud
    * then holds a few hundred points), at most 128 */
   DevBuf<uint32_t> mm;
@@ -114,10 +114,11 @@ ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>
 
 extern "C" {
 
-ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int cols, ppf_cloud** out) {
+ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int noff, int cols, ppf_cloud** out) {
   if (!out) return fail(PPF_ERR_INVALID, "ppf_cloud_upload: out is NULL");
   *out = nullptr;
-  if (!rows || n < 0 || (cols != 3 && cols != 6) || stride < cols) return fail(PPF_ERR_INVALID, "ppf_cloud_upload: bad argument");
+  if (!rows || n < 0 || (cols != 3 && cols != 6) || stride < cols || (cols == 6 && bad_layout(stride, noff)))
+    return fail(PPF_ERR_INVALID, "ppf_cloud_upload: bad argument");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_cloud_upload: no HIP device (this engine has no CPU fallback)");
   std::unique_ptr<ppf_cloud> c;
   ppf_status s = cloud_alloc(c, n);
@@ -126,7 +127,7 @@ ppf_status ppf_cloud_upload(const float* rows, int n, int stride, int cols, ppf_
     DevBuf<float> raw;
     HIPCHK(raw.reserve((size_t)n * stride));
     HIPCHK(hipMemcpy(raw.p, rows, (size_t)n * stride * sizeof(float), hipMemcpyHostToDevice));
-    k_prep_pack<<<grid_for(n, 256), dim3(256)>>>(raw.p, n, stride, cols, c->rows.p, c->curv.p);
+    k_prep_pack<<<grid_for(n, 256), dim3(256)>>>(raw.p, n, stride, noff, cols, c->rows.p, c->curv.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
   }
@@ -358,18 +359,24 @@ ppf_status ppf_match_clouds(const ppf_model* m, const ppf_cloud* scene, const pp
   if (!scene) return fail(PPF_ERR_INVALID, "ppf_match_clouds: scene is NULL");
   if (!m) return fail(PPF_ERR_NOT_TRAINED, "The model is not trained. Cannot match without training");
   if (!have_device()) return fail(PPF_ERR_HIP, "ppf_match_clouds: no HIP device (this engine has no CPU fallback)");
-  ppf_status s = check_match_args(m, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params);
+  ppf_status s = check_match_args(m, scene->rows.p, scene->n, 6, 3, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, 3, params);
   if (s != PPF_OK) return s;
-  ppf_workspace ws;
-  s = ppf_match_device(m, &ws, scene->rows.p, scene->n, 6, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, params, nullptr);
-  if (s == PPF_OK) s = ppf_workspace_results(&ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
+  /* a warm context of the model (ppf_match_host.h); the clouds are resident, so nothing is staged.  The stages that made
+   * them ran on the default stream and waited for it before returning. */
+  HostLoan loan(m);
+  if ((s = loan.open()) != PPF_OK) return s;
+  if ((s = ppf_workspace_enable_timing(&loan.c->ws, 0)) != PPF_OK) return s;
+  s = ppf_match_device(m, &loan.c->ws, scene->rows.p, scene->n, 6, 3, edge ? edge->rows.p : nullptr, edge ? edge->n : 0, 6, 3, params,
+                       loan.c->stream);
+  if (s == PPF_OK) s = ppf_workspace_results(&loan.c->ws, nullptr, nullptr, 0, nullptr, out, cap, n_out, nullptr);
+  loan.ok = s == PPF_OK || s == PPF_ERR_CAPACITY;
   return s;
 }
 
 ppf_status ppf_icp_refine_clouds(const ppf_cloud* model, const ppf_cloud* scene, const ppf_icp_params* params, ppf_pose* poses_io,
                                  int n_poses, int* iterations_out) {
   if (!model || !scene) return fail(PPF_ERR_INVALID, "ppf_icp_refine_clouds: cloud is NULL");
-  return ppf_icp_refine_device(model->rows.p, model->n, 6, scene->rows.p, scene->n, 6, params, poses_io, n_poses, iterations_out, nullptr);
+  return ppf_icp_refine_device(model->rows.p, model->n, 6, 3, scene->rows.p, scene->n, 6, 3, params, poses_io, n_poses, iterations_out, nullptr);
 }
 
 }  // extern "C"

@@ -59,12 +59,15 @@ __global__ __launch_bounds__(256) void k_prep_gather(const float* __restrict__ r
 }
 
 /* rows of `cols` floats at `stride` -> packed rows of 6 (+ zero curvature) */
-__global__ __launch_bounds__(256) void k_prep_pack(const float* __restrict__ src, int n, int stride, int cols, float* __restrict__ rows,
+__global__ __launch_bounds__(256) void k_prep_pack(const float* __restrict__ src, int n, int stride, int noff, int cols, float* __restrict__ rows,
                                                    float* __restrict__ curv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
 #pragma unroll
-  for (int k = 0; k < 6; k++) rows[(size_t)i * 6 + k] = k < cols ? src[(size_t)i * stride + k] : 0.f;
+  for (int k = 0; k < 3; k++) {
+    rows[(size_t)i * 6 + k] = src[(size_t)i * stride + k];
+    rows[(size_t)i * 6 + 3 + k] = cols == 6 ? src[(size_t)i * stride + noff + k] : 0.f;
+  }
   curv[i] = 0.f;
 }
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_seg_starts(const uint32_t* __restrict__
 }
 
 /* one thread per non-empty cell: fp64 sums in ascending point order, mean, re-normalised normal */
-__global__ __launch_bounds__(64) void k_seg_sum(const float* __restrict__ src, int stride, const uint32_t* __restrict__ vals,
+__global__ __launch_bounds__(64) void k_seg_sum(const float* __restrict__ src, int stride, int noff, const uint32_t* __restrict__ vals,
                                                 const uint32_t* __restrict__ starts, int n_rows, int n,
                                                 float* __restrict__ soa, int pitch, float* __restrict__ aos) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void k_seg_sum(const float* __restrict__ src, i
   for (uint32_t k = s; k < e; k++) {
     const float* p = src + (size_t)vals[k] * stride;
 #pragma unroll
-    for (int c = 0; c < 6; c++) acc[c] += (double)p[c];
+    for (int c = 0; c < 3; c++) { acc[c] += (double)p[c]; acc[3 + c] += (double)p[noff + c]; }
   }
   const double cn = (double)(e - s);
 #pragma unroll

@@ -32,12 +32,16 @@ struct SlotWord {
   uint32_t bits_lo, bits_hi, rank, pad;
 };
 
-__global__ void k_aos_to_soa(const float* __restrict__ src, int n, int stride, float* __restrict__ dst, int pitch) {
+/* rows (x y z at 0, normal at noff, pitch stride) -> six planes */
+__global__ void k_aos_to_soa(const float* __restrict__ src, int n, int stride, int noff, float* __restrict__ dst, int pitch) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = src + (size_t)i * stride;
 #pragma unroll
-  for (int k = 0; k < 6; k++) dst[(size_t)k * pitch + i] = p[k];
+  for (int k = 0; k < 3; k++) {
+    dst[(size_t)k * pitch + i] = p[k];
+    dst[(size_t)(3 + k) * pitch + i] = p[noff + k];
+  }
 }
 
 __device__ __forceinline__ ppf_vec3 ld3(const float* a, const float* b, const float* c, int i) {
@@ -87,6 +91,36 @@ __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_st
     pair_slot[idx] = slot;
     pair_alpha[idx] = (float)ppf_model_alpha(R, t, p2);
     atomicOr(&slot_bits[slot >> 6], 1ull << (slot & 63));
+  }
+}
+
+/* pcl::PPFEstimation::compute: row i*n + j = {f1, f2, f3, f4, alpha_m} (float32) of the pair (i, j); NaN rows for i == j and
+ * for the pairs the Darboux feature leaves undefined */
+__global__ __launch_bounds__(256) void k_pair_features(CloudSoA m, int darboux, float* __restrict__ out) {
+  __shared__ double frame[12];
+  const int i = blockIdx.x;
+  const ppf_vec3 p1 = ld3(m.x, m.y, m.z, i), n1 = ld3(m.nx, m.ny, m.nz, i);
+  if (threadIdx.x == 0) ppf_transform_rt(p1, n1, frame, frame + 9);
+  __syncthreads();
+  double R[9], t[3];
+  for (int k = 0; k < 9; k++) R[k] = frame[k];
+  for (int k = 0; k < 3; k++) t[k] = frame[9 + k];
+  const float nanf_ = __uint_as_float(0x7FC00000u);
+  for (int j = threadIdx.x; j < m.n; j += blockDim.x) {
+    float* o = out + ((size_t)i * m.n + j) * 5;
+    const ppf_vec3 p2 = ld3(m.x, m.y, m.z, j), n2 = ld3(m.nx, m.ny, m.nz, j);
+    double f[4] = {0, 0, 0, 0};
+    bool ok = j != i;
+    if (ok) {
+      if (darboux) ok = ppf_pair_feature_darboux(p1, n1, p2, n2, f) != 0;
+      else ppf_pair_feature(p1, n1, p2, n2, f);
+    }
+    if (!ok) {
+      for (int k = 0; k < 5; k++) o[k] = nanf_;
+      continue;
+    }
+    for (int k = 0; k < 4; k++) o[k] = (float)f[k];
+    o[4] = (float)ppf_model_alpha(R, t, p2);
   }
 }
 
@@ -187,7 +221,10 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  */
 
 __device__ uint32_t agg_cell_bits(float am, int A); /* ppf_match_kernels.h */
-constexpr uint32_t DEAL_BANKS = 64; /* LDS banks the dealing order spreads a bucket's entries over */
+#ifndef PPF_DEAL_BANKS
+#define PPF_DEAL_BANKS 32
+#endif
+constexpr uint32_t DEAL_BANKS = PPF_DEAL_BANKS; /* LDS banks the dealing order spreads a bucket's entries over */
 
 __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
                                                   uint32_t* cls, uint32_t* lvl) {

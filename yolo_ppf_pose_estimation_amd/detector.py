@@ -61,9 +61,11 @@ class Pose3D:
         return Pose3D(self.to_record())
 
 
-def _cloud(a, name):
+def _cloud(a, name, normal_offset: int = 3):
+    """A cloud argument: float32 rows with x y z first and the normal `normal_offset` floats into the row (3 for the
+    reference's N x 6 Mat, 4 for rows laid out like pcl::PointNormal); the row pitch is the array's width."""
     a = np.ascontiguousarray(a, dtype=np.float32)
-    if a.ndim != 2 or a.shape[1] < 6 or a.shape[0] < 1:
+    if a.ndim != 2 or a.shape[1] < 6 or a.shape[0] < 1 or normal_offset < 3 or normal_offset + 3 > a.shape[1]:
         raise PPFError(_capi.PPF_ERR_INVALID, f"{name} must be an N x 6 float32 cloud (x y z nx ny nz)")
     return a
 
@@ -135,8 +137,8 @@ class PPF3DDetector:
         return self
 
     # -- training ---------------------------------------------------------------------------------
-    def trainModel(self, model: np.ndarray, presampled: bool = False):
-        pc = _cloud(model, "model")
+    def trainModel(self, model: np.ndarray, presampled: bool = False, *, normal_offset: int = 3):
+        pc = _cloud(model, "model", normal_offset)
         tp = TrainParams()
         lib().ppf_default_train_params(C.byref(tp))
         tp.relative_sampling_step = self.sampling_step_relative
@@ -148,9 +150,16 @@ class PPF3DDetector:
         tp.key_equality = self._key_equality
         tp.feature = self._feature
         out = C.c_void_p()
-        check(lib().ppf_model_train(pc.ctypes.data, pc.shape[0], pc.shape[1], C.byref(tp), C.byref(out)))
+        check(lib().ppf_model_train(pc.ctypes.data, pc.shape[0], pc.shape[1], normal_offset, C.byref(tp), C.byref(out)))
         self._model = _ModelHandle(out.value)
         return self
+
+    def device(self) -> int:
+        """HIP device the trained table lives on."""
+        self._require_trained()
+        d = C.c_int(-1)
+        check(lib().ppf_model_get_device(self._model.ptr, C.byref(d)))
+        return d.value
 
     def info(self) -> dict:
         self._require_trained()
@@ -213,36 +222,38 @@ class PPF3DDetector:
 
     def match(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
               relativeSceneDistance: float = 0.03, *, presampled: bool = False, edge: Optional[np.ndarray] = None,
-              max_results: Optional[int] = None) -> List[Pose3D]:
+              max_results: Optional[int] = None, normal_offset: int = 3) -> List[Pose3D]:
         """detector.match(): clustered poses sorted by votes (descending)."""
         self._require_trained()
-        sc = _cloud(scene, "scene")
-        ed = _cloud(edge, "edge") if edge is not None else None
+        sc = _cloud(scene, "scene", normal_offset)
+        ed = _cloud(edge, "edge", normal_offset) if edge is not None else None
         mp = self._params(relativeSceneSampleStep, relativeSceneDistance, presampled)
         cap = max(sc.shape[0] // max(int(1.0 / relativeSceneSampleStep), 1) + 8, 8)
         out = (Pose * cap)()
         n = C.c_int(0)
-        check(lib().ppf_match(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1],
+        check(lib().ppf_match(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1], normal_offset,
                               ed.ctypes.data if ed is not None else None, ed.shape[0] if ed is not None else 0,
-                              ed.shape[1] if ed is not None else 6, C.byref(mp), out, cap, C.byref(n)))
+                              ed.shape[1] if ed is not None else 6, normal_offset if ed is not None else 3,
+                              C.byref(mp), out, cap, C.byref(n)))
         res = [Pose3D(out[i]) for i in range(n.value)]
         return res if max_results is None else res[:max_results]
 
     def match_S2B(self, scene: np.ndarray, edge: np.ndarray, relativeSceneSampleStep: float = 0.05,
-                  relativeSceneDistance: float = 0.05, *, presampled: bool = False) -> List[Pose3D]:
+                  relativeSceneDistance: float = 0.05, *, presampled: bool = False, normal_offset: int = 3) -> List[Pose3D]:
         """detector.match_S2B(): reference points from the surface cloud, paired points from the
         edge cloud (the reference's own definition is not recoverable)."""
-        return self.match(scene, relativeSceneSampleStep, relativeSceneDistance, presampled=presampled, edge=edge)
+        return self.match(scene, relativeSceneSampleStep, relativeSceneDistance, presampled=presampled, edge=edge,
+                          normal_offset=normal_offset)
 
     def raw_votes(self, scene: np.ndarray, relativeSceneSampleStep: float = 1.0 / 5.0,
                   relativeSceneDistance: float = 0.03, *, presampled: bool = False,
                   edge: Optional[np.ndarray] = None, ref_offset: int = 0, ref_stride: int = 1,
-                  vote_mode: int = 0) -> dict:
+                  vote_mode: int = 0, normal_offset: int = 3) -> dict:
         """Per-reference-point argmax triples {refIndMax, alphaIndMax, maxVotes} + raw poses +
         exact counters: the bit-exact parity surface."""
         self._require_trained()
-        sc = _cloud(scene, "scene")
-        ed = _cloud(edge, "edge") if edge is not None else None
+        sc = _cloud(scene, "scene", normal_offset)
+        ed = _cloud(edge, "edge", normal_offset) if edge is not None else None
         mp = self._params(relativeSceneSampleStep, relativeSceneDistance, presampled, ref_offset, ref_stride, True,
                           vote_mode)
         cap = sc.shape[0] + 8
@@ -250,10 +261,10 @@ class PPF3DDetector:
         poses = (Pose * cap)()
         n = C.c_int(0)
         st = MatchStats()
-        check(lib().ppf_raw_votes(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1],
+        check(lib().ppf_raw_votes(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1], normal_offset,
                                   ed.ctypes.data if ed is not None else None, ed.shape[0] if ed is not None else 0,
-                                  ed.shape[1] if ed is not None else 6, C.byref(mp), votes, poses, cap, C.byref(n),
-                                  C.byref(st)))
+                                  ed.shape[1] if ed is not None else 6, normal_offset if ed is not None else 3,
+                                  C.byref(mp), votes, poses, cap, C.byref(n), C.byref(st)))
         nr = n.value
         triples = np.array([[votes[i].ref_ind_max, votes[i].alpha_ind_max, votes[i].max_votes] for i in range(nr)],
                            dtype=np.uint32).reshape(nr, 3)
@@ -274,9 +285,9 @@ class PPF3DDetector:
         nr = max((n_tot - ref_offset + ref_stride - 1) // ref_stride, 0)
         acc = np.zeros((max(nr, 1), mi["n_ref"], mi["num_angles"]), dtype=np.uint32)
         n = C.c_int(0)
-        check(lib().ppf_debug_accumulators(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1],
+        check(lib().ppf_debug_accumulators(self._model.ptr, sc.ctypes.data, sc.shape[0], sc.shape[1], 3,
                                            ed.ctypes.data if ed is not None else None,
-                                           ed.shape[0] if ed is not None else 0, ed.shape[1] if ed is not None else 6,
+                                           ed.shape[0] if ed is not None else 0, ed.shape[1] if ed is not None else 6, 3,
                                            C.byref(mp), acc.ctypes.data, acc.size, C.byref(n)))
         return acc[: n.value]
 
@@ -311,25 +322,35 @@ def match_batch(detectors: List[PPF3DDetector], scenes: List[np.ndarray], relati
     mp = detectors[0]._params(relativeSceneSampleStep, relativeSceneDistance, presampled)
     out = (Pose * (nc * nm * top_k))()
     n_out = (C.c_int * (nc * nm))()
-    check(lib().ppf_match_batch(models, nm, ptrs, ns, stride, nc, C.byref(mp), out, top_k, n_out))
+    check(lib().ppf_match_batch(models, nm, ptrs, ns, stride, 3, nc, C.byref(mp), out, top_k, n_out))
     return [[[Pose3D(out[(c * nm + k) * top_k + i]) for i in range(n_out[c * nm + k])] for k in range(nm)]
             for c in range(nc)]
 
 
-def samplePCByQuantization(pc: np.ndarray, relative_step: float) -> np.ndarray:
-    a = _cloud(pc, "cloud")
+def samplePCByQuantization(pc: np.ndarray, relative_step: float, *, normal_offset: int = 3) -> np.ndarray:
+    a = _cloud(pc, "cloud", normal_offset)
     n = C.c_int(0)
     out = np.empty((a.shape[0], 6), dtype=np.float32)
-    check(lib().ppf_sample_cloud(a.ctypes.data, a.shape[0], a.shape[1], float(relative_step), out.ctypes.data,
+    check(lib().ppf_sample_cloud(a.ctypes.data, a.shape[0], a.shape[1], normal_offset, float(relative_step), out.ctypes.data,
                                  a.shape[0], C.byref(n)))
     return out[: n.value].copy()
 
 
-def transformPCPose(pc: np.ndarray, pose: np.ndarray) -> np.ndarray:
-    a = _cloud(pc, "cloud")
+def pairFeatures(pc: np.ndarray, feature: int = _capi.PPF_FEATURE_DARBOUX, *, normal_offset: int = 3) -> np.ndarray:
+    """pcl::PPFEstimation::compute (ppf_pair_features): (N, N, 5) float32 = f1..f4, alpha_m of every ordered pair; NaN rows for
+    i == j and degenerate pairs."""
+    a = _cloud(pc, "cloud", normal_offset)
+    n = a.shape[0]
+    out = np.empty((n, n, 5), dtype=np.float32)
+    check(lib().ppf_pair_features(a.ctypes.data, n, a.shape[1], normal_offset, int(feature), out.ctypes.data, n * n))
+    return out
+
+
+def transformPCPose(pc: np.ndarray, pose: np.ndarray, *, normal_offset: int = 3) -> np.ndarray:
+    a = _cloud(pc, "cloud", normal_offset)
     T = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
     out = np.empty((a.shape[0], 6), dtype=np.float32)
-    check(lib().ppf_transform_pc_pose(a.ctypes.data, a.shape[0], a.shape[1],
+    check(lib().ppf_transform_pc_pose(a.ctypes.data, a.shape[0], a.shape[1], normal_offset,
                                       T.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data))
     return out
 
@@ -356,8 +377,8 @@ class ICP:
         if poses is None:
             pose = (C.c_double * 16)()
             res, it = C.c_double(0), C.c_int(0)
-            check(lib().ppf_icp_register(src.ctypes.data, src.shape[0], src.shape[1], dst.ctypes.data, dst.shape[0],
-                                         dst.shape[1], C.byref(self._prm), pose, C.byref(res), C.byref(it)))
+            check(lib().ppf_icp_register(src.ctypes.data, src.shape[0], src.shape[1], 3, dst.ctypes.data, dst.shape[0],
+                                         dst.shape[1], 3, C.byref(self._prm), pose, C.byref(res), C.byref(it)))
             self.last_iterations = [it.value]
             return res.value, np.array(pose, dtype=np.float64).reshape(4, 4)
         n = len(poses)
@@ -365,7 +386,7 @@ class ICP:
         for i, p in enumerate(poses):
             recs[i] = p.to_record()
         iters = (C.c_int * max(n, 1))()
-        check(lib().ppf_icp_refine(src.ctypes.data, src.shape[0], src.shape[1], dst.ctypes.data, dst.shape[0], dst.shape[1],
+        check(lib().ppf_icp_refine(src.ctypes.data, src.shape[0], src.shape[1], 3, dst.ctypes.data, dst.shape[0], dst.shape[1], 3,
                                    C.byref(self._prm), recs, n, iters))
         self.last_iterations = [iters[i] for i in range(n)]
         for i, p in enumerate(poses):

@@ -39,12 +39,12 @@ class Workspace:
     def match_device(self, det: PPF3DDetector, d_scene_ptr: int, ns: int, stride: int, step: float, dist: float,
                      *, presampled: bool = True, d_edge_ptr: Optional[int] = None, ne: int = 0, estride: int = 6,
                      ref_offset: int = 0, ref_stride: int = 1, skip_clustering: bool = False, stream: int = 0,
-                     vote_mode: int = 0):
+                     vote_mode: int = 0, normal_offset: int = 3, edge_normal_offset: int = 3):
         """Enqueue one match on `stream` (raw hipStream_t value, 0 = default stream)."""
         det._require_trained()
         mp = det._params(step, dist, presampled, ref_offset, ref_stride, skip_clustering, vote_mode)
-        check(lib().ppf_match_device(det._model.ptr, self.ptr, C.c_void_p(d_scene_ptr), ns, stride,
-                                     C.c_void_p(d_edge_ptr) if d_edge_ptr else None, ne, estride, C.byref(mp),
+        check(lib().ppf_match_device(det._model.ptr, self.ptr, C.c_void_p(d_scene_ptr), ns, stride, normal_offset,
+                                     C.c_void_p(d_edge_ptr) if d_edge_ptr else None, ne, estride, edge_normal_offset, C.byref(mp),
                                      C.c_void_p(stream) if stream else None))
 
     def results(self, cap_ref: int, want_poses: bool = True) -> dict:
@@ -120,11 +120,13 @@ class Workspace:
 class BatchMatcher:
     """ppf_batch_*: crops x models over `lanes` streams with their own workspaces (BASELINE config C5)."""
 
-    def __init__(self, lanes: int = 4):
+    def __init__(self, lanes: int = 4, timing: bool = False):
         p = C.c_void_p()
         check(lib().ppf_batch_create(int(lanes), C.byref(p)))
         self.ptr = p.value
         self.lanes = int(lanes)
+        if timing:  # HIP events around the kernels of every match: res["ms_vote_kernel"] etc. are sums over the run
+            check(lib().ppf_batch_enable_timing(self.ptr, 1))
 
     def __del__(self):
         try:
@@ -145,7 +147,7 @@ class BatchMatcher:
         out = (Pose * (nc * nm * top_k))() if want_host else None
         n_out = (C.c_int * (nc * nm))()
         st = BatchStats()
-        check(lib().ppf_batch_run(self.ptr, models, nm, scenes, cnt, stride, nc, int(on_device), C.byref(mp), out, top_k,
+        check(lib().ppf_batch_run(self.ptr, models, nm, scenes, cnt, stride, 3, nc, int(on_device), C.byref(mp), out, top_k,
                                   n_out, C.byref(st)))
         res = {f: getattr(st, f) for f, _ in BatchStats._fields_}
         res["n_out"] = [n_out[i] for i in range(nc * nm)]
