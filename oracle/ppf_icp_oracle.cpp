@@ -18,8 +18,26 @@
  *     accumulated in chunks of 64 (sequential inside a chunk, chunk sums added sequentially) -- the order the device
  *     kernels reproduce -- with Tikhonov damping 1e-10 * trace, solved by Gaussian elimination (solve6).
  *   - median: element of rank (m-1)/2 of the sorted values (lower median).
- *   - every other sum over points (means, distance sums) is taken in the same chunk-of-64 order; sin/cos/sqrt come
- *     from include/ppf_detmath.h (<= 1 ulp from libm), so the device kernels can match this file bit for bit.
+ *   - a level stops when picky ICP leaves SIX OR FEWER correspondences (`sel.size() <= 6`).  Upstream only tests for zero
+ *     (`if (selInd)` in ICP::registerModelToScene) and would hand a 1..6-row system to cv::solve(DECOMP_SVD), whose
+ *     minimum-norm step moves the model along the few constrained directions; with fewer rows than unknowns that step
+ *     carries no information about the pose, so this restatement ends the level instead (the pose of the level stays what it
+ *     was).  It is the one place where an iteration COUNT can differ from an upstream build.
+ *
+ * WHY REFINED POSES CAN COME BACK WITH RESIDUAL 9999999999 AFTER ONE TO THREE ITERATIONS (profiles/r03_icp_levels.json,
+ * tools/icp_levels.py: the per-pass trace of this oracle on the top-5 matched poses of the C2 crop): `residual` is upstream's
+ * fval_min of the LAST (finest) level, which starts at 9999999999 and is only lowered by a completed iteration.  The reference
+ * refines the five best clusters of the match (CloudProcessing.h:455-470); on a crop with one instance, clusters 2..5 are
+ * wrong poses.  Picky ICP -- upstream's "if more than one model point is assigned to the same scene point keep the closest"
+ * (the duplicateTable / hashtable pass of ICP::registerModelToScene) -- is hard on the coarse levels: level 7 pairs 155
+ * model rows with 391 scene rows spread over the whole crop, and keeps 12-13 pairs EVEN FOR THE CORRECT POSE (which then
+ * improves level by level: 26, 56, 99, ... 858 pairs, 19 iterations, residual 1.5e-3).  From a wrong pose those dozen pairs
+ * do not describe one surface, the 6-DoF step they give throws the model off the data, after which every model point has
+ * the same nearest scene point, the rejection threshold (distances all alike) accepts all of them and picky ICP keeps ONE
+ * pair (trace: accepted 19,753, kept 1, at every remaining level).  The level ends (rule above), the finest level never
+ * completes an iteration, and the sentinel comes back with the diverged pose.  An upstream build loses the same
+ * correspondences by the same rule; what it would do differently is keep taking minimum-norm steps on the one remaining pair
+ * and report that pair's residual.  Neither result is a usable pose: a residual of 9999999999 is the honest label.
  */
 #include <algorithm>
 #include <cmath>
@@ -114,6 +132,18 @@ bool solve6(double M[6][7]) {
 
 struct IcpParams { int iterations; float tolerance, rejection_scale; int num_levels; };
 
+/* optional trace (oracle_icp_set_trace): one row {level, iteration, source rows, scene rows, accepted by the rejection
+ * threshold, kept by picky ICP, exit code} per pass of the while loop -- exit 0: iterated, 1: six or fewer correspondences,
+ * 2: the 6x6 solve failed, 3: NaN in the solution -- how tools/icp_levels.py explains a pose's iteration count and residual */
+int* g_trace = nullptr;
+int g_trace_cap = 0, g_trace_n = 0;
+void trace_row(int level, int it, int ns, int nd, int acc, int sel, int code) {
+  if (!g_trace || g_trace_n >= g_trace_cap) return;
+  int* r = g_trace + (size_t)g_trace_n * 7;
+  r[0] = level; r[1] = it; r[2] = ns; r[3] = nd; r[4] = acc; r[5] = sel; r[6] = code;
+  g_trace_n++;
+}
+
 /* ICP::registerModelToScene(srcPC, dstPC, residual, pose) */
 int icp_single(const Cloud& srcPC, const Cloud& dstPC, const IcpParams& prm, double* pose, double* residual, int* iters_total) {
   const int n = srcPC.rows();
@@ -197,7 +227,7 @@ int icp_single(const Cloud& srcPC, const Cloud& dstPC, const IcpParams& prm, dou
       for (int a : accI) { const int b = nn[a]; if (owner[b] < 0 || dist[a] < dist[owner[b]]) owner[b] = a; }
       std::vector<std::pair<int, int>> sel; /* (model row, scene row), ordered by scene row */
       for (int b = 0; b < nd; b++) if (owner[b] >= 0) sel.push_back({owner[b], b});
-      if ((int)sel.size() <= 6) break;
+      if ((int)sel.size() <= 6) { trace_row(level, i, ns, nd, (int)accI.size(), (int)sel.size(), 1); break; }
       /* minimizePointToPlaneMetric on the level's UNMOVED source rows; normal equations in chunk order */
       double M[6][7]; memset(M, 0, sizeof(M));
       double fsum = 0;
@@ -219,15 +249,16 @@ int icp_single(const Cloud& srcPC, const Cloud& dstPC, const IcpParams& prm, dou
         for (int r = 0; r < 6; r++) for (int cc = 0; cc < 7; cc++) M[r][cc] += P[r][cc];
         fsum += fs;
       }
-      if (!solve6(M)) break;
+      if (!solve6(M)) { trace_row(level, i, ns, nd, (int)accI.size(), (int)sel.size(), 2); break; }
       const double rpy[3] = {M[0][6], M[1][6], M[2][6]}, t[3] = {M[3][6], M[4][6], M[5][6]};
-      if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) break;
+      if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) { trace_row(level, i, ns, nd, (int)accI.size(), (int)sel.size(), 3); break; }
       transform_from_euler(rpy, t, PoseX);
       moved = transformPCPose(srcPCT, PoseX);
       const double fval = ppf_sqrt(fsum) / (double)ns;
       fval_perc = fval / fval_old;
       fval_old = fval;
       if (fval < fval_min) fval_min = fval;
+      trace_row(level, i, ns, nd, (int)accI.size(), (int)sel.size(), 0);
       i++;
     }
     total += i;
@@ -247,6 +278,13 @@ int icp_single(const Cloud& srcPC, const Cloud& dstPC, const IcpParams& prm, dou
 }  // namespace
 
 extern "C" {
+/* rows of 7 ints per pass of the ICP loop are written to buf from now on (NULL switches the trace off); returns the rows
+ * written since the previous call */
+int oracle_icp_set_trace(int* buf, int cap_rows) {
+  const int n = g_trace_n;
+  g_trace = buf; g_trace_cap = buf ? cap_rows : 0; g_trace_n = 0;
+  return n;
+}
 /* ICP::registerModelToScene(model, scene, poses): for each initial pose, move the model, refine, append.
  * poses_io: n_poses x 16 doubles (row-major 4x4), updated in place to poseICP * pose; residuals: n_poses. */
 int oracle_icp_refine(const float* model, int n_model, const float* scene, int n_scene, int iterations, float tolerance,

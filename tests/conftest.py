@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the full-size configuration fixtures must be what the GPU tests compare with: a regenerated crop whose sha256 differs
+# from the fixture's fails the test instead of quietly taking the reduced oracle-on-the-spot branch (test_gpu_configs.py)
+os.environ.setdefault("PPF_REQUIRE_FIXTURES", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -379,6 +379,20 @@ def icp_refine(model, scene, poses, iterations=100, tolerance=0.005, rejection_s
     return P.reshape(-1, 4, 4), res, its
 
 
+def icp_refine_traced(model, scene, poses, **kw):
+    """icp_refine plus the oracle's per-pass trace: rows {level, iteration, source rows, scene rows, accepted by the
+    rejection threshold, kept by picky ICP, exit code (0 iterated, 1 six or fewer correspondences, 2 solve failed, 3 NaN)}."""
+    buf = np.zeros((4096, 7), dtype=np.int32)
+    L = lib()
+    L.oracle_icp_set_trace.restype = C.c_int
+    L.oracle_icp_set_trace(buf.ctypes.data_as(C.POINTER(C.c_int)), buf.shape[0])
+    try:
+        out = icp_refine(model, scene, poses, **kw)
+    finally:
+        n = L.oracle_icp_set_trace(None, 0)
+    return out + (buf[:n].copy(),)
+
+
 # ---- pre-processing stages (oracle/ppf_prep_oracle.cpp) ------------------------------------------------------------
 def _xyz(cloud):
     a = np.ascontiguousarray(np.asarray(cloud, dtype=np.float32))

@@ -7,9 +7,11 @@
   C4  ~10k-pt model vs 200k-pt scene (10 accumulator tiles, 1e8-entry table): 40 reference points, shard identities.
   C5  4 models x 8 crops through the batched entry: whole matches on 12,000-pt crops, reference points at 50,000 pts.
 
-The crops are regenerated from seeds; every fixture carries the sha256 of the cloud the oracle saw.  Should numpy on
-another CPU produce a different float somewhere (it never has), the test falls back to running the oracle itself on a
-subset of the reference points instead of comparing against stale numbers.
+The crops are regenerated from seeds; every fixture carries the sha256 of the cloud the oracle saw.  With
+PPF_REQUIRE_FIXTURES=1 (tests/conftest.py sets it unless the caller chose otherwise) a regenerated crop whose digest differs
+FAILS the test: a green run therefore proves that the full-size fixtures were what the engine was compared with.  With
+PPF_REQUIRE_FIXTURES=0 such a crop is checked against the oracle run on the spot on a subset of the reference points, and
+the branch taken is printed.  tests/test_fixture_digests.py checks the same digests on the CPU, so drift shows up early.
 
 "parity unpinned" (DESIGN.md section 2): the oracle is our restatement of the un-vendored upstream library.
 """
@@ -33,8 +35,18 @@ def _fixture(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def _same_cloud(cloud, digest) -> bool:
-    return W.cloud_digest(cloud) == str(digest)
+def _same_cloud(cloud, digest, what="crop") -> bool:
+    """True: the regenerated cloud is bit-identical to the one the fixture's oracle run saw.  A mismatch is an error unless
+    PPF_REQUIRE_FIXTURES=0, in which case the caller's fallback branch runs and says so."""
+    same = W.cloud_digest(cloud) == str(digest)
+    if not same:
+        assert os.environ.get("PPF_REQUIRE_FIXTURES", "1") == "0", (
+            f"{what}: the regenerated cloud differs from the one the committed fixture was computed on (sha256 mismatch); "
+            "rerun tests/golden/make_config_fixtures.py or set PPF_REQUIRE_FIXTURES=0 to compare with the oracle on the spot")
+        print(f"[fixtures] {what}: digest mismatch -> FALLBACK branch (oracle subset computed here)")
+    else:
+        print(f"[fixtures] {what}: digest matches -> compared with the committed full-size fixture")
+    return same
 
 
 @pytest.fixture(scope="module")
@@ -54,7 +66,7 @@ def test_c2_full_size_equals_the_oracle_fixture(bottle, det_c2):
     scene = W.c2_scene()
     got = det_c2.raw_votes(scene, STEP, W.REL_DISTANCE, presampled=True)
     assert got["n_ref"] == 2500 and got["stats"]["n_pairs"] == 2500 * 49999
-    if _same_cloud(scene, fx["digest"]):
+    if _same_cloud(scene, fx["digest"], "C2 crop"):
         np.testing.assert_array_equal(got["triples"], fx["triples"])
         assert got["stats"]["n_votes"] == int(fx["votes"].sum())
         assert got["stats"]["n_pairs"] == int(fx["pairs"].sum())
@@ -77,7 +89,7 @@ def test_c2_full_size_equals_the_oracle_fixture(bottle, det_c2):
         # the same block as a device-side gather would see it
         blk = ws.device_top_block(W.TOP_K).cpu().numpy()
         np.testing.assert_array_equal(blk[:, :16].reshape(-1, 4, 4), np.stack([q.pose for q in res["poses"][: W.TOP_K]]))
-    else:  # pragma: no cover - another numpy/CPU produced a different crop: check against the oracle run here
+    else:  # PPF_REQUIRE_FIXTURES=0 only: another numpy/CPU produced a different crop, check against the oracle run here
         want = _oracle_subset(bottle, W.C2["model_step"], scene, 7, 125, 20)
         sub = det_c2.raw_votes(scene, STEP, W.REL_DISTANCE, presampled=True, ref_offset=7, ref_stride=125)
         np.testing.assert_array_equal(sub["triples"], want["triples"])
@@ -140,12 +152,12 @@ def test_c3_rank_crops_equal_the_oracle_fixture(bottle, det_c2):
     for r, crop in enumerate(crops):
         got = det_c2.raw_votes(crop, STEP, W.REL_DISTANCE, presampled=True, ref_offset=off, ref_stride=stride)
         alone.append(got["triples"])
-        if _same_cloud(crop, fx[f"digest_{r}"]):
+        if _same_cloud(crop, fx[f"digest_{r}"], f"C3 crop of rank {r}"):
             np.testing.assert_array_equal(got["triples"], fx[f"triples_{r}"])
             assert got["stats"]["n_votes"] == int(fx[f"votes_{r}"].sum())
             for g, w in zip(got["raw_poses"], fx[f"raw_{r}"]):
                 assert np.array_equal(g.pose, w)
-        else:  # pragma: no cover
+        else:  # PPF_REQUIRE_FIXTURES=0 only
             want = _oracle_subset(bottle, W.C2["model_step"], crop, off, stride, 20)
             np.testing.assert_array_equal(got["triples"], want["triples"])
     for r in (3, 1, 7, 0, 1):  # crops are independent: any order, repeated, same answer
@@ -163,12 +175,12 @@ def test_c4_equals_the_oracle_fixture_and_shards_add_up(bottle):
     off, stride = int(fx["ref_offset"][0]), int(fx["ref_stride"][0])
     a = det.raw_votes(scene, STEP, W.REL_DISTANCE, presampled=True, ref_offset=off, ref_stride=stride)
     assert a["n_ref"] == 40 and a["stats"]["n_pairs"] == 40 * 199999
-    if _same_cloud(scene, fx["digest"]):
+    if _same_cloud(scene, fx["digest"], "C4 scene"):
         np.testing.assert_array_equal(a["triples"], fx["triples"])
         assert a["stats"]["n_votes"] == int(fx["votes"].sum())
         for g, w in zip(a["raw_poses"], fx["raw"]):
             assert np.array_equal(g.pose, w)
-    else:  # pragma: no cover
+    else:  # PPF_REQUIRE_FIXTURES=0 only
         want = _oracle_subset(bottle, W.C4["model_step"], scene, off, 2500, 4)
         np.testing.assert_array_equal(a["triples"][::10], want["triples"])
     # the same points split over two "ranks"
@@ -205,7 +217,7 @@ def test_c5_batch_equals_the_oracle_fixture():
     assert res["n_matches"] == 32
     votes = 0
     for c, crop in enumerate(small):
-        if not _same_cloud(crop, fx[f"small_digest_{c}"]):  # pragma: no cover
+        if not _same_cloud(crop, fx[f"small_digest_{c}"], f"C5 crop {c} (12,000 points)"):  # pragma: no cover
             pytest.skip("synthetic crop differs on this platform")
         for k in range(4):
             got = res["poses"][c][k]
@@ -226,7 +238,7 @@ def test_c5_batch_equals_the_oracle_fixture():
     full = W.c5_crops(0, models=models)
     off, stride = int(fx["full_ref_offset"][0]), int(fx["full_ref_stride"][0])
     for c in (0, 5):
-        assert _same_cloud(full[c], fx[f"full_digest_{c}"])
+        assert _same_cloud(full[c], fx[f"full_digest_{c}"], f"C5 crop {c} (50,000 points)")
         for k, d in enumerate(dets):
             got = d.raw_votes(full[c], STEP, W.REL_DISTANCE, presampled=True, ref_offset=off, ref_stride=stride)
             np.testing.assert_array_equal(got["triples"], fx[f"full_triples_{c}_{k}"])

@@ -9,7 +9,7 @@ mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > "$ROOT/$OUT/$name.log" 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs ${BENCH_ARGS} > "$ROOT/$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA

@@ -12,7 +12,7 @@ for v in "$@"; do
   if [ "$name" = product ]; then lib=$ROOT/yolo_ppf_pose_estimation_amd/csrc/libppf_hip.so; else lib=$ROOT/build_var/$name.so; fi
   export PPF_HIP_LIB=$lib
   cd "$ROOT"
-  timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline $BENCH_ARGS > "$OUT/$name.json" 2> "$OUT/$name.err" || { echo "$name: bench failed"; tail -5 "$OUT/$name.err"; exit 1; }
+  timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs $BENCH_ARGS > "$OUT/$name.json" 2> "$OUT/$name.err" || { echo "$name: bench failed"; tail -5 "$OUT/$name.err"; exit 1; }
   python3 - "$OUT/$name.json" "$name" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); k = d.get("kernel_ms", {})
@@ -21,7 +21,7 @@ PY
   if [ -z "$NO_PMC" ]; then
     cd /tmp && export TMPDIR=/tmp
     timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS \
-      --output-format csv -d "$ROOT/$OUT/pmc_$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > "$ROOT/$OUT/pmc_$name.log" 2>&1 || { echo "$name: pmc failed"; tail -5 "$ROOT/$OUT/pmc_$name.log"; exit 1; }
+      --output-format csv -d "$ROOT/$OUT/pmc_$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $BENCH_ARGS > "$ROOT/$OUT/pmc_$name.log" 2>&1 || { echo "$name: pmc failed"; tail -5 "$ROOT/$OUT/pmc_$name.log"; exit 1; }
   fi
 done
 echo done

@@ -66,15 +66,16 @@ def gather_poses(local: np.ndarray, device=None):
     return out.cpu().numpy().reshape((world,) + tuple(t.shape))
 
 
-def gather_device(block, dist=None):
+def gather_device(block, dist=None, force=False):
     """all_gather of a device tensor block (rows = pose records as float64 words) without leaving HBM: every rank
     contributes the same shape; returns (world * rows, words) on the device (RCCL under backend "nccl").  With the
-    gloo rehearsal backend the block travels through the host."""
+    gloo rehearsal backend the block travels through the host.  A world of one returns the block itself unless `force`
+    asks for the collective anyway (tests/test_gpu_rccl.py: RCCL's first call must not be the 8-GPU run)."""
     import torch
     import torch.distributed as tdist
 
     d = dist or tdist
-    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+    if not (d.is_available() and d.is_initialized()) or (d.get_world_size() == 1 and not force):
         return block
     world = d.get_world_size()
     if d.get_backend() != "nccl":
