@@ -231,6 +231,11 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
 ppf_status ppf_model_save(const ppf_model* m, const char* path);
 /* every field and table of the file is validated before use: a truncated or corrupt file is PPF_ERR_IO */
 ppf_status ppf_model_load(const char* path, ppf_model** out);
+/* The same byte stream to and from memory (what cv::FileStorage carries for detector.write / detector.read,
+ * CloudProcessing.h:112,250): buf == NULL queries *size; a too small buffer is PPF_ERR_CAPACITY with *size set.
+ * ppf_model_load_mem validates exactly like ppf_model_load. */
+ppf_status ppf_model_save_mem(const ppf_model* m, void* buf, size_t cap, size_t* size);
+ppf_status ppf_model_load_mem(const void* buf, size_t size, ppf_model** out);
 /* the same validation without a device (host only): PPF_OK or PPF_ERR_IO */
 ppf_status ppf_model_check_file(const char* path);
 

@@ -37,6 +37,8 @@
 #include <string>
 #include <vector>
 
+#include <climits>
+
 #include "ppf_hip.h"
 
 #if defined(__has_include)
@@ -207,43 +209,31 @@ class PPF3DDetector {
    * file); read() validates them like any other model file. */
   void write(cv::FileStorage& fs) const {
     require_trained();
-    const std::string tmp = temp_name();
-    check(ppf_model_save(model_, tmp.c_str()));
-    std::ifstream in(tmp.c_str(), std::ios::binary);
-    std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-    in.close();
-    std::remove(tmp.c_str());
-    if (bytes.empty()) throw Error(PPF_ERR_IO, "write(FileStorage): could not serialise the model");
-    cv::Mat blob(1, (int)bytes.size(), CV_8U, bytes.data());
+    size_t size = 0;
+    check(ppf_model_save_mem(model_, nullptr, 0, &size));
+    if (size == 0 || size > (size_t)INT_MAX) throw Error(PPF_ERR_IO, "write(FileStorage): the table does not fit one cv::Mat row (> 2 GiB); use write(path)");
+    std::vector<unsigned char> bytes(size);
+    check(ppf_model_save_mem(model_, bytes.data(), bytes.size(), &size));
+    cv::Mat blob(1, (int)size, CV_8U, bytes.data());
     fs << "ppf_hip_model" << blob;
   }
   void read(const cv::FileNode& fn) {
     cv::Mat blob;
     fn["ppf_hip_model"] >> blob;
     if (blob.empty() || blob.depth() != CV_8U) throw Error(PPF_ERR_IO, "read(FileNode): no ppf_hip_model entry in this storage");
-    const std::string tmp = temp_name();
-    {
-      std::ofstream out(tmp.c_str(), std::ios::binary);
-      for (int r = 0; r < blob.rows; r++) out.write(reinterpret_cast<const char*>(blob.ptr<unsigned char>(r)), (std::streamsize)blob.cols);
-    }
-    try {
-      read(tmp);
-    } catch (...) {
-      std::remove(tmp.c_str());
-      throw;
-    }
-    std::remove(tmp.c_str());
+    std::vector<unsigned char> bytes;
+    bytes.reserve((size_t)blob.rows * (size_t)blob.cols);
+    for (int r = 0; r < blob.rows; r++) bytes.insert(bytes.end(), blob.ptr<unsigned char>(r), blob.ptr<unsigned char>(r) + blob.cols);
+    ppf_model* m = nullptr;
+    check(ppf_model_load_mem(bytes.data(), bytes.size(), &m)); /* validated field by field like any model file */
+    if (model_) ppf_model_release(model_);
+    model_ = m;
   }
 #endif
   ppf_model_info info() const { require_trained(); ppf_model_info i; check(ppf_model_get_info(model_, &i)); return i; }
   const ppf_model* handle() const { return model_; }
 
  private:
-  static std::string temp_name() {
-    char buf[64];
-    std::snprintf(buf, sizeof(buf), "/tmp/ppf_hip_model_%p_%ld.bin", (void*)&buf, (long)std::rand());
-    return buf;
-  }
   template <class M> static int stride_of(const M& m) { return detail::stride_of(m); }
   template <class M> static void require_cloud(const M& m, const char* who) {
     if (m.rows <= 0 || m.cols < 6) throw Error(PPF_ERR_INVALID, std::string(who) + ": expected an N x 6 float32 cloud (x y z nx ny nz)");

@@ -215,7 +215,20 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
         if out.value:
             lib().ppf_model_release(out)
         assert lib().ppf_model_check_file(str(p).encode()) == rc
+        out2 = C.c_void_p()  # the in-memory entry (what the FileStorage overloads use) validates the same way
+        assert lib().ppf_model_load_mem(data, len(data), C.byref(out2)) == rc
+        if out2.value:
+            lib().ppf_model_release(out2)
         return rc
+
+    # memory round trip: the same bytes as the file, a too small buffer says how much it needs
+    blob = det.to_bytes()
+    assert blob == good.read_bytes()
+    need = C.c_size_t(0)
+    small = C.create_string_buffer(16)
+    assert lib().ppf_model_save_mem(det._model.ptr, small, 16, C.byref(need)) == _capi.PPF_ERR_CAPACITY and need.value == len(blob)
+    again = PPF3DDetector(0.05, 0.05).from_bytes(blob)
+    np.testing.assert_array_equal(again.raw_votes(crop, 1.0 / 10.0, 0.05, presampled=True)["triples"], oracle_crop["triples"])
 
     assert load(bytes(raw)) == _capi.PPF_OK
     assert load(bytes(raw[: len(raw) // 2])) == _capi.PPF_ERR_IO           # truncated

@@ -1,0 +1,63 @@
+"""The compile-time switches of the vote kernel are part of the source, so they are exercised: builds of libppf_hip.so with
+other values (made on the GPU box with hipcc, as tools/build_variant.sh does) must give the oracle's votes bit for bit.
+
+  exact   -DPPF_FORCE_EXACT          every direct vote takes the fp64 chain instead of the fp32 bin + guard band
+          -DPPF_TWO_QUEUES=1         count-table items and direct items claimed from two queues
+          -DPPF_DEAL_BANKS=64        round 2's dealing order of the table's entries
+  tuned   -DPPF_AGG_MIN_HITS=40 -DPPF_AGG_CHUNK=4096 -DPPF_PREFETCH=0 -DPPF_PIPE_VALU=2   other tunables
+
+Each variant runs in a child process (PPF_HIP_LIB selects the library before it is loaded)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "yolo_ppf_pose_estimation_amd", "csrc")
+
+CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PPF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PPF_ROOT"], "tests"))
+import oracle_lib as O
+from yolo_ppf_pose_estimation_amd import _capi, synth, workloads as W
+from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
+assert os.path.samefile(_capi.LIB_PATH, os.environ["PPF_HIP_LIB"])
+bottle = W.bottle()
+scene, _ = synth.make_scene(bottle, n_points=9000, seed=17)
+for step, stride in ((0.05, 1.0 / 25.0), (0.036, 1.0 / 60.0)):
+    det = PPF3DDetector(step, 0.05).trainModel(bottle)
+    ora = O.OracleDetector(step, 0.05).train_model(bottle)
+    want = ora.match(scene, relative_scene_sample_step=stride, presampled=True, cluster=False)
+    for mode in (0, 1):
+        got = det.raw_votes(scene, stride, 0.05, presampled=True, vote_mode=mode)
+        np.testing.assert_array_equal(got["triples"], want["triples"])
+        assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum())
+        for g, w in zip(got["raw_poses"][::7], want["raw_poses"][::7]):
+            assert np.array_equal(g.pose, np.asarray(w["pose"]))
+print("VARIANT_OK")
+"""
+
+VARIANTS = {
+    "exact": ["-DPPF_FORCE_EXACT", "-DPPF_TWO_QUEUES=1", "-DPPF_DEAL_BANKS=64"],
+    "tuned": ["-DPPF_AGG_MIN_HITS=40", "-DPPF_AGG_CHUNK=4096", "-DPPF_PREFETCH=0", "-DPPF_PIPE_VALU=2"],
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variant_builds_vote_like_the_oracle(name, tmp_path):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this box")
+    lib = str(tmp_path / f"libppf_hip_{name}.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+           "-fno-slp-vectorize"] + VARIANTS[name] + [os.path.join(CSRC, "ppf_hip.hip"), "-o", lib]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, PPF_HIP_LIB=lib, PPF_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

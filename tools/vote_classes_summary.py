@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Per-class attribution of k_vote from the attribution builds (tools/vote_variants.sh on build_var/a_*.so).
+
+    python tools/vote_classes_summary.py gpurun_out/r03_e3 PRODUCT_NAME > profiles/r03_vote_classes.md
+
+Every class is priced as (product build) - (build without that class): kernel time (HIP events, 10 steps), LDS
+wave-instructions, LDS-array cycles, bank- and address-conflict cycles, VALU wave-instructions, and the share of wave time
+parked (SQ_WAIT_ANY) of the build WITHOUT the class."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+STEPS = 3.0
+
+
+def counters(d):
+    agg = collections.defaultdict(float)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "k_vote<false, false>" in row["Kernel_Name"]:
+                agg[row["Counter_Name"]] += float(row["Counter_Value"]) / STEPS
+    return agg
+
+
+def main():
+    root, prod = sys.argv[1], sys.argv[2]
+
+    def load(name):
+        b = json.load(open(os.path.join(root, name + ".json")))
+        c = counters(os.path.join(root, "pmc_" + name))
+        return {"ms": b["kernel_ms"]["k_vote"], "lds": c["SQ_INSTS_LDS"], "idx": c["SQ_LDS_IDX_ACTIVE"], "bank": c["SQ_LDS_BANK_CONFLICT"],
+                "addr": c["SQ_LDS_ADDR_CONFLICT"], "valu": c["SQ_INSTS_VALU"], "wait": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1),
+                "wait_lds": c["SQ_WAIT_INST_LDS"] / max(c["SQ_WAVE_CYCLES"], 1)}
+
+    p = load(prod)
+    rows = [("counted atomics + the table-row reads behind them (count-table items)", "a_counted0", -1),
+            ("own-cell loop: one-by-one votes of an entry's own 1/32 cell (count-table items)", "a_owncell0", -1),
+            ("direct votes on buckets of more than 32 records (loads + votes)", "a_dbig0", -1),
+            ("   of which: the record loads alone (build that loads but does not vote, minus the one that does neither)", ("a_dbig2", "a_dbig0"), +1),
+            ("direct votes on buckets of at most 32 records", "a_dsmall0", -1),
+            ("count-table builds (build that makes every table twice, minus the product)", "a_build2", +1)]
+    print("# k_vote by class of work (C2, MI355X)\n")
+    print(f"Product build `{prod}`: k_vote {p['ms']:.3f} ms, {p['lds'] / 1e6:.1f} M LDS wave-instructions, {p['idx'] / p['lds']:.2f} LDS-array cycles per "
+          f"instruction of which {p['bank'] / p['lds']:.2f} bank-conflict and {p['addr'] / p['lds']:.2f} address-conflict cycles, {p['valu'] / 1e6:.0f} M VALU "
+          f"wave-instructions, {p['wait']:.1%} of wave time parked (SQ_WAIT_ANY), {p['wait_lds']:.1%} stalled on LDS issue (SQ_WAIT_INST_LDS).\n")
+    print("Each class = product minus a build that leaves the class out (`PPF_ABL_*`, ppf_match_kernels.h; wrong votes, the 16-bit overflow check off): "
+          "time includes the latency the class exposes.\n")
+    print("| class | k_vote ms | LDS wave-instr (M) | array cycles / instr of the class | bank-conflict cycles (M) | share of the product's conflict cycles | "
+          "address-conflict cycles (M) | VALU wave-instr (M) | SQ_WAIT_ANY without the class |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    out = {"product": p, "classes": {}}
+    tot = collections.defaultdict(float)
+    for label, name, sign in rows:
+        if isinstance(name, tuple):
+            a, b = load(name[0]), load(name[1])
+            d = {k: a[k] - b[k] for k in ("ms", "lds", "idx", "bank", "addr", "valu")}
+            wait = a["wait"]
+        else:
+            v = load(name)
+            d = {k: (p[k] - v[k]) * (1 if sign < 0 else -1) for k in ("ms", "lds", "idx", "bank", "addr", "valu")}
+            wait = v["wait"]
+        out["classes"][label] = dict(d, wait_any_without=wait)
+        if not isinstance(name, tuple):
+            for k in d:
+                tot[k] += d[k]
+        print(f"| {label} | {d['ms']:.3f} | {d['lds'] / 1e6:.1f} | {d['idx'] / max(d['lds'], 1):.2f} | {d['bank'] / 1e6:.0f} | {d['bank'] / p['bank']:.1%} | "
+              f"{d['addr'] / 1e6:.0f} | {d['valu'] / 1e6:.0f} | {wait:.1%} |")
+    n = load("a_none")
+    print(f"| everything else: staging, claims, item look-up, record loads and table reads of count-table items, clear, scan (build with all four vote "
+          f"classes out) | {n['ms']:.3f} | {n['lds'] / 1e6:.1f} | {n['idx'] / n['lds']:.2f} | {n['bank'] / 1e6:.0f} | {n['bank'] / p['bank']:.1%} | {n['addr'] / 1e6:.0f} | "
+          f"{n['valu'] / 1e6:.0f} | {n['wait']:.1%} |")
+    print(f"| sum of the rows (without the sub-row) | {tot['ms'] + n['ms']:.3f} | {(tot['lds'] + n['lds']) / 1e6:.1f} | | {(tot['bank'] + n['bank']) / 1e6:.0f} | "
+          f"{(tot['bank'] + n['bank']) / p['bank']:.1%} | {(tot['addr'] + n['addr']) / 1e6:.0f} | {(tot['valu'] + n['valu']) / 1e6:.0f} | |")
+    for extra, lab in (("a_aggonly", "count-table items only (no direct votes at all)"), ("a_directonly", "direct items only (no counted atomics, no own-cell loop)")):
+        v = load(extra)
+        print(f"\n`{extra}` — {lab}: {v['ms']:.3f} ms, {v['lds'] / 1e6:.1f} M LDS wave-instructions at {v['idx'] / v['lds']:.2f} array cycles, "
+              f"{v['valu'] / 1e6:.0f} M VALU, SQ_WAIT_ANY {v['wait']:.1%}, SQ_WAIT_INST_LDS {v['wait_lds']:.1%}.")
+        out[extra] = v
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_vote_classes.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,8 @@ _SIGNATURES = {
     "ppf_model_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ppf_model_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ppf_model_check_file": (C.c_int, [C.c_char_p]),
+    "ppf_model_save_mem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ppf_model_load_mem": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ppf_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                             C.POINTER(MatchParams), C.POINTER(Pose), C.c_int, C.POINTER(C.c_int)]),
     "ppf_match_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,

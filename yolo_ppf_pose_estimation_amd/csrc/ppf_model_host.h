@@ -397,8 +397,8 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
  * private OpenCV patch and unknown) ------------------------------------------------- */
 static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '3'}; /* 02: pair-record table; 03: ppf_train_params.feature */
 
-ppf_status ppf_model_save(const ppf_model* m, const char* path) {
-  if (!m || !path) return fail(PPF_ERR_INVALID, "ppf_model_save: NULL");
+/* the model as a byte stream (what a model file holds), written to an open FILE */
+static ppf_status model_write(const ppf_model* m, FILE* f, const char* path) {
   const size_t words = ((size_t)m->info.slots + 63) / 64, nb = m->info.n_buckets, ne = m->n_records;
   std::vector<SlotWord> slotmap(words);
   std::vector<uint32_t> boff((size_t)m->info.n_tiles * (nb + 1)), bslot(nb);
@@ -407,8 +407,6 @@ ppf_status ppf_model_save(const ppf_model* m, const char* path) {
   HIPCHK(hipMemcpy(boff.data(), m->bucket_off.p, boff.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (nb) HIPCHK(hipMemcpy(bslot.data(), m->bucket_slot.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (ne) HIPCHK(hipMemcpy(ent.data(), m->records.p, ne * sizeof(uint4), hipMemcpyDeviceToHost));
-  FILE* f = fopen(path, "wb");
-  if (!f) return fail(PPF_ERR_IO, "ppf_model_save: cannot open %s", path);
   bool ok = fwrite(PPF_MAGIC, 1, 8, f) == 8;
   ok = ok && fwrite(&m->params, sizeof(m->params), 1, f) == 1;
   ok = ok && fwrite(&m->info, sizeof(m->info), 1, f) == 1;
@@ -418,18 +416,50 @@ ppf_status ppf_model_save(const ppf_model* m, const char* path) {
   ok = ok && fwrite(boff.data(), sizeof(uint32_t), boff.size(), f) == boff.size();
   ok = ok && fwrite(bslot.data(), sizeof(uint32_t), nb, f) == nb;
   ok = ok && fwrite(ent.data(), sizeof(uint4), ne, f) == ne;
-  ok = (fclose(f) == 0) && ok;
   if (!ok) return fail(PPF_ERR_IO, "ppf_model_save: short write to %s", path);
   return PPF_OK;
+}
+
+ppf_status ppf_model_save(const ppf_model* m, const char* path) {
+  if (!m || !path) return fail(PPF_ERR_INVALID, "ppf_model_save: NULL");
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(PPF_ERR_IO, "ppf_model_save: cannot open %s", path);
+  ppf_status s = model_write(m, f, path);
+  if (fclose(f) != 0 && s == PPF_OK) s = fail(PPF_ERR_IO, "ppf_model_save: short write to %s", path);
+  return s;
+}
+
+/* the same bytes into the caller's memory: no file in between (the FileStorage overloads of the C++ facade) */
+ppf_status ppf_model_save_mem(const ppf_model* m, void* buf, size_t cap, size_t* size) {
+  if (!m || !size) return fail(PPF_ERR_INVALID, "ppf_model_save_mem: NULL");
+  char* mem = nullptr;
+  size_t len = 0;
+  FILE* f = open_memstream(&mem, &len);
+  if (!f) return fail(PPF_ERR_NOMEM, "ppf_model_save_mem: out of memory");
+  ppf_status s = model_write(m, f, "memory");
+  if (fclose(f) != 0 && s == PPF_OK) s = fail(PPF_ERR_NOMEM, "ppf_model_save_mem: out of memory");
+  if (s == PPF_OK) {
+    *size = len;
+    if (buf && cap >= len) memcpy(buf, mem, len);
+    else if (buf) s = fail(PPF_ERR_CAPACITY, "ppf_model_save_mem: need %zu bytes", len);
+  }
+  free(mem);
+  return s;
 }
 
 /* Everything read from the file is checked before it reaches a kernel: header fields against each other and against
  * the file size, the CSR rows, the record rows (LDS byte offsets k_vote adds to) and alphas, the slot map's ranks.  A file
  * that fails any check is PPF_ERR_IO; no exception leaves this function. */
+static ppf_status model_load_stream(FILE* f, const char* path, ppf_model** out, bool check_only);
+
 static ppf_status model_load_impl(const char* path, ppf_model** out, bool check_only) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(PPF_ERR_IO, "ppf_model_load: cannot open %s", path);
   struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+  return model_load_stream(f, path, out, check_only);
+}
+
+static ppf_status model_load_stream(FILE* f, const char* path, ppf_model** out, bool check_only) {
   auto bad = [&](const char* what) { return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file (%s)", path, what); };
   if (fseek(f, 0, SEEK_END) != 0) return bad("seek");
   const long fsize = ftell(f);
@@ -575,6 +605,23 @@ ppf_status ppf_model_load(const char* path, ppf_model** out) {
     return fail(PPF_ERR_NOMEM, "ppf_model_load: out of host memory reading %s", path);
   } catch (...) {
     return fail(PPF_ERR_IO, "ppf_model_load: %s is not a valid model file", path);
+  }
+}
+
+ppf_status ppf_model_load_mem(const void* buf, size_t size, ppf_model** out) {
+  if (!buf || !out) return fail(PPF_ERR_INVALID, "ppf_model_load_mem: NULL");
+  *out = nullptr;
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_load_mem: no HIP device");
+  if (size == 0) return fail(PPF_ERR_IO, "ppf_model_load: memory is not a valid model file (empty)");
+  FILE* f = fmemopen(const_cast<void*>(buf), size, "rb");
+  if (!f) return fail(PPF_ERR_NOMEM, "ppf_model_load_mem: out of memory");
+  struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+  try {
+    return model_load_stream(f, "memory", out, false);
+  } catch (const std::bad_alloc&) {
+    return fail(PPF_ERR_NOMEM, "ppf_model_load_mem: out of host memory");
+  } catch (...) {
+    return fail(PPF_ERR_IO, "ppf_model_load_mem: not a valid model");
   }
 }
 

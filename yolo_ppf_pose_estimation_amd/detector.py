@@ -197,6 +197,22 @@ class PPF3DDetector:
         mi = self.info()
         return self
 
+    def to_bytes(self) -> bytes:
+        """The model file's byte stream in memory (ppf_model_save_mem)."""
+        self._require_trained()
+        n = C.c_size_t(0)
+        check(lib().ppf_model_save_mem(self._model.ptr, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        check(lib().ppf_model_save_mem(self._model.ptr, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value]
+
+    def from_bytes(self, data: bytes):
+        """ppf_model_load_mem: the same validation as read()."""
+        out = C.c_void_p()
+        check(lib().ppf_model_load_mem(data, len(data), C.byref(out)))
+        self._model = _ModelHandle(out.value)
+        return self
+
     # -- matching -----------------------------------------------------------------------------------
     def _require_trained(self):
         if self._model is None:
