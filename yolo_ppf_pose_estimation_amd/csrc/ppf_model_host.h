@@ -122,18 +122,24 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   HIPCHK(m->bucket_slot.reserve(std::max<uint32_t>(n_buckets, 1)));
   HIPCHK(hipMemsetAsync(counts.p, 0, ncnt * sizeof(uint32_t), st));
   /* Dealing order inside a bucket (see "table layout" above): two levels (the accumulator-word half of the entry's row),
-   * inside a level every bank's entries in phase order, spread evenly over the level. */
+   * a level cut into up to gmax cell groups, inside a group every bank's entries in phase order, spread evenly over it. */
   const int levels = 2;
-  const size_t ncls = ncnt * (size_t)levels * DEAL_BANKS;
-  DevBuf<uint32_t> class_cnt, class_cur;
-  HIPCHK(class_cnt.reserve(ncls));
-  HIPCHK(class_cur.reserve(ncls));
-  HIPCHK(hipMemsetAsync(class_cnt.p, 0, ncls * sizeof(uint32_t), st));
-  HIPCHK(hipMemsetAsync(class_cur.p, 0, ncls * sizeof(uint32_t), st));
+  uint32_t gmax = 32; /* fewer groups when the class keys would not fit 32 bits or the group counters would be unreasonably big */
+  while (gmax > 1 && (ncnt * (size_t)levels * gmax * DEAL_BANKS >= 0xFFFFFFF0ull || ncnt * (size_t)levels * gmax * sizeof(uint32_t) > ((size_t)1 << 30)))
+    gmax >>= 1;
+  if (ncnt * (size_t)levels * gmax * DEAL_BANKS >= 0xFFFFFFF0ull)
+    return fail(PPF_ERR_INVALID, "ppf_model_train: %u buckets x %d tiles are more than the table build can key", n_buckets, T);
+  DevBuf<uint32_t> level_cnt, mirror_cur, group_cnt;
+  HIPCHK(level_cnt.reserve(ncnt * levels));
+  HIPCHK(mirror_cur.reserve(ncnt));
+  HIPCHK(group_cnt.reserve(ncnt * levels * gmax));
+  HIPCHK(hipMemsetAsync(level_cnt.p, 0, ncnt * levels * sizeof(uint32_t), st));
+  HIPCHK(hipMemsetAsync(mirror_cur.p, 0, ncnt * sizeof(uint32_t), st));
+  HIPCHK(hipMemsetAsync(group_cnt.p, 0, ncnt * levels * gmax * sizeof(uint32_t), st));
   const unsigned nblk = (unsigned)((NN + 255) / 256);
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
                                                 m->info.tile_refs, T, m->info.num_angles, levels, counts.p, nullptr,
-                                                class_cnt.p, class_cur.p, nullptr, m->bucket_slot.p, 0);
+                                                level_cnt.p, mirror_cur.p, nullptr, gmax, nullptr, m->bucket_slot.p, 0);
   HIPCHK(hipGetLastError());
   /* real entries (N(N-1) + mirrored spill entries) */
   s = device_exclusive_scan(counts.p, offsets.p, ncnt, st);
@@ -162,14 +168,14 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
     k_record_init<<<dim3((n_records + 255) / 256), dim3(256), 0, st>>>(m->records.p, n_records, m->info.num_angles);
     HIPCHK(hipGetLastError());
   }
-  DevBuf<uint32_t> pair_pos; /* dealing position of every pair inside its (tile, bucket, level) */
+  DevBuf<uint32_t> pair_pos; /* dealing position of every pair inside its (tile, bucket, level, cell group) */
   {
-    DevBuf<uint32_t> kcls, kph, v1, kt, v2, starts, pair_rank;
+    DevBuf<uint32_t> kcls, kph, v1, kt, v2, starts, pair_rank, pair_n;
     HIPCHK(kcls.reserve(NN)); HIPCHK(kph.reserve(NN)); HIPCHK(v1.reserve(NN)); HIPCHK(kt.reserve(NN)); HIPCHK(v2.reserve(NN));
-    HIPCHK(pair_rank.reserve(NN)); HIPCHK(pair_pos.reserve(NN));
-    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 2 * DEAL_BANKS);
+    HIPCHK(pair_rank.reserve(NN)); HIPCHK(pair_n.reserve(NN)); HIPCHK(pair_pos.reserve(NN));
+    const uint32_t invalid = (uint32_t)((size_t)T * n_buckets * 2 * gmax * DEAL_BANKS);
     k_train_keys<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets, m->info.tile_refs,
-                                                   m->info.num_angles, invalid, kcls.p, kph.p, v1.p);
+                                                   m->info.num_angles, level_cnt.p, gmax, group_cnt.p, invalid, kcls.p, kph.p, v1.p);
     HIPCHK(hipGetLastError());
     /* (1) rank of every pair by phase inside its (tile, bucket, level, bank): two stable sorts (phase, then group) */
     uint32_t* va = nullptr;
@@ -184,11 +190,11 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
       s = sort_segments(kph, vin, kt, vtmp, (int)NN, (unsigned long long)invalid, starts, &va, &n_runs, st);
       if (s != PPF_OK) return s;
     }
-    k_train_ranks<<<dim3(nblk), dim3(256), 0, st>>>(va, starts.p, n_runs, NN, pair_rank.p);
+    k_train_ranks<<<dim3(nblk), dim3(256), 0, st>>>(va, starts.p, n_runs, NN, pair_rank.p, pair_n.p);
     HIPCHK(hipGetLastError());
-    /* (2) position inside the level: the banks' entries spread evenly, i.e. sorted by (rank + 1/2) / bank size; ties keep
+    /* (2) position inside the cell group: the banks' entries spread evenly, i.e. sorted by (rank + 1/2) / class size; ties keep
      * the pair order (stable sorts from the identity) */
-    k_train_spread<<<dim3(nblk), dim3(256), 0, st>>>(kcls.p, pair_rank.p, class_cnt.p, invalid, NN, kph.p, kt.p, v1.p);
+    k_train_spread<<<dim3(nblk), dim3(256), 0, st>>>(kcls.p, pair_rank.p, pair_n.p, invalid, NN, kph.p, kt.p, v1.p);
     HIPCHK(hipGetLastError());
     {
       DevBuf<uint32_t> kseg;
@@ -210,7 +216,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   }
   k_train_bin<<<dim3(nblk), dim3(256), 0, st>>>(pair_slot.p, pair_alpha.p, N, m->slotmap.p, (int)n_buckets,
                                                 m->info.tile_refs, T, m->info.num_angles, levels, counts.p, offsets.p,
-                                                class_cnt.p, class_cur.p, m->records.p, nullptr, 1, pair_pos.p);
+                                                level_cnt.p, mirror_cur.p, group_cnt.p, gmax, m->records.p, nullptr, 1, pair_pos.p);
   HIPCHK(hipGetLastError());
   HIPCHK(m->bucket_total.reserve(std::max<uint32_t>(n_buckets, 1)));
   if (n_buckets) {

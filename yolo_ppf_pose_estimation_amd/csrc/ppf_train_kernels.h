@@ -216,6 +216,12 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  *     entries (a model row that owns much of the bucket) as well as one with few -- dealing the banks round robin
  *     left the tail of a level to the few heavy banks (1.32 serialised passes per 16 counted adds on the headline
  *     table, against 1.09 now; direct votes with their jitter 1.58 -> 1.31).
+ *   - the level is first cut into up to 32 CELL GROUPS of at least 64 entries each (deal_groups): group = the entry's
+ *     count-table cell q (the 1/32 of an alpha bin its alpha_m sits in) scaled to the number of groups; the spreading
+ *     above happens inside each group.  A level of 2,048 entries or more is thereby sorted by cell exactly, so the 128
+ *     entries of a record block share one cell (two at a group boundary): the lanes of k_vote's own-cell loop then walk the
+ *     same hits for the same number of steps and read the same table rows (round 2 ordered a whole level by the
+ *     per-bank phase quantile, which scattered a block over 3-5 cells: the loop ran as long as the fullest of them).
  * Dealing position j -> record 32*(j/64) + j%32, slot (j%64)/32: 32 consecutive dealing positions share a slot of
  * 32 consecutive records (lanes 16g .. 16g+15 of a wave-instruction are 16 consecutive dealing positions).  Unused slots of the last records hold dummies that vote into the LDS guard words.
  */
@@ -225,6 +231,22 @@ __device__ uint32_t agg_cell_bits(float am, int A); /* ppf_match_kernels.h */
 #define PPF_DEAL_BANKS 32
 #endif
 constexpr uint32_t DEAL_BANKS = PPF_DEAL_BANKS; /* LDS banks the dealing order spreads a bucket's entries over */
+
+/* cell groups of a level of n entries: the largest power of two <= gmax that leaves every group PPF_DEAL_GROUP_MIN entries on
+ * average (a group must be several 32-entry windows long for the bank spreading inside it to work) */
+#ifndef PPF_DEAL_GROUP_MIN
+#define PPF_DEAL_GROUP_MIN 256
+#endif
+__host__ __device__ __forceinline__ uint32_t deal_groups(uint32_t n_level, uint32_t gmax) {
+  uint32_t g = 1;
+  while (g < gmax && n_level >= 2u * PPF_DEAL_GROUP_MIN * g) g <<= 1;
+  return g;
+}
+/* group of an entry: its count-table cell (0..AGG_Q-1, AGG_Q = votes one by one: last group) scaled to `groups` */
+__device__ __forceinline__ uint32_t deal_group_of(float alpha_m, int num_angles, uint32_t groups) {
+  const uint32_t q = min((agg_cell_bits(alpha_m, num_angles) >> ROW_Q_SHIFT) & 63u, 31u);
+  return (q * groups) >> 5;
+}
 
 __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
                                                   uint32_t* cls, uint32_t* lvl) {
@@ -241,22 +263,33 @@ __host__ __device__ __forceinline__ uint32_t records_for(uint32_t n_entries) {
 /* phase 0: count; phase 1: place (rec_off = record offset of the (tile, bucket)).
  * pos = the entry's dealing position inside its level (k_train_spread + sorts); mirror: one of the few mirrored spill
  * entries, which are not part of the sorts: they take the last positions of the low-half level */
+/* level_cnt[tb*2 + level]: entries of the level (mirrored ones included, they sit at the end of level 0);
+ * group_cnt[(tb*2 + level)*gmax + group]: sorted entries of each cell group (k_train_keys); mirror_cur[tb]: cursor of the mirrored
+ * entries.  pos = the entry's position inside its group (k_train_spread + sorts). */
 __device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_bytes, float am, int num_angles, int levels,
                                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
-                                            uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
+                                            uint32_t* __restrict__ level_cnt, uint32_t* __restrict__ mirror_cur,
+                                            const uint32_t* __restrict__ group_cnt, uint32_t gmax,
                                             uint4* __restrict__ records, bool mirror, uint32_t pos) {
   uint32_t c, lv;
   entry_class_level(row_bytes, am, num_angles, levels, &c, &lv);
-  const size_t cbase = tb * (size_t)levels * DEAL_BANKS;
   if (phase == 0) {
     atomicAdd(&counts[tb], 1u);
-    atomicAdd(&class_cnt[cbase + lv * DEAL_BANKS + c], 1u);
+    atomicAdd(&level_cnt[tb * 2 + lv], 1u);
     return;
   }
-  uint32_t n0 = 0; /* entries of the low-half level */
-  if (lv || mirror)
-    for (uint32_t cc = 0; cc < DEAL_BANKS; cc++) n0 += class_cnt[cbase + cc];
-  const uint32_t j = mirror ? n0 - 1u - atomicAdd(&class_cur[cbase], 1u) : (lv ? n0 : 0u) + pos;
+  const uint32_t n0 = level_cnt[tb * 2]; /* entries of the low-half level */
+  uint32_t j;
+  if (mirror) {
+    j = n0 - 1u - atomicAdd(&mirror_cur[tb], 1u);
+  } else {
+    /* the same group as k_train_keys gave the entry: both size the groups from the level's count */
+    const uint32_t groups = deal_groups(level_cnt[tb * 2 + lv], gmax), g = deal_group_of(am, num_angles, groups);
+    uint32_t before = 0;
+    const uint32_t* gc = group_cnt + (tb * 2 + lv) * (size_t)gmax;
+    for (uint32_t k = 0; k < g; k++) before += gc[k];
+    j = (lv ? n0 : 0u) + before + pos;
+  }
   uint32_t* rec = reinterpret_cast<uint32_t*>(&records[rec_off[tb] + 32u * (j / 64u) + (j % 32u)]);
   const uint32_t slot = (j % 64u) / 32u;
   rec[slot] = row_bytes | agg_cell_bits(am, num_angles);
@@ -266,7 +299,8 @@ __device__ __forceinline__ void place_entry(int phase, size_t tb, uint32_t row_b
 __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
                             const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int n_tiles,
                             int num_angles, int levels, uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_off,
-                            uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_cur,
+                            uint32_t* __restrict__ level_cnt, uint32_t* __restrict__ mirror_cur,
+                            const uint32_t* __restrict__ group_cnt, uint32_t gmax,
                             uint4* __restrict__ records, uint32_t* __restrict__ bucket_slot, int phase,
                             const uint32_t* __restrict__ pair_rank = nullptr) {
   const size_t total = (size_t)n_model * n_model;
@@ -280,18 +314,20 @@ __global__ void k_train_bin(const uint32_t* __restrict__ pair_slot, const float*
   const float am = pair_alpha[idx];
   if (phase == 0 && bucket_slot) bucket_slot[b] = slot;
   place_entry(phase, (size_t)tile * n_buckets + b, vote_row_code(i - tile * tile_refs, tile_refs, num_angles), am, num_angles,
-              levels, counts, rec_off, class_cnt, class_cur, records, false, pair_rank ? pair_rank[idx] : 0u);
+              levels, counts, rec_off, level_cnt, mirror_cur, group_cnt, gmax, records, false, pair_rank ? pair_rank[idx] : 0u);
   /* alpha bin == numAngles spills into the next model reference point's bin 0 (see k_vote); when
    * that point lives in the next tile, the entry is mirrored there: bin A -> cell 0, others -> guard. */
   if (am >= SPILL_ALPHA_MIN && tile + 1 < n_tiles && i == (tile + 1) * tile_refs - 1)
     place_entry(phase, (size_t)(tile + 1) * n_buckets + b, (uint32_t)((vote_guard(num_angles) - num_angles) * 4), am,
-                num_angles, levels, counts, rec_off, class_cnt, class_cur, records, true, 0u);
+                num_angles, levels, counts, rec_off, level_cnt, mirror_cur, group_cnt, gmax, records, true, 0u);
 }
 
-/* sort keys of the model pairs for the dealing order: key_class = ((tile*n_buckets + bucket)*2 + level)*64 + bank (invalid pairs:
- * `invalid`), key_phase = position of alpha_m inside its bin, 16 bits */
+/* sort keys of the model pairs for the dealing order: key_class = (((tile*n_buckets + bucket)*2 + level)*gmax + cell group)*DEAL_BANKS
+ * + bank (invalid pairs: `invalid`), key_phase = position of alpha_m inside its bin, 16 bits; also counts the entries of every
+ * cell group */
 __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__ pair_slot, const float* __restrict__ pair_alpha, int n_model,
                                                     const SlotWord* __restrict__ slotmap, int n_buckets, int tile_refs, int num_angles,
+                                                    const uint32_t* __restrict__ level_cnt, uint32_t gmax, uint32_t* __restrict__ group_cnt,
                                                     uint32_t invalid, uint32_t* __restrict__ key_class, uint32_t* __restrict__ key_phase,
                                                     uint32_t* __restrict__ vals) {
   const size_t total = (size_t)n_model * n_model;
@@ -308,13 +344,16 @@ __global__ __launch_bounds__(256) void k_train_keys(const uint32_t* __restrict__
   uint32_t c, lv;
   entry_class_level(row_bytes, am, num_angles, 2, &c, &lv);
   const float q = am * (float)((double)num_angles / (4 * PPF_PI)) + 0.5f * (float)num_angles;
-  key_class[idx] = (uint32_t)((((size_t)tile * n_buckets + b) * 2 + lv) * DEAL_BANKS + c);
+  const size_t seg = ((size_t)tile * n_buckets + b) * 2 + lv;
+  const uint32_t g = deal_group_of(am, num_angles, deal_groups(level_cnt[seg], gmax));
+  atomicAdd(&group_cnt[seg * gmax + g], 1u);
+  key_class[idx] = (uint32_t)((seg * gmax + g) * DEAL_BANKS + c);
   key_phase[idx] = min((uint32_t)((q - floorf(q)) * 65536.0f), 65535u);
 }
 /* second stage of the dealing order: key_frac = (k + 1/2) / n as a 32-bit fraction, k = the pair's rank by phase inside its
- * (tile, bucket, level, bank) and n that group's size; key_seg = (tile*n_buckets + bucket)*2 + level */
+ * (tile, bucket, level, cell group, bank) and n that class's size; key_seg = ((tile*n_buckets + bucket)*2 + level)*gmax + cell group */
 __global__ __launch_bounds__(256) void k_train_spread(const uint32_t* __restrict__ key_class, const uint32_t* __restrict__ pair_rank,
-                                                      const uint32_t* __restrict__ class_cnt, uint32_t invalid, size_t n,
+                                                      const uint32_t* __restrict__ pair_n, uint32_t invalid, size_t n,
                                                       uint32_t* __restrict__ key_frac, uint32_t* __restrict__ key_seg,
                                                       uint32_t* __restrict__ vals) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(256) void k_train_spread(const uint32_t* __restrict
   vals[idx] = (uint32_t)idx;
   const uint32_t kc = key_class[idx];
   if (kc == invalid) { key_frac[idx] = 0u; key_seg[idx] = invalid / DEAL_BANKS; return; }
-  const uint32_t nb = class_cnt[kc]; /* >= rank + 1 */
+  const uint32_t nb = pair_n[idx]; /* >= rank + 1 */
   key_frac[idx] = (uint32_t)((((unsigned long long)(2u * pair_rank[idx] + 1u)) << 31) / nb);
   key_seg[idx] = kc / DEAL_BANKS;
 }
@@ -331,9 +370,10 @@ __global__ __launch_bounds__(256) void k_gather_u32(const uint32_t* __restrict__
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) dst[p] = src[idx[p]];
 }
-/* rank of every pair inside its run of equal class keys: pair_rank[vals[p]] = p - start of p's run */
+/* rank of every pair inside its run of equal class keys: pair_rank[vals[p]] = p - start of p's run; pair_n (optional) = the
+ * run's length */
 __global__ __launch_bounds__(256) void k_train_ranks(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ starts, uint32_t n_runs,
-                                                     size_t n, uint32_t* __restrict__ pair_rank) {
+                                                     size_t n, uint32_t* __restrict__ pair_rank, uint32_t* __restrict__ pair_n = nullptr) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   uint32_t lo = 0, hi = n_runs; /* last run start <= p */
@@ -342,6 +382,7 @@ __global__ __launch_bounds__(256) void k_train_ranks(const uint32_t* __restrict_
     if ((size_t)starts[mid] <= p) lo = mid; else hi = mid;
   }
   pair_rank[vals[p]] = (uint32_t)(p - starts[lo]);
+  if (pair_n) pair_n[vals[p]] = (lo + 1 < n_runs ? starts[lo + 1] : (uint32_t)n) - starts[lo];
 }
 
 __global__ void k_record_counts(const uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_cnt, size_t n) {
