@@ -33,6 +33,7 @@ The ONE line printed by rank 0 carries
   host_entry     (N = 1, c2) the call the reference really makes: ppf_match from HOST memory, upload and read-back
                  included (SURVEY section 8d's "poses/s per crop"), on a warm context
   other_configs  (N = 1, c2) C4 and C5 measured in the same run, 2 steps each, with the same roofline fields
+  pipelined      (N = 1, c2) throughput with two independent crops in flight (extra information, never `value`)
   cpu_baseline   the CPU oracle (kind "port", -O3 -march=native build made on this box) on a bounded sample of the
                  same workload: min and median of 5 repetitions on all usable cores plus a 1-thread figure; N = 1 only
 """
@@ -618,6 +619,16 @@ def main(argv=None):
                 line["cpu_baseline"] = cpu_baseline(res["model_step"], bottle, res["scene"], res["n_ref_total"], args.cpu_seconds)
             else:
                 line["cpu_baseline"] = None
+            if world == 1 and args.config == "c2" and not args.no_other_configs and res["depth"] == 1:
+                # what a serving loop gets from keeping two independent crops in flight on two streams (k_pairs / k_group of
+                # one under k_vote of the other).  Extra information only: `value`, kernel_ms and the rooflines above come
+                # from the strictly serial steps, whose HIP-event kernel times are the kernels' own
+                rp = run_single("c2", max(args.steps, 10), 3, depth_arg=2, scene=res["scene"])
+                line["pipelined"] = {"crops_in_flight": rp["depth"], "ms_per_step": rp["elapsed"] / max(args.steps, 10) * 1e3,
+                                     "pair_matches_per_s": rp["tally"]["votes"] / rp["elapsed"],
+                                     "note": "same crop and model, steps enqueued two deep; per-kernel event times of such a run "
+                                             "overlap and are not reported"}
+                del rp
             if world == 1 and args.config == "c2" and not args.no_other_configs:
                 # the other single-GPU configurations of BASELINE.json under the same clock: 2 steps each
                 del res

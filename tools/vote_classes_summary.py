@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-class attribution of k_vote from the attribution builds (tools/vote_variants.sh on build_var/a_*.so).
 
-    python tools/vote_classes_summary.py gpurun_out/r03_e3 PRODUCT_NAME > profiles/r03_vote_classes.md
+    python tools/vote_classes_summary.py gpurun_out/r03_final/classes product r03 > profiles/r03_vote_classes.md
 
 Every class is priced as (product build) - (build without that class): kernel time (HIP events, 10 steps), LDS
 wave-instructions, LDS-array cycles, bank- and address-conflict cycles, VALU wave-instructions, and the share of wave time
@@ -27,6 +27,7 @@ def counters(d):
 
 def main():
     root, prod = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
 
     def load(name):
         b = json.load(open(os.path.join(root, name + ".json")))
@@ -79,7 +80,12 @@ def main():
         print(f"\n`{extra}` — {lab}: {v['ms']:.3f} ms, {v['lds'] / 1e6:.1f} M LDS wave-instructions at {v['idx'] / v['lds']:.2f} array cycles, "
               f"{v['valu'] / 1e6:.0f} M VALU, SQ_WAIT_ANY {v['wait']:.1%}, SQ_WAIT_INST_LDS {v['wait_lds']:.1%}.")
         out[extra] = v
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_vote_classes.json"), "w"), indent=1)
+    print("\nHow to read it (arithmetic in DESIGN.md section 4): the LDS pipe charges an atomic or a store 4 cycles and a read 2.3 whatever its lanes "
+          "do, plus what its array cycles exceed that by (profiles/r03_ubench_lds_counters.md), so a class whose instructions average 4 array cycles or "
+          "fewer pays nothing for its conflicts: the counted atomics own the largest share of the conflict cycles and none of their cost; the direct "
+          "votes' conflicts (above 4.5 array cycles per instruction) are the ones that cost.  The times add up to the product's: the classes do not hide "
+          "each other, a wave's work items are a serial chain (claim, look-up, loads, votes) and neither the LDS pipe nor the VALU is saturated.")
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", f"{tag}_vote_classes.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
