@@ -429,7 +429,10 @@ def main(argv=None):
         # Crops are independent, so consecutive steps CAN be software-pipelined like a serving loop would do.  The
         # default is depth 1: with overlap the per-kernel HIP-event times `roofline` is computed from are stretched.
         depth = max(1, min(depth_arg, max(n_warm, 1)))
-        streams = [torch.cuda.Stream() for _ in range(depth)]
+        # HIP maps streams onto a few hardware queues round robin: two streams created late in a process can share one and
+        # then do not overlap at all.  With as many streams as there are queues, consecutive steps sit on different queues
+        # wherever the sequence starts.
+        streams = [torch.cuda.Stream() for _ in range(1 if depth == 1 else 4)]
         wss = [Workspace(timing=True) for _ in range(depth)]
         if cells == "32":
             for w_ in wss:
@@ -443,13 +446,13 @@ def main(argv=None):
         last, gathered = {}, {}
 
         def enqueue(i):
-            s = streams[i % depth]
+            s = streams[i % len(streams)]
             with torch.cuda.stream(s):
                 wss[i % depth].match_device(det, d_scene.data_ptr(), n_scene, 6, W.SCENE_STEP, W.REL_DISTANCE,
                                             presampled=True, stream=s.cuda_stream, **ref_kw)
 
         def collect(i, timed):
-            ws, s = wss[i % depth], streams[i % depth]
+            ws, s = wss[i % depth], streams[i % len(streams)]
             with torch.cuda.stream(s):
                 st = ws.stats()  # waits for that step's stream (and re-runs a step whose scratch estimate was too small)
                 if shard:
@@ -516,7 +519,20 @@ def main(argv=None):
         run(n_steps, True)
         sync()
         elapsed = time.perf_counter() - t0
-        return {"elapsed": elapsed, "tally": tally, "kernel_ms": {k: float(np.mean(v)) for k, v in ms.items()},
+        overlapped = {k: float(np.mean(v)) for k, v in ms.items()}
+        # kernel times for the rooflines: the lanes of the timed steps overlap, which stretches every kernel's event time by
+        # an amount that changes from run to run; one more step on a SINGLE lane gives each kernel's own time
+        kernel_ms = overlapped
+        if bm.lanes > 1:
+            bm1 = BatchMatcher(lanes=1, timing=True)
+            one = {}
+            for rep in range(2):  # the first run of a batch context sizes its pools
+                r1 = bm1.run_device(dets, [t.data_ptr() for t in d_crops], [c.shape[0] for c in crops], 6, W.SCENE_STEP,
+                                    W.REL_DISTANCE, presampled=True, top_k=W.TOP_K)
+                one = {"k_vote": r1["ms_vote_kernel"], "k_pairs": r1["ms_pair_kernel"], "k_group": r1["ms_group_kernel"]}
+            kernel_ms = dict(one, lanes_overlapped=overlapped)
+            del bm1
+        return {"elapsed": elapsed, "tally": tally, "kernel_ms": kernel_ms,
                 "info": dets[0].info(), "n_models": len(dets), "n_crops": len(crops), "lanes": bm.lanes,
                 "n_scene": W.C2["n_points"]}
 
@@ -644,7 +660,9 @@ def main(argv=None):
                 other["c5"] = dict(leg_fields("c5", r5, 2), workload=describe("c5"), batch_lanes=r5["lanes"],
                                    crops_per_s=r5["n_crops"] * 2 / r5["elapsed"],
                                    matches_per_s=r5["n_models"] * r5["n_crops"] * 2 / r5["elapsed"],
-                                   kernel_ms_note="sums over the 32 matches of a step; the lanes overlap, so they exceed ms_per_step")
+                                   kernel_ms_note="sums over the 32 matches of one extra step run on a single lane (each kernel alone on the device); "
+                                                  "lanes_overlapped = the same sums over the timed steps, whose lanes overlap and stretch every "
+                                                  "kernel's event time")
                 line["other_configs"] = other
         print(json.dumps(line), flush=True)
     if world > 1:
