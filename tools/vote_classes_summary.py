@@ -67,7 +67,8 @@ def main():
         if not isinstance(name, tuple):
             for k in d:
                 tot[k] += d[k]
-        print(f"| {label} | {d['ms']:.3f} | {d['lds'] / 1e6:.1f} | {d['idx'] / max(d['lds'], 1):.2f} | {d['bank'] / 1e6:.0f} | {d['bank'] / p['bank']:.1%} | "
+        per = f"{d['idx'] / d['lds']:.2f}" if d["lds"] > 1e5 else "-"
+        print(f"| {label} | {d['ms']:.3f} | {d['lds'] / 1e6:.1f} | {per} | {d['bank'] / 1e6:.0f} | {d['bank'] / p['bank']:.1%} | "
               f"{d['addr'] / 1e6:.0f} | {d['valu'] / 1e6:.0f} | {wait:.1%} |")
     n = load("a_none")
     print(f"| everything else: staging, claims, item look-up, record loads and table reads of count-table items, clear, scan (build with all four vote "
