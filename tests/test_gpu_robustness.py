@@ -192,6 +192,53 @@ def test_two_host_threads_share_one_model(det, bottle):
             np.testing.assert_array_equal(tri, single[k])
 
 
+def test_host_entry_contexts_are_private_to_a_call_and_reused(det, bottle):
+    """The entry the reference binds to (detector.match -> ppf_match) borrows a warm context from the model.  Three host
+    threads calling it at once on one detector (more calls in flight than the two idle contexts a model keeps), crops of
+    different sizes, match and match_S2B mixed: every result equals the single-thread one, and so do later calls on the
+    contexts that stayed (their learned pool sizes come from other crops)."""
+    crops = [synth.make_scene(bottle, n_points=3000 + 1500 * k, seed=400 + k)[0] for k in range(4)]
+    edges = [c[::4].copy() for c in crops]
+
+    def run(k, s2b):
+        if s2b:
+            return det.raw_votes(crops[k], 1.0 / 10.0, 0.05, presampled=True, edge=edges[k])["triples"], \
+                [(p.numVotes, p.pose.tobytes()) for p in det.match_S2B(crops[k], edges[k], 1.0 / 10.0, 0.05, presampled=True)[:5]]
+        return det.raw_votes(crops[k], 1.0 / 10.0, 0.05, presampled=True)["triples"], \
+            [(p.numVotes, p.pose.tobytes()) for p in det.match(crops[k], 1.0 / 10.0, 0.05, presampled=True)[:5]]
+
+    single = {(k, s): run(k, s) for k in range(4) for s in (False, True)}
+    errors, out = [], {}
+
+    def worker(tid):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            got = []
+            for it in range(10):
+                k, s = (tid + it) % 4, (tid + it) % 3 == 0
+                got.append(((k, s), run(k, s)))
+            out[tid] = got
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tid in range(3):
+        assert len(out[tid]) == 10
+        for key, (tri, top) in out[tid]:
+            np.testing.assert_array_equal(tri, single[key][0])
+            assert top == single[key][1]
+    for key in single:  # the contexts that stayed idle serve later calls
+        tri, top = run(*key)
+        np.testing.assert_array_equal(tri, single[key][0])
+        assert top == single[key][1]
+
+
 def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_path):
     good = tmp_path / "detector_bottle.ppf"
     det.write(str(good))

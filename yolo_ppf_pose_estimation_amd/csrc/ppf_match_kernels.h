@@ -116,7 +116,12 @@ constexpr int AGG_Q = 32;             /* cells per alpha bin */
 constexpr int AGG_NY = 16;            /* integer parts Y + 8 of a hit */
 constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes; 3 hits per lane) */
 constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in [-8, 7] */
-constexpr int RUN_SEG = 512;          /* runs staged in LDS per segment (every segment costs the workgroup two dependent reads and three barriers: 256 -> 512 is worth 3 % on C2) */
+#ifndef PPF_RUN_SEG
+#define PPF_RUN_SEG 704
+#endif
+constexpr int RUN_SEG = PPF_RUN_SEG;  /* runs staged in LDS per segment (every segment costs the workgroup two dependent reads and three barriers: 256 -> 512 was worth
+                                         3 % on C2, whose reference points have about 580 runs: 704 is what the LDS leaves room for next to a 2,000-row tile) */
+static_assert(RUN_SEG % 64 == 0 && RUN_SEG <= 1024, "the staging loop gives one thread to a run and scans whole waves");
 constexpr int GROUP_BLOCK = 512;       /* two k_group workgroups per CU when the bucket counters fit half the LDS (0.705 -> 0.665 ms on C2) */
 constexpr int GROUP_MLP = 4;            /* hits a k_group thread has in flight per step of its two passes */
 constexpr int GROUP_MAX_BUCKETS = 36000; /* LDS counters of k_group per round (144 KB) */
@@ -133,9 +138,9 @@ constexpr int CUR_OVERFLOW = CUR_OVFCOUNT + CUR_STRIDE; /* bits 1, 2, 4: raw poo
 constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
 
 /* per-wave LDS scratch of the aggregated path */
-constexpr int AGG_ROW = 28;                           /* bytes per table row: 17 counts + padding; 7 words: rows q and q' never share a bank */
-constexpr int AGG_OFF_CE = 928;                       /* 33 rows end at 924 (row AGG_Q is all zero: entries that vote one by one) */
-constexpr int AGG_OFF_A32 = 1072;                     /* cell ends / starts: 33 u32 from 928 */
+constexpr int AGG_ROW = 20;                           /* bytes per table row: 17 counts + padding; 5 words: the same word of rows q and q' never shares a bank */
+constexpr int AGG_OFF_CE = 672;                       /* 33 rows end at 660 (row AGG_Q is all zero: entries that vote one by one) */
+constexpr int AGG_OFF_A32 = 816;                      /* cell ends / starts: 33 u32 from 672 */
 constexpr int AGG_OFF_IDX = AGG_OFF_A32 + 768;        /* folded offsets Ohg of the hits in cell order: AGG_SUB x 4 B (first: 512 B of byte counters) */
 constexpr int AGG_SCRATCH = AGG_OFF_IDX + 192;        /* position of each sorted hit inside the table's hit range: AGG_SUB x 1 B */
 static_assert((AGG_Q + 1) * AGG_ROW <= AGG_OFF_CE, "table rows overlap the cell table");
