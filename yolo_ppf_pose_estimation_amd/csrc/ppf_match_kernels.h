@@ -123,7 +123,10 @@ constexpr int RUN_SEG = PPF_RUN_SEG;  /* runs staged in LDS per segment (every s
                                          3 % on C2, whose reference points have about 580 runs: 704 is what the LDS leaves room for next to a 2,000-row tile) */
 static_assert(RUN_SEG % 64 == 0 && RUN_SEG <= 1024, "the staging loop gives one thread to a run and scans whole waves");
 constexpr int GROUP_BLOCK = 512;       /* two k_group workgroups per CU when the bucket counters fit half the LDS (0.705 -> 0.665 ms on C2) */
-constexpr int GROUP_MLP = 4;            /* hits a k_group thread has in flight per step of its two passes */
+#ifndef PPF_GROUP_MLP
+#define PPF_GROUP_MLP 4
+#endif
+constexpr int GROUP_MLP = PPF_GROUP_MLP; /* hits a k_group thread has in flight per step of its two passes */
 constexpr int GROUP_MAX_BUCKETS = 36000; /* LDS counters of k_group per round (144 KB) */
 constexpr int POOL_STRIPES = 64;      /* the raw hit pool is cut into stripes with one cursor each */
 constexpr int LDS_HEADER = 256;       /* bytes: reduction scratch (16 words) + claim counter */
