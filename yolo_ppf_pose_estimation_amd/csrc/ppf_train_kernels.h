@@ -202,28 +202,31 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  * The entries of a (tile, bucket) are stored as PAIR RECORDS {row_a, row_b, alpha_a, alpha_b} (16 B): a lane of
  * k_vote loads one record (global_load_dwordx4), computes both alpha bins with one v_pk_fma_f32 and casts two
  * LDS atomics.  One ds_add_u32 wave-instruction therefore covers the a-slots (or the b-slots) of 64 consecutive
- * records; the LDS pipe takes them in groups of 16 lanes and serialises the lanes of a group that meet in one of its 64
- * banks (profiles/r02_ubench_lds_ops.txt).  Entries are therefore put in a DEALING ORDER in which 16 consecutive entries
- * hit (almost always) 16 different banks:
- *   - bank  c = (row_word + bin0(alpha_m)) mod 64: the bank of the vote when alpha_s == 0, and of the counted adds of
+ * records; the LDS serves it as two halves of 32 lanes over 32 banks (bank = word address mod 32), one array cycle per
+ * distinct address on the fullest bank of a half, and charges the wave max(4 cycles, array cycles) -- two addresses on a
+ * bank are free, the third is not (profiles/r03_ubench_lds_counters.md; round 2 assumed 64 banks and groups of 16 lanes).
+ * Entries are therefore put in a DEALING ORDER in which the 32 consecutive entries of a half rarely put three on a bank:
+ *   - bank  c = (row_word + bin0(alpha_m)) mod 32: the bank of the vote when alpha_s == 0, and of the counted adds of
  *     the count-table path up to a constant; for another alpha_s all bins shift together, up to one bin of jitter
  *     decided by where alpha_m sits inside its bin;
  *   - level lv = the half of the accumulator words the entry's row owns (vote_row_code): the rows of the low halves are
  *     dealt first, so the records of a (tile, bucket) are those of its low-half rows, at most 32 mixed records, those of
  *     its high-half rows -- the launch with 32-bit cells walks only its half's share (k_bucket_mid);
  *   - inside a level the k-th entry (by phase) of a bank that holds n of them gets the key (k + 1/2) / n, and the
- *     entries are dealt in key order: every bank's entries are spread evenly over the level, a bank with many
- *     entries (a model row that owns much of the bucket) as well as one with few -- dealing the banks round robin
- *     left the tail of a level to the few heavy banks (1.32 serialised passes per 16 counted adds on the headline
- *     table, against 1.09 now; direct votes with their jitter 1.58 -> 1.31).
- *   - the level is first cut into up to 32 CELL GROUPS of at least 64 entries each (deal_groups): group = the entry's
- *     count-table cell q (the 1/32 of an alpha bin its alpha_m sits in) scaled to the number of groups; the spreading
- *     above happens inside each group.  A level of 2,048 entries or more is thereby sorted by cell exactly, so the 128
- *     entries of a record block share one cell (two at a group boundary): the lanes of k_vote's own-cell loop then walk the
- *     same hits for the same number of steps and read the same table rows (round 2 ordered a whole level by the
- *     per-bank phase quantile, which scattered a block over 3-5 cells: the loop ran as long as the fullest of them).
+ *     entries are dealt in key order: every bank's entries are spread evenly, a bank with many entries (a model row
+ *     that owns much of the bucket) as well as one with few -- dealing the banks round robin left the tail to the few
+ *     heavy banks;
+ *   - the level is first cut into up to 32 CELL GROUPS of at least PPF_DEAL_GROUP_MIN (256) entries each (deal_groups):
+ *     group = the entry's count-table cell q (the 1/32 of an alpha bin its alpha_m sits in) scaled to the number of
+ *     groups; the spreading above happens inside each group.  A level of 8,192 entries or more is thereby sorted by cell
+ *     exactly, so the 128 entries of a record block share one cell (two at a group boundary): the lanes of k_vote's
+ *     own-cell loop then walk the same hits for the same number of steps and read the same table rows (round 2 ordered
+ *     a whole level by the per-bank phase quantile, which scattered a block over 3-5 cells: the loop ran as long as the
+ *     fullest of them).  Smaller groups sort smaller levels exactly too but lose more to bank conflicts at the group
+ *     boundaries than the loop gains (profiles/r03_vote_variants.md).
  * Dealing position j -> record 32*(j/64) + j%32, slot (j%64)/32: 32 consecutive dealing positions share a slot of
- * 32 consecutive records (lanes 16g .. 16g+15 of a wave-instruction are 16 consecutive dealing positions).  Unused slots of the last records hold dummies that vote into the LDS guard words.
+ * 32 consecutive records (one half of a wave-instruction is 32 consecutive dealing positions).  Unused slots of the last
+ * records hold dummies that vote into the LDS guard words.
  */
 
 __device__ uint32_t agg_cell_bits(float am, int A); /* ppf_match_kernels.h */
