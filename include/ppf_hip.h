@@ -170,7 +170,7 @@ typedef struct ppf_match_stats {
   float ms_vote_kernel;    /* device time of the voting kernel, summed over the batches of the call (timing enabled) */
   float ms_pair_kernel;    /* pair kernel, likewise */
   float ms_total_device;   /* first kernel start -> last kernel end */
-  float ms_group_kernel;   /* hit grouping (k_group and the two rankings), likewise */
+  float ms_group_kernel;   /* hit grouping (k_group, the two rankings, the count tables), likewise */
   uint64_t n_hits;         /* scene pairs that found a non-empty bucket */
   uint64_t n_lds_atomics;  /* LDS atomic lane-operations the voting kernel issued (<= n_votes when runs vote by counts) */
   uint64_t scratch_bytes;  /* device scratch of the call: hit pools, run table, frames */
@@ -178,6 +178,7 @@ typedef struct ppf_match_stats {
   int32_t n_retries;       /* repeats because the hit pools (sized from earlier calls) were too small */
   uint64_t n_acc32_items;  /* (reference point, accumulator tile)s voted with 32-bit cells: those whose 16-bit cells overflowed, or all
                               of them once a workspace has seen a tenth of a call's votes cast in such ones (or with PPF_OPT_ACC32) */
+  uint64_t n_tables;       /* count tables built for the runs of many hits (one per 191 hits of such a run) */
 } ppf_match_stats;
 
 /* totals of one ppf_batch_run */
@@ -283,6 +284,7 @@ ppf_status ppf_workspace_destroy(ppf_workspace* ws);
 #define PPF_OPT_CLUSTER_SERIAL 3 /* != 0: the serial greedy cluster assignment (the path for > 11,520 poses) for any size */
 #define PPF_OPT_ACC32 4          /* != 0: 32-bit accumulator cells for every (reference point, tile) (otherwise 16-bit cells first, and 32-bit
                                    cells only for those the vote kernel saw overflow) */
+#define PPF_OPT_TABLE_FRACTION 5 /* expected count tables per hit (sizes the table pool of the next call; learned from then on) */
 ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);
 /* record HIP events around the kernels of each call (read back through ppf_workspace_results' stats) */
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);

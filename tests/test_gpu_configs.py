@@ -114,7 +114,7 @@ def test_c2_full_size_identities(det_c2):
     shuf = det_c2.raw_votes(scene[perm], STEP, W.REL_DISTANCE, presampled=True, ref_stride=50)
     np.testing.assert_array_equal(shuf["triples"], full["triples"][::50])
     # the scratch stays well below the worst case (one hit record per scene pair)
-    assert full["stats"]["scratch_bytes"] < 1.0e9 and full["stats"]["n_batches"] == 1
+    assert full["stats"]["scratch_bytes"] < 1.6e9 and full["stats"]["n_batches"] == 1
 
 
 def test_c2_crop_seen_twice_overflows_some_16_bit_cells(bottle, det_c2):

@@ -71,6 +71,24 @@ def test_hit_pools_that_start_too_small_are_grown(det, crop, oracle_crop):
     assert again["stats"]["scratch_bytes"] < res["stats"]["scratch_bytes"] * 4
 
 
+def test_a_count_table_pool_that_starts_too_small_is_grown(det, crop, oracle_crop):
+    """The pool of count tables (one per 191 hits of a run of >= 24 hits) is sized from the tables per hit the workspace has
+    seen.  One that starts far too small raises the device flag; the call is repeated with a bigger pool: same votes."""
+    want = _device_run(det, crop, skip_clustering=True)["stats"]
+    assert want["n_tables"] > 0
+    ws = Workspace()
+    ws.set_option(_capi.PPF_OPT_HIT_FRACTION, 0.5)
+    ws.set_option(_capi.PPF_OPT_TABLE_FRACTION, 1e-6)
+    res = _device_run(det, crop, ws, skip_clustering=True)
+    np.testing.assert_array_equal(res["triples"], oracle_crop["triples"])
+    assert res["stats"]["n_votes"] == want["n_votes"] and res["stats"]["n_tables"] == want["n_tables"]
+    if want["n_tables"] > 4 * want["n_ref"] + 256:  # the floor of the pool
+        assert res["stats"]["n_retries"] >= 1
+    again = _device_run(det, crop, ws, skip_clustering=True)
+    assert again["stats"]["n_retries"] == 0
+    np.testing.assert_array_equal(again["triples"], oracle_crop["triples"])
+
+
 def test_an_all_hit_scene_needs_the_worst_case_pool(det):
     """The model matched against its own sampled points: every pair finds a bucket.  A cold workspace counts its hits
     first, so even this scene (4x the default estimate) runs once."""
@@ -289,7 +307,7 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
     bad = bytearray(raw); bad[header + sampled + 8] ^= 0x01               # a slot map rank
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
-    # the row codes of the pair records (byte offset | word half in bit 0 | count-table X << 18 | cell << 23)
+    # the row codes of the pair records (byte offset | word half in bit 0 | count-table X << 18 | cell << 23, 7 bits)
     recs = np.frombuffer(bytes(raw[rec0:]), dtype=np.uint32).reshape(-1, 4)
     halves = recs[:, 0] & 1
     assert halves.any() and not halves.all()                               # one tile of 2 x H rows: both halves in use
@@ -303,7 +321,7 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     assert victim is not None
     bad = bytearray(raw); bad[rec0 + 16 * victim] ^= 0x01                  # a low-half row in the middle of the high-half ones
     assert load(bytes(bad)) == _capi.PPF_ERR_IO and "halves" in _capi.last_error()
-    bad = bytearray(raw); bad[rec0 + 3] |= 0x1F                            # cell 63 > 32 and a reserved bit
+    bad = bytearray(raw); bad[rec0 + 3] |= 0x3F                            # cell >= 126: beyond the count table's cells
     assert load(bytes(bad)) == _capi.PPF_ERR_IO and "cell" in _capi.last_error()
     bad = bytearray(raw); bad[8 + C.sizeof(_capi.TrainParams)] ^= 0x40     # n_ref in the header
     assert load(bytes(bad)) == _capi.PPF_ERR_IO

@@ -5,6 +5,7 @@ other values (made on the GPU box with hipcc, as tools/build_variant.sh does) mu
           -DPPF_TWO_QUEUES=1         count-table items and direct items claimed from two queues
           -DPPF_DEAL_BANKS=64        round 2's dealing order of the table's entries
   tuned   -DPPF_AGG_MIN_HITS=40 -DPPF_AGG_CHUNK=4096 -DPPF_PREFETCH=0 -DPPF_PIPE_VALU=2   other tunables
+  cells48 -DPPF_AGG_Q=48             count tables with 48 cells per alpha bin instead of 64 (a table layout of its own)
 
 Each variant runs in a child process (PPF_HIP_LIB selects the library before it is loaded)."""
 import os
@@ -45,6 +46,7 @@ print("VARIANT_OK")
 VARIANTS = {
     "exact": ["-DPPF_FORCE_EXACT", "-DPPF_TWO_QUEUES=1", "-DPPF_DEAL_BANKS=64"],
     "tuned": ["-DPPF_AGG_MIN_HITS=40", "-DPPF_AGG_CHUNK=4096", "-DPPF_PREFETCH=0", "-DPPF_PIPE_VALU=2"],
+    "cells48": ["-DPPF_AGG_Q=48"],
 }
 
 

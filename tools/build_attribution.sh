@@ -4,7 +4,7 @@
 # classes.  Extra flags are added to every build.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-for v in "counted0:-DPPF_ABL_COUNTED=0" "owncell0:-DPPF_ABL_OWNCELL=0" "build2:-DPPF_ABL_BUILD=2" "dsmall0:-DPPF_ABL_DIRECT_SMALL=0" \
+for v in "counted0:-DPPF_ABL_COUNTED=0" "owncell0:-DPPF_ABL_OWNCELL=0" "dsmall0:-DPPF_ABL_DIRECT_SMALL=0" \
          "dbig0:-DPPF_ABL_DIRECT_BIG=0" "dbig2:-DPPF_ABL_DIRECT_BIG=2" "aggonly:-DPPF_ABL_DIRECT_SMALL=0 -DPPF_ABL_DIRECT_BIG=0" \
          "directonly:-DPPF_ABL_COUNTED=0 -DPPF_ABL_OWNCELL=0" \
          "none:-DPPF_ABL_COUNTED=0 -DPPF_ABL_OWNCELL=0 -DPPF_ABL_DIRECT_SMALL=0 -DPPF_ABL_DIRECT_BIG=0"; do

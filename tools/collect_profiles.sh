@@ -26,7 +26,7 @@ if [ "$WHAT" = lines ]; then
     rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c4" -o c4 -- python3 "$ROOT/bench.py" --config c4 --cells 32 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c4.log" 2>&1
     rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c5" -o c5 -- python3 "$ROOT/bench.py" --config c5 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c5.log" 2>&1 )
   echo "traces done"
-  tools/vote_variants.sh "$OUT/classes" product a_counted0 a_owncell0 a_build2 a_dsmall0 a_dbig0 a_dbig2 a_aggonly a_directonly a_none
+  tools/vote_variants.sh "$OUT/classes" product a_counted0 a_owncell0 a_dsmall0 a_dbig0 a_dbig2 a_aggonly a_directonly a_none
 else
   tools/pmc_vote.sh "$OUT/pmc_c2"
   echo "pmc c2 done"

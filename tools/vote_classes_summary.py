@@ -38,11 +38,10 @@ def main():
 
     p = load(prod)
     rows = [("counted atomics + the table-row reads behind them (count-table items)", "a_counted0", -1),
-            ("own-cell loop: one-by-one votes of an entry's own 1/32 cell (count-table items)", "a_owncell0", -1),
+            ("own-cell loop: one-by-one votes of an entry's own 1/64 cell (count-table items)", "a_owncell0", -1),
             ("direct votes on buckets of more than 32 records (loads + votes)", "a_dbig0", -1),
             ("   of which: the record loads alone (build that loads but does not vote, minus the one that does neither)", ("a_dbig2", "a_dbig0"), +1),
-            ("direct votes on buckets of at most 32 records", "a_dsmall0", -1),
-            ("count-table builds (build that makes every table twice, minus the product)", "a_build2", +1)]
+            ("direct votes on buckets of at most 32 records", "a_dsmall0", -1)]
     print("# k_vote by class of work (C2, MI355X)\n")
     print(f"Product build `{prod}`: k_vote {p['ms']:.3f} ms, {p['lds'] / 1e6:.1f} M LDS wave-instructions, {p['idx'] / p['lds']:.2f} LDS-array cycles per "
           f"instruction of which {p['bank'] / p['lds']:.2f} bank-conflict and {p['addr'] / p['lds']:.2f} address-conflict cycles, {p['valu'] / 1e6:.0f} M VALU "
@@ -71,7 +70,7 @@ def main():
         print(f"| {label} | {d['ms']:.3f} | {d['lds'] / 1e6:.1f} | {per} | {d['bank'] / 1e6:.0f} | {d['bank'] / p['bank']:.1%} | "
               f"{d['addr'] / 1e6:.0f} | {d['valu'] / 1e6:.0f} | {wait:.1%} |")
     n = load("a_none")
-    print(f"| everything else: staging, claims, item look-up, record loads and table reads of count-table items, clear, scan (build with all four vote "
+    print(f"| everything else: staging, claims, item look-up, record loads and table copies of count-table items, clear, scan (build with all four vote "
           f"classes out) | {n['ms']:.3f} | {n['lds'] / 1e6:.1f} | {n['idx'] / n['lds']:.2f} | {n['bank'] / 1e6:.0f} | {n['bank'] / p['bank']:.1%} | {n['addr'] / 1e6:.0f} | "
           f"{n['valu'] / 1e6:.0f} | {n['wait']:.1%} |")
     print(f"| sum of the rows (without the sub-row) | {tot['ms'] + n['ms']:.3f} | {(tot['lds'] + n['lds']) / 1e6:.1f} | | {(tot['bank'] + n['bank']) / 1e6:.0f} | "
@@ -85,7 +84,8 @@ def main():
           "do, plus what its array cycles exceed that by (profiles/r03_ubench_lds_counters.md), so a class whose instructions average 4 array cycles or "
           "fewer pays nothing for its conflicts: the counted atomics own the largest share of the conflict cycles and none of their cost; the direct "
           "votes' conflicts (above 4.5 array cycles per instruction) are the ones that cost.  The times add up to the product's: the classes do not hide "
-          "each other, a wave's work items are a serial chain (claim, look-up, loads, votes) and neither the LDS pipe nor the VALU is saturated.")
+          "each other, a wave's work items are a serial chain (claim, look-up, loads, votes) and neither the LDS pipe nor the VALU is saturated.  "
+          "The count tables themselves are built by k_tables (its own line in the kernel statistics), once per run.")
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", f"{tag}_vote_classes.json"), "w"), indent=1)
 
 

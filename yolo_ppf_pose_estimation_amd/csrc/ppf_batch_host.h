@@ -189,6 +189,10 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
         at_full = fm->hit >= 1.0;
         if (flags & 3u) fm->hit = std::min(1.0, 2.0 * fm->hit);
         if (flags & 4u) fm->run = std::min(1.0, 2.0 * fm->run);
+        if (flags & 8u) {
+          if ((flags & 3u) == 0 && fm->tbl >= TBL_FRAC_MAX) fm->hit = std::min(1.0, 2.0 * fm->hit);
+          fm->tbl = std::min(TBL_FRAC_MAX, 2.0 * fm->tbl);
+        }
         s = enqueue_pair(lane, c, k);
         if (s != PPF_OK) return s;
         HIPCHK(hipStreamSynchronize(b->streams[lane]));
@@ -198,7 +202,7 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
     }
   }
   /* what every lane remembers per model: the densest crop it saw */
-  std::vector<double> lane_hit((size_t)b->lanes * n_models, 0.0), lane_run((size_t)b->lanes * n_models, 0.0);
+  std::vector<double> lane_hit((size_t)b->lanes * n_models, 0.0), lane_run((size_t)b->lanes * n_models, 0.0), lane_tbl((size_t)b->lanes * n_models, 0.0);
   ppf_batch_stats st{};
   for (size_t idx = 0; idx < n_match; idx++) {
     const unsigned long long* t = &tot[idx * 8];
@@ -206,16 +210,17 @@ ppf_status ppf_batch_run(ppf_batch* b, const ppf_model* const* models, int n_mod
     const size_t slot = (size_t)((idx / n_models) % b->lanes) * n_models + idx % n_models;
     if (t[1]) lane_hit[slot] = std::max(lane_hit[slot], (double)t[3] / (double)t[1]);
     if (t[3]) lane_run[slot] = std::max(lane_run[slot], (double)t[4] / (double)t[3]);
+    if (t[3]) lane_tbl[slot] = std::max(lane_tbl[slot], (double)t[7] / (double)t[3]);
   }
   for (int l = 0; l < b->lanes; l++) {
     ppf_workspace* ws = b->ws[l];
     workspace_hold_model(ws, nullptr); /* the next call looks its model up */
     for (int k = 0; k < n_models; k++) {
-      const double fh = lane_hit[(size_t)l * n_models + k], fr = lane_run[(size_t)l * n_models + k];
+      const double fh = lane_hit[(size_t)l * n_models + k], fr = lane_run[(size_t)l * n_models + k], ft = lane_tbl[(size_t)l * n_models + k];
       if (!(fh > 0)) continue;
       const double hit = std::min(1.0, std::max(1e-3, 1.06 * fh)), run = std::min(1.0, std::max(0.02, 1.10 * fr));
       ppf_workspace::Learned* fm = workspace_learned(ws, models[k], true);
-      fm->hit = hit; fm->run = run;
+      fm->hit = hit; fm->run = run; fm->tbl = std::min(TBL_FRAC_MAX, std::max(1e-4, 1.15 * ft));
     }
   }
   if (out) HIPCHK(hipMemcpy(out, b->d_out.p, n_match * cap * sizeof(ppf_pose), hipMemcpyDeviceToHost));

@@ -122,11 +122,17 @@ PPF_HD bool key_index(const KeyDims& d, const int32_t k0, const int32_t k1, cons
 PPF_HD size_t key_table_size(const KeyDims& d) { return (size_t)d.n0 * d.n1 * d.n2 * d.nd; }
 
 /* A pair record names a model row by a code: bits 0..17 the byte offset of the row's bin 0 in the LDS accumulator (a multiple
- * of 4) with the half of the word its 16-bit cells live in as bit 0; bits 18..22 and 23..28 the entry's X and cell q of the
+ * of 4) with the half of the word its 16-bit cells live in as bit 0; bits 18..22 and 23..29 the entry's X and cell q of the
  * count-table path (agg_cell: a function of alpha_m and numAngles alone, so the table build evaluates it once instead
  * of k_vote once per entry and range of hits: 3 % of the kernel) */
 constexpr uint32_t ROW_OFFSET_MASK = 0x3FFFCu, ROW_CODE_MASK = 0x3FFFFu;
 constexpr int ROW_X_SHIFT = 18, ROW_Q_SHIFT = 23;
+constexpr uint32_t ROW_Q_MASK = 127u; /* the cell field: bits 23..29 (0 .. AGG_Q, AGG_Q <= 64) */
+#ifndef PPF_AGG_Q
+#define PPF_AGG_Q 64
+#endif
+constexpr int AGG_Q = PPF_AGG_Q;      /* count-table cells per alpha bin (a multiple of 16, at most 64: one cell per lane in the table build) */
+static_assert(AGG_Q % 16 == 0 && AGG_Q >= 16 && AGG_Q <= 64, "count-table cells");
 
 /* ---- reference frame (row A4): R rotates n onto +x (Rodrigues about (0, n.z, -n.y)), t = -R p */
 PPF_HD void ppf_transform_rt(const ppf_vec3& p, const ppf_vec3& n, double* R, double* t) {

@@ -214,11 +214,13 @@ struct ppf_workspace {
   DevBuf<double> s_a64;
   DevBuf<uint16_t> s_cell;
   DevBuf<uint4> runs;
+  DevBuf<unsigned char> tables;          /* count tables of a batch's many-hit runs (k_tables -> k_vote), TBL_BYTES each */
+  DevBuf<uint2> table_desc;              /* what each table covers: {first sorted hit, hits} */
   DevBuf<uint2> run_blocks;
   DevBuf<unsigned long long> work;
   DevBuf<uint32_t> perm;
   DevBuf<uint32_t> perm_group;
-  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[5] */
+  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[6] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
   DevBuf<ppf_pose> d_final;
@@ -245,8 +247,9 @@ struct ppf_workspace {
   double hit_frac = 0.25;                /* expected hits per scene pair: sizes the hit pools, learned from every call */
   bool frac_known = false;               /* false: the next call first COUNTS its hits (one extra pair pass and one wait) */
   double run_frac = 0.4;                 /* expected runs (distinct buckets hit by a reference point) per hit, learned likewise */
-  struct Learned { uint64_t model_serial; double hit, run; };
-  std::vector<Learned> frac_by_model;    /* the two fractions remembered per model, at most 16 (batches alternate models): workspace_learned() */
+  double tbl_frac = TBL_FRAC_START;      /* expected count tables per hit, learned likewise (at most TBL_FRAC_MAX) */
+  struct Learned { uint64_t model_serial; double hit, run, tbl; };
+  std::vector<Learned> frac_by_model;    /* the three fractions remembered per model, at most 16 (batches alternate models): workspace_learned() */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
   bool acc32 = false;                    /* a 16-bit accumulator cell overflowed with this model: 32-bit cells until the model changes */
   bool force_acc32 = false;              /* PPF_OPT_ACC32 */

@@ -37,6 +37,10 @@ ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value)
     case PPF_OPT_ACC32:
       ws->force_acc32 = value != 0;
       return PPF_OK;
+    case PPF_OPT_TABLE_FRACTION:
+      if (!(value > 0 && value <= 1)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: table fraction must be in (0, 1]");
+      ws->tbl_frac = std::min(TBL_FRAC_MAX, value);
+      return PPF_OK;
     default:
       return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: unknown option %d", option);
   }
@@ -101,7 +105,7 @@ static ppf_workspace::Learned* workspace_learned(ppf_workspace* ws, const ppf_mo
     if (fm.model_serial == m->serial) return &fm;
   if (!create) return nullptr;
   if (ws->frac_by_model.size() >= 16) ws->frac_by_model.erase(ws->frac_by_model.begin());
-  ws->frac_by_model.push_back({m->serial, 0.25, 0.4});
+  ws->frac_by_model.push_back({m->serial, 0.25, 0.4, TBL_FRAC_START});
   return &ws->frac_by_model.back();
 }
 
@@ -109,7 +113,7 @@ static ppf_workspace::Learned* workspace_learned(ppf_workspace* ws, const ppf_mo
 static void workspace_remember_frac(ppf_workspace* ws) {
   if (!ws->model || !ws->frac_known) return;
   ppf_workspace::Learned* fm = workspace_learned(ws, ws->model, true);
-  fm->hit = ws->hit_frac; fm->run = ws->run_frac;
+  fm->hit = ws->hit_frac; fm->run = ws->run_frac; fm->tbl = ws->tbl_frac;
 }
 
 /* the workspace keeps the model alive until its next call (or its destruction): results are fetched later.  A context
@@ -158,7 +162,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     workspace_remember_frac(ws);
     ws->acc32 = false;
     if (const ppf_workspace::Learned* fm = workspace_learned(ws, m, false)) {
-      ws->hit_frac = fm->hit; ws->run_frac = fm->run;
+      ws->hit_frac = fm->hit; ws->run_frac = fm->run; ws->tbl_frac = fm->tbl;
       ws->frac_known = true;
     } else if (!ws->frac_by_model.empty()) {
       ws->frac_known = false; /* a model this workspace has not met: count first */
@@ -192,7 +196,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->partial.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->half_edge.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->ovf_items.reserve((size_t)n_ref * T));
-  const size_t n_cnt = (size_t)n_ref * T + n_ref + 7; /* cellsum | pairs | totals[2] | tally[5]: LDS operations, hits, runs, 32-bit items, votes cast twice */
+  const size_t n_cnt = (size_t)n_ref * T + n_ref + 8; /* cellsum | pairs | totals[2] | tally[6]: LDS operations, hits, runs, 32-bit items, votes cast twice, count tables */
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
   HIPCHK(ws->raw_poses.reserve(n_ref));
@@ -261,7 +265,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   /* batch of reference points: its expected hits fit the scratch budget (and 32-bit pool offsets) */
   const double frac = std::min(1.0, std::max(ws->hit_frac, 1e-3));
   const double hits_per_ref = std::max(64.0, frac * (double)n_paired);
-  int batch = (int)std::min<double>((double)n_ref, std::max(1.0, (double)HIT_BYTES_BUDGET / (hits_per_ref * HIT_SCRATCH_BYTES)));
+  const double tbl_frac = !va.agg_min_hits ? 0.0 : frac >= 1.0 ? TBL_FRAC_MAX : std::min(TBL_FRAC_MAX, ws->tbl_frac);
+  int batch = (int)std::min<double>((double)n_ref, std::max(1.0, (double)HIT_BYTES_BUDGET / (hits_per_ref * (HIT_SCRATCH_BYTES + tbl_frac * TBL_BYTES))));
   batch = (int)std::min<double>((double)batch, std::max(1.0, 2.0e9 / hits_per_ref));
   batch = std::min(batch, 32768); /* grid.y of k_pairs */
   const bool worst_case = frac >= 1.0;
@@ -283,7 +288,11 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->hit_count.reserve(batch));
   HIPCHK(ws->s_a64.fit(sorted_cap));
   HIPCHK(ws->s_cell.fit(sorted_cap));
+  /* count tables: a run of c >= agg_min_hits hits takes ceil(c / AGG_SUB), so TBL_FRAC_MAX per hit is the ceiling */
+  const uint32_t table_cap = !va.agg_min_hits ? 1u : (uint32_t)std::min(1.0e9, std::max(est * (worst_case ? TBL_FRAC_MAX : tbl_frac), 4.0 * batch) + 256.0);
   HIPCHK(ws->runs.fit(run_cap));
+  HIPCHK(ws->tables.fit((size_t)table_cap * TBL_BYTES));
+  HIPCHK(ws->table_desc.fit(table_cap));
   HIPCHK(ws->run_blocks.reserve((size_t)batch * va.n_rounds));
   HIPCHK(ws->work.reserve(batch));
   HIPCHK(ws->perm.reserve(batch));
@@ -291,13 +300,14 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->ovf_list.reserve((size_t)batch * T));
   va.ovf_list = ws->ovf_list.p;
   ws->stats.scratch_bytes = ws->frames.bytes() + ws->raw.bytes() + ws->cursors.bytes() + ws->chunk_desc.bytes() + ws->hit_count.bytes() +
-                            ws->s_a64.bytes() + ws->s_cell.bytes() + ws->runs.bytes() + ws->run_blocks.bytes() +
+                            ws->s_a64.bytes() + ws->s_cell.bytes() + ws->runs.bytes() + ws->run_blocks.bytes() + ws->tables.bytes() + ws->table_desc.bytes() +
                             ws->work.bytes() + ws->perm.bytes() + ws->perm_group.bytes();
   va.frames = ws->frames.p;
   va.raw = ws->raw.p; va.stripe_cap = stripe_cap; va.stripe_bits = stripe_bits;
   va.chunk_desc = ws->chunk_desc.p; va.hit_count = ws->hit_count.p;
   va.s_a64 = ws->s_a64.p; va.s_cell = ws->s_cell.p; va.sorted_cap = sorted_cap;
   va.runs = ws->runs.p; va.run_cap = run_cap; va.run_blocks = ws->run_blocks.p;
+  va.tables = ws->tables.p; va.table_desc = ws->table_desc.p; va.table_cap = table_cap;
   va.work = ws->work.p; va.perm = ws->perm.p; va.perm_group = ws->perm_group.p;
 
   const size_t lds = VOTE_LDS_FIXED + (size_t)vote_lds_words(m->info.tile_refs, m->info.num_angles) * 4;
@@ -331,6 +341,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     va.ref_base = base;
     va.n_ref = std::min(batch, n_ref - base);
     if (bi) HIPCHK(hipMemsetAsync(ws->cursors.p, 0, CUR_OVERFLOW * sizeof(uint32_t), st)); /* the overflow word lives on */
+    if (va.agg_min_hits) HIPCHK(hipMemsetAsync(ws->table_desc.p, 0, (size_t)table_cap * sizeof(uint2), st));
     k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[ws->ev_base + bi * 4 + 0], st));
@@ -342,6 +353,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.hit_count, va.n_ref, nullptr, ws->perm_group.p, nullptr);
     k_group<<<dim3(va.n_ref), dim3(GROUP_BLOCK), group_lds, st>>>(va);
     HIPCHK(hipGetLastError());
+    if (va.agg_min_hits) { /* the count tables of the batch's many-hit runs, once per run */
+      k_tables<<<dim3((table_cap + TABLE_BLOCK / 64 - 1) / (TABLE_BLOCK / 64)), dim3(TABLE_BLOCK), 0, st>>>(va);
+      HIPCHK(hipGetLastError());
+    }
     /* k_vote takes the reference points that will cast the most votes first */
     k_rank<<<dim3((va.n_ref + RANK_KEYS - 1) / RANK_KEYS), dim3(256), 0, st>>>(va.work, va.n_ref, nullptr, va.perm, nullptr);
     HIPCHK(hipGetLastError());
@@ -396,7 +411,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
   if (ws->checked || ws->n_ref == 0) { ws->checked = true; return PPF_OK; }
   for (;;) {
     const int T = ws->model->info.n_tiles;
-    unsigned long long tot[7];
+    unsigned long long tot[8];
     uint32_t ovf = 0;
     HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
@@ -411,6 +426,8 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       if (!ws->acc32 && (double)tot[6] > 0.10 * (double)tot[0]) ws->acc32 = true;
       if (tot[1]) ws->hit_frac = std::min(1.0, std::max(1e-3, 1.06 * (double)tot[3] / (double)tot[1]));
       if (tot[3]) ws->run_frac = std::min(1.0, std::max(0.02, 1.10 * (double)tot[4] / (double)tot[3]));
+      if (tot[3]) ws->tbl_frac = std::min(TBL_FRAC_MAX, std::max(1e-4, 1.15 * (double)tot[7] / (double)tot[3]));
+      ws->stats.n_tables = tot[7];
       ws->frac_known = true;
       if (ws->clustered) {
         uint32_t nf = 0;
@@ -436,6 +453,10 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
     if (ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
     if (ovf & 3u) ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0); /* raw or sorted hit pool */
     if (ovf & 4u) ws->run_frac = std::min(1.0, ws->run_frac * 2.0); /* run table */
+    if (ovf & 8u) { /* count-table pool */
+      if ((ovf & 3u) == 0 && ws->tbl_frac >= TBL_FRAC_MAX) ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0); /* more hits than expected, then */
+      ws->tbl_frac = std::min(TBL_FRAC_MAX, ws->tbl_frac * 2.0);
+    }
     ws->stats.n_retries++;
     const ppf_match_params p = ws->params;
     ppf_model* m = ws->model;
@@ -567,7 +588,7 @@ __global__ __launch_bounds__(256) void k_pose_block(const ppf_pose* __restrict__
     reinterpret_cast<unsigned long long*>(dst)[i] = row < n ? s64[i] : 0ull;
   }
   if (i == 0 && meta_out) { meta_out[0] = (uint32_t)n; meta_out[1] = flag_in ? *flag_in : 0u; }
-  if (i < 5 && tot_out && tot_in) tot_out[i] = tot_in[i]; /* votes, pairs, LDS operations, hits, runs */
+  if (i < 8 && tot_out && tot_in) tot_out[i] = tot_in[i]; /* votes, pairs, LDS operations, hits, runs, (two of k_vote's own), count tables */
 }
 
 ppf_status ppf_workspace_copy_top_poses(ppf_workspace* ws, void* d_dst, int k, void* stream) {

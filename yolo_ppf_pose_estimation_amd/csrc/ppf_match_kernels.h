@@ -18,7 +18,12 @@
  *   k_group    one workgroup per reference point: alpha_s of every hit, counting sort of the hits by
  *              bucket (one LDS counter per bucket), the run table {bucket, first hit, m hits} (runs with
  *              many hits first) and the per-hit payload in sorted order: (float)alpha_s, alpha_s, and the
- *              hit's cell (Y, p) in units of alpha bins (see "aggregated votes").
+ *              hit's cell (Y, p) in units of alpha bins (see "aggregated votes").  Also gives every run of many
+ *              hits its count tables (one per 191 hits) out of the batch's table pool and writes down what each covers.
+ *
+ *   k_tables   one wave per count table: histogram of the table's hits by cell, the counts an entry in each cell adds
+ *              to each bin, the hits' offsets in cell order; built in LDS, copied to the pool (HBM / L2).  Once per run:
+ *              k_vote meets the run again for every chunk of the bucket's records, accumulator tile and half.
  *
  *   k_vote     one workgroup per (reference point, accumulator tile); the tile's Hough accumulator
  *              lives in LDS as 16-BIT cells, two model rows per 32-bit word: row r < H (H = half the tile's
@@ -36,9 +41,9 @@
  *              A run (one bucket, m hits) meets the bucket's entries in one of two ways:
  *                direct      every entry votes once per hit: 1 fma + cvt + fract + address + ds_add_u32
  *                            per vote, entries held in registers while the hits go by;
- *                aggregated  (m >= PPF_AGG_MIN_HITS) the hits of the run are first histogrammed by cell,
- *                            then every entry adds COUNTS: 17 ds_add_u32 per entry and <= 191 hits
- *                            instead of one per hit (see below).
+ *                aggregated  (m >= PPF_AGG_MIN_HITS) the hits of the run were histogrammed by cell (k_tables);
+ *                            every entry adds COUNTS: 17 ds_add_u32 per entry and <= 191 hits instead of
+ *                            one per hit (see below).
  *              Work items (run x chunk of entries x group of hits) are claimed by waves from an LDS
  *              counter.
  *
@@ -49,11 +54,11 @@
  *
  * Aggregated votes.  With x = alpha_m*A/(4pi) + A/2 = X + phi and y = alpha_s*A/(4pi) = Y + psi
  * (X, Y integers, 0 <= phi, psi < 1) the bin is floor(x - y) = X - Y - [phi < psi].  The fraction is cut
- * into Q = 32 cells: an entry in cell q = floor(32 phi) and a hit in cell p = floor(32 psi) with p != q
+ * into Q = 64 cells: an entry in cell q = floor(64 phi) and a hit in cell p = floor(64 psi) with p != q
  * are ordered by their cells alone, so for one entry all hits of a run with p < q and the same Y land
  * in bin X - Y, those with p > q in bin X - Y - 1: a table T[q][j] (j = Y + 8 = 0..16, built per run
  * from the hits' cell histogram) holds the COUNT that bin X + 8 - j receives, and the entry casts 17
- * counted atomics whatever m is.  Hits in the entry's own cell (1/32 of them) are voted one by one
+ * counted atomics whatever m is.  Hits in the entry's own cell (1/64 of them) are voted one by one
  * with the direct arithmetic.  Exactness: the table is only used for pairs separated by a cell boundary
  * from which the entry is provably away (fp32 cell index with a guard band, fp64 when inside the band,
  * one-by-one votes when fp64 is still within 1e-7 of a boundary), where the fp64 chain's rounding
@@ -72,9 +77,8 @@
 #ifndef PPF_AGG_MIN_RECORDS
 #define PPF_AGG_MIN_RECORDS 32 /* ... when the (tile, bucket) holds at least this many pair records */
 #endif
-/* Attribution builds (tools/build_variant.sh + tools/vote_classes.sh, never the product): PPF_ABL_<class>=0 leaves one class of
- * k_vote's work out, =2 does it twice (table builds: leaving them out would leave loop bounds undefined); the votes are then
- * wrong and the 16-bit overflow check is off, only times and counters of such a build mean anything.  The difference to the
+/* Attribution builds (tools/build_attribution.sh, never the product): PPF_ABL_<class>=0 leaves one class of k_vote's work
+ * out; the votes are then wrong and the 16-bit overflow check is off, only times and counters of such a build mean anything.  The difference to the
  * product build is what the class costs, with the latency it exposes included (profiles/r03_vote_classes.md). */
 #ifndef PPF_ABL_COUNTED
 #define PPF_ABL_COUNTED 1      /* count-table items: the 17 counted atomics per entry and the table-row reads behind them */
@@ -82,16 +86,13 @@
 #ifndef PPF_ABL_OWNCELL
 #define PPF_ABL_OWNCELL 1      /* count-table items: the one-by-one votes of an entry's own cell */
 #endif
-#ifndef PPF_ABL_BUILD
-#define PPF_ABL_BUILD 1        /* count-table items: the table build (2 = twice) */
-#endif
 #ifndef PPF_ABL_DIRECT_SMALL
 #define PPF_ABL_DIRECT_SMALL 1 /* direct items on at most 32 records (one entry per lane) */
 #endif
 #ifndef PPF_ABL_DIRECT_BIG
 #define PPF_ABL_DIRECT_BIG 1   /* direct items on more than 32 records: 0 = neither loads nor votes, 2 = the record loads without the votes */
 #endif
-#define PPF_ABL_ANY (PPF_ABL_COUNTED != 1 || PPF_ABL_OWNCELL != 1 || PPF_ABL_BUILD != 1 || PPF_ABL_DIRECT_SMALL != 1 || PPF_ABL_DIRECT_BIG != 1)
+#define PPF_ABL_ANY (PPF_ABL_COUNTED != 1 || PPF_ABL_OWNCELL != 1 || PPF_ABL_DIRECT_SMALL != 1 || PPF_ABL_DIRECT_BIG != 1)
 
 #ifndef PPF_TWO_QUEUES
 #define PPF_TWO_QUEUES 0 /* 1: k_vote claims count-table items and direct items from two queues, half of the waves preferring each (measured: +2 %, profiles/r03_vote_variants.md) */
@@ -111,8 +112,7 @@ constexpr int VOTE_MAX_HITS = PPF_AGG_MIN_HITS; /* hits of one run voted per dir
 #ifndef PPF_AGG_CHUNK
 #define PPF_AGG_CHUNK 2048
 #endif
-constexpr int AGG_CHUNK = PPF_AGG_CHUNK; /* pair records per aggregated work item (each item builds the count table of its hits) */
-constexpr int AGG_Q = 32;             /* cells per alpha bin */
+constexpr int AGG_CHUNK = PPF_AGG_CHUNK; /* pair records per aggregated work item (each item copies its count table into LDS; 256 / 512 / 1024: +4 / +1 / 0 %) */
 constexpr int AGG_NY = 16;            /* integer parts Y + 8 of a hit */
 constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes; 3 hits per lane) */
 constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in [-8, 7] */
@@ -137,19 +137,30 @@ constexpr int CUR_SORTED = POOL_STRIPES * CUR_STRIDE;
 constexpr int CUR_RUNS = CUR_SORTED + CUR_STRIDE;
 constexpr int CUR_ODDVALUES = CUR_RUNS + CUR_STRIDE; /* != 0: the batch has a reference frame or a paired point that is not finite (or absurdly large): k_group checks every hit for an alpha_s */
 constexpr int CUR_OVFCOUNT = CUR_ODDVALUES + CUR_STRIDE; /* (reference point, tile)s of this batch whose 16-bit cells overflowed: length of ovf_list */
-constexpr int CUR_OVERFLOW = CUR_OVFCOUNT + CUR_STRIDE; /* bits 1, 2, 4: raw pool, sorted pool, run table too small */
+constexpr int CUR_TABLES = CUR_OVFCOUNT + CUR_STRIDE; /* count tables given out by k_group */
+constexpr int CUR_OVERFLOW = CUR_TABLES + CUR_STRIDE; /* bits 1, 2, 4, 8: raw pool, sorted pool, run table, count-table pool too small */
 constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
 
-/* per-wave LDS scratch of the aggregated path */
-constexpr int AGG_ROW = 20;                           /* bytes per table row: 17 counts + padding; 5 words: the same word of rows q and q' never shares a bank */
-constexpr int AGG_OFF_CE = 672;                       /* 33 rows end at 660 (row AGG_Q is all zero: entries that vote one by one) */
-constexpr int AGG_OFF_A32 = 816;                      /* cell ends / starts: 33 u32 from 672 */
-constexpr int AGG_OFF_IDX = AGG_OFF_A32 + 768;        /* folded offsets Ohg of the hits in cell order: AGG_SUB x 4 B (first: 512 B of byte counters) */
-constexpr int AGG_SCRATCH = AGG_OFF_IDX + 192;        /* position of each sorted hit inside the table's hit range: AGG_SUB x 1 B */
-static_assert((AGG_Q + 1) * AGG_ROW <= AGG_OFF_CE, "table rows overlap the cell table");
-static_assert(AGG_OFF_CE + (AGG_Q + 1) * 4 <= AGG_OFF_A32, "cell table overlaps");
-static_assert(AGG_SUB * 4 <= 768 && AGG_SUB <= 192 && AGG_NY * AGG_Q <= 768 && AGG_SUB < 256, "aggregation scratch too small");
-static_assert(AGG_SCRATCH % 16 == 0, "wave scratch must keep 16-byte alignment");
+/* A count table (one per run and range of <= AGG_SUB hits; built once per batch by k_tables, kept in HBM/L2):
+ *   rows      (AGG_Q + 1) x AGG_ROW bytes   T[q][j], j = 0..16 (row AGG_Q all zero: entries that vote one by one)
+ *   ranges    (AGG_Q + 1) x u32             start of every cell in the cell-sorted hit list (entry AGG_Q = number of hits)
+ *   offsets   AGG_SUB x f32                 folded offsets Ohg of the hits in cell order (while building: 16 x AGG_Q byte counters)
+ *   index     AGG_SUB x u8                  position of each sorted hit inside the table's hit range (the exact-bin fallback)
+ * k_vote copies rows + ranges of the table an item works with into its wave's LDS (AGG_SCRATCH bytes) and reads the
+ * offsets of an entry's own cell straight from the table (four of them, a block of records ahead of their votes). */
+constexpr int AGG_ROW = 20;                                        /* bytes per row: 17 counts + padding; 5 words: the same word of rows q and q' never shares a bank */
+constexpr int AGG_OFF_CE = ((AGG_Q + 1) * AGG_ROW + 15) / 16 * 16;  /* cell ranges behind the rows */
+constexpr int AGG_SCRATCH = AGG_OFF_CE + ((AGG_Q + 1) * 4 + 15) / 16 * 16; /* per-wave LDS of k_vote: rows + ranges */
+constexpr int TBL_OFF_A32 = AGG_SCRATCH;
+constexpr int TBL_A32_BYTES = (AGG_NY * AGG_Q > 768 ? AGG_NY * AGG_Q : 768);
+constexpr int TBL_OFF_IDX = TBL_OFF_A32 + TBL_A32_BYTES;
+constexpr int TBL_BYTES = TBL_OFF_IDX + 192;                        /* one table in HBM, and the LDS a k_tables wave builds it in */
+static_assert(AGG_SUB * 4 <= 768 && AGG_SUB <= 192 && AGG_SUB < 256, "table hit range too long");
+static_assert(AGG_SCRATCH % 16 == 0 && TBL_BYTES % 16 == 0, "tables are copied 16 bytes at a time");
+constexpr int TABLE_BLOCK = 256; /* k_tables: four tables per workgroup */
+/* count tables per hit: a run of c >= PPF_AGG_MIN_HITS hits takes ceil(c / AGG_SUB) of them */
+constexpr double TBL_FRAC_MAX = 1.0 / PPF_AGG_MIN_HITS + 1.0 / AGG_SUB;
+constexpr double TBL_FRAC_START = 0.02; /* before a workspace has seen the model (learned from the first call on) */
 
 /* fp32 acos for BIN SELECTION only: acos(|x|) = sqrt(1-|x|) * P(|x|), degree-7 least-squares/minimax fit,
  * measured max error 3.4e-7 rad including fp32 evaluation with a correctly rounded sqrt; the square root here is the bare
@@ -264,7 +275,10 @@ struct MatchArgs {
   double* s_a64;           /* sorted payload: alpha_s */
   uint16_t* s_cell;        /*                 (Y + 8) * AGG_Q + p */
   uint32_t sorted_cap;
-  uint4* runs;             /* {bucket, first sorted hit, m, 0} */
+  uint4* runs;             /* {bucket, first sorted hit, m, first count table of the run (m >= agg_min_hits)} */
+  unsigned char* tables;   /* count tables, TBL_BYTES each: built by k_tables, read by k_vote */
+  uint2* table_desc;       /* {first sorted hit, hits <= AGG_SUB} of every table, written by k_group (zeroed before: 0 hits = not given out) */
+  uint32_t table_cap;
   uint32_t run_cap;
   uint2* run_blocks;       /* [n_ref][n_rounds] {first run, runs} */
   int n_rounds, round_buckets; /* k_group sorts round_buckets bucket ids per pass over the reference point's hits */
@@ -286,7 +300,7 @@ struct MatchArgs {
   uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: bin A of the last low-half row; pass 1: bin 0 of the first high-half row */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
-  unsigned long long* tally;    /* [5] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group; (reference point, tile)s voted with 32-bit cells; votes the 16-bit launch cast for the ones it flagged */
+  unsigned long long* tally;    /* [6] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group; (reference point, tile)s voted with 32-bit cells; votes the 16-bit launch cast for the ones it flagged; count tables handed out by k_group */
   uint32_t* acc_dump;           /* optional [n_ref_all][n_model*num_angles] full accumulators (debug/tests) */
 };
 
@@ -473,8 +487,8 @@ __device__ __forceinline__ uint32_t hit_cell(const double alpha_s, const double 
 __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   extern __shared__ __align__(8) uint32_t gcnt[]; /* round_buckets counters, then cursors */
   __shared__ unsigned long long wsum[GROUP_BLOCK / 64];
-  __shared__ uint32_t wtot[3][GROUP_BLOCK / 64];
-  __shared__ uint32_t sh[4];
+  __shared__ uint32_t wtot[4][GROUP_BLOCK / 64];
+  __shared__ uint32_t sh[5];
   const int r = a.perm_group ? (int)a.perm_group[blockIdx.x] : (int)blockIdx.x; /* most hits first: no long block at the tail */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t* cpre = gcnt + ((a.round_buckets + 1) & ~1);                     /* pair_chunks + 1 (even offsets: the doubles behind stay 8-byte aligned) */
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const uint32_t n_list = ok ? n_raw : 0u;
   const bool check_alpha = a.cursors[CUR_ODDVALUES] != 0u;
   unsigned long long w = 0;
-  uint32_t placed = 0, runs_written = 0;
+  uint32_t placed = 0, runs_written = 0, tables_given = 0;
   for (int round = 0; round < a.n_rounds; round++) {
     const uint32_t b0 = (uint32_t)round * (uint32_t)a.round_buckets;
     const uint32_t nb = min((uint32_t)a.round_buckets, (uint32_t)a.n_buckets - b0);
@@ -568,26 +582,26 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     /* each thread owns a contiguous slice of the counters: hits, count-table runs, direct runs in it */
     const uint32_t per = (nb + GROUP_BLOCK - 1) / GROUP_BLOCK;
     const uint32_t k0 = min((uint32_t)tid * per, nb), k1 = min(k0 + per, nb);
-    uint32_t th = 0, tH = 0, tL = 0;
+    uint32_t th = 0, tH = 0, tL = 0, tT = 0; /* hits, many-hit runs, few-hit runs, count tables (one per AGG_SUB hits of a many-hit run) */
     for (uint32_t k = k0; k < k1; k++) {
       const uint32_t c = gcnt[k];
       th += c;
-      if (c) { if (c >= agg_min) tH++; else tL++; }
+      if (c) { if (c >= agg_min) { tH++; tT += (c + AGG_SUB - 1) / AGG_SUB; } else tL++; }
     }
-    uint32_t ih = th, iH = tH, iL = tL;
+    uint32_t ih = th, iH = tH, iL = tL, iT = tT;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y0 = __shfl_up(ih, o), y1 = __shfl_up(iH, o), y2 = __shfl_up(iL, o);
-      if (lane >= o) { ih += y0; iH += y1; iL += y2; }
+      const uint32_t y0 = __shfl_up(ih, o), y1 = __shfl_up(iH, o), y2 = __shfl_up(iL, o), y3 = __shfl_up(iT, o);
+      if (lane >= o) { ih += y0; iH += y1; iL += y2; iT += y3; }
     }
-    if (lane == 63) { wtot[0][wave] = ih; wtot[1][wave] = iH; wtot[2][wave] = iL; }
+    if (lane == 63) { wtot[0][wave] = ih; wtot[1][wave] = iH; wtot[2][wave] = iL; wtot[3][wave] = iT; }
     __syncthreads();
-    uint32_t oh = ih - th, oH = iH - tH, oL = iL - tL, nh = 0, nH = 0, nL = 0;
+    uint32_t oh = ih - th, oH = iH - tH, oL = iL - tL, oT = iT - tT, nh = 0, nH = 0, nL = 0, nT = 0;
 #pragma unroll
     for (int k = 0; k < GROUP_BLOCK / 64; k++) {
-      const uint32_t v0 = wtot[0][k], v1 = wtot[1][k], v2 = wtot[2][k];
-      if (k < wave) { oh += v0; oH += v1; oL += v2; }
-      nh += v0; nH += v1; nL += v2;
+      const uint32_t v0 = wtot[0][k], v1 = wtot[1][k], v2 = wtot[2][k], v3 = wtot[3][k];
+      if (k < wave) { oh += v0; oH += v1; oL += v2; oT += v3; }
+      nh += v0; nH += v1; nL += v2; nT += v3;
     }
     if (tid == 0) {
       const uint32_t R = nH + nL;
@@ -596,6 +610,13 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
         rb = atomicAdd(&a.cursors[CUR_RUNS], R);
         if (!(rb <= a.run_cap && R <= a.run_cap - rb)) { okr = 0; atomicOr(&a.cursors[CUR_OVERFLOW], 4u); }
       }
+      uint32_t tb = 0, okt = 1;
+      if (nT) {
+        tb = atomicAdd(&a.cursors[CUR_TABLES], nT);
+        if (!(tb <= a.table_cap && nT <= a.table_cap - tb)) { okt = 0; atomicOr(&a.cursors[CUR_OVERFLOW], 8u); }
+      }
+      okr &= okt; /* a block of runs whose tables have no room is left out like one that has no room itself: the call is repeated */
+      sh[4] = tb;
       sh[2] = rb; sh[3] = okr;
       a.run_blocks[(size_t)r * a.n_rounds + round] = okr ? make_uint2(rb, R) : make_uint2(0u, 0u);
     }
@@ -603,13 +624,18 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     {
       const uint32_t rb = sh[2];
       const bool okr = sh[3] != 0;
-      uint32_t pos = oh, rh = oH, rl = nH + oL;
+      uint32_t pos = oh, rh = oH, rl = nH + oL, tt = sh[4] + oT;
       for (uint32_t k = k0; k < k1; k++) {
         const uint32_t c = gcnt[k];
         gcnt[k] = placed + pos; /* the bucket's cursor */
         if (c) {
-          const uint32_t idx = c >= agg_min ? rh++ : rl++;
-          if (okr) a.runs[rb + idx] = make_uint4(b0 + k, hit_base + placed + pos, c, 0u);
+          const bool many = c >= agg_min;
+          const uint32_t idx = many ? rh++ : rl++;
+          if (okr) a.runs[rb + idx] = make_uint4(b0 + k, hit_base + placed + pos, c, many ? tt : 0u);
+          if (many) {
+            for (uint32_t h0 = 0; h0 < c; h0 += AGG_SUB, tt++)
+              if (okr) a.table_desc[tt] = make_uint2(hit_base + placed + pos + h0, min((uint32_t)AGG_SUB, c - h0));
+          }
           w += (unsigned long long)c * a.bucket_total[b0 + k]; /* votes this run will cast (the launch order of k_vote) */
         }
         pos += c;
@@ -661,6 +687,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     }
     placed += nh;
     runs_written += nH + nL;
+    tables_given += nT;
     __syncthreads();
   }
 #pragma unroll
@@ -673,6 +700,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
     a.work[r] = t;
     atomicAdd(&a.tally[1], (unsigned long long)placed);
     atomicAdd(&a.tally[2], (unsigned long long)runs_written);
+    atomicAdd(&a.tally[5], (unsigned long long)tables_given);
   }
 }
 
@@ -697,6 +725,8 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
  *   taken once per batch of U entries and only when some lane of the wave needs it.
  */
 typedef __attribute__((address_space(3))) unsigned char lds_byte; /* explicit LDS pointers: 32-bit arithmetic, ds_* ops */
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4; /* ds_read_b128 / ds_write_b128 */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 __device__ __forceinline__ void lds_add(const uint32_t addr, const uint32_t v) {
@@ -900,17 +930,17 @@ struct AggConsts {
   uint32_t sel_lo, step_lo, sel_hi, step_hi;
 };
 
-/* Count table of one range of <= AGG_SUB hits (global indices g0 .. g0+ms of the sorted payload), built by one wave in its
- * own LDS scratch:
+/* Count table of one range of <= AGG_SUB hits (global indices g0 .. g0+ms of the sorted payload), built by one wave in
+ * TBL_BYTES of LDS at `ws` (layout above):
  *   T[q][j], q < AGG_Q, j = 0..16   hits with cell p < q and Y + 8 == j, plus hits with p > q and Y + 8 == j - 1: what an
  *                                   entry in cell q adds to its bin X + 8 - j (bytes; row AGG_Q stays zero)
- *   ce[p], ce[p+1]                  range of the hits of cell p in the cell-sorted copy sa32[] / sidx[] */
-__device__ __forceinline__ void agg_build(const AggConsts& k, const double* __restrict__ g_a64, const uint16_t* __restrict__ g_cell,
-                                          const int ms, const int lane) {
-  const uint32_t ws = k.ws;
-  lds_st(ws + AGG_OFF_A32 + lane * 8, 0u);     /* byte counters cnt[Y][p]: 512 B */
-  lds_st(ws + AGG_OFF_A32 + lane * 8 + 4, 0u);
-  if (lane < AGG_Q + 1) lds_st(ws + AGG_OFF_CE + lane * 4, 0u);
+ *   ce[p], ce[p+1]                  range of the hits of cell p in the cell-sorted copy (offsets / index) */
+__device__ __forceinline__ void table_build(const uint32_t ws, const float S, const float Og, const double* __restrict__ g_a64,
+                                            const uint16_t* __restrict__ g_cell, const int ms, const int lane) {
+  constexpr int PER = AGG_Q / 4; /* cells of one Y a lane owns in the histogram pass */
+#pragma unroll
+  for (int w = 0; w < PER / 4; w++) lds_st(ws + TBL_OFF_A32 + lane * PER + w * 4, 0u); /* byte counters cnt[Y][p]: 16 x AGG_Q bytes */
+  for (int e = lane; e < AGG_Q + 1; e += 64) lds_st(ws + AGG_OFF_CE + e * 4, 0u);
   if (lane < AGG_ROW / 4) lds_st(ws + AGG_Q * AGG_ROW + lane * 4, 0u); /* the all-zero row */
   uint32_t cell[3], a32[3];
 #pragma unroll
@@ -918,45 +948,48 @@ __device__ __forceinline__ void agg_build(const AggConsts& k, const double* __re
     const int i = lane + 64 * t;
     const bool v = i < ms;
     cell[t] = v ? (uint32_t)g_cell[i] : 0xFFFFu;
-    a32[t] = v ? __float_as_uint(k.Og - (float)g_a64[i] * k.S) : 0u; /* Ohg = A/2 + G - alpha_s*S of the direct arithmetic */
+    a32[t] = v ? __float_as_uint(Og - (float)g_a64[i] * S) : 0u; /* Ohg = A/2 + G - alpha_s*S of the direct arithmetic */
   }
   wave_lds_fence();
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     if (cell[t] != 0xFFFFu) {
-      lds_add(ws + AGG_OFF_A32 + (cell[t] & ~3u), 1u << (8u * (cell[t] & 3u)));
-      lds_add(ws + AGG_OFF_CE + (cell[t] & (AGG_Q - 1)) * 4, 1u);
+      lds_add(ws + TBL_OFF_A32 + (cell[t] & ~3u), 1u << (8u * (cell[t] & 3u)));
+      lds_add(ws + AGG_OFF_CE + (cell[t] % (uint32_t)AGG_Q) * 4, 1u);
     }
   }
   wave_lds_fence();
-  /* lane L holds cnt[Y = L/4][p = 8*(L%4) .. +8] */
-  const uint2 cw = lds_ld2(ws + AGG_OFF_A32 + lane * 8);
-  uint32_t c[8], less[8], more[8];
+  /* lane L holds cnt[Y = L/4][p = PER*(L%4) .. +PER] */
+  uint32_t c[PER], less[PER], more[PER];
 #pragma unroll
-  for (int t = 0; t < 8; t++) c[t] = ((t < 4 ? cw.x : cw.y) >> (8 * (t & 3))) & 0xFFu;
+  for (int w = 0; w < PER / 4; w++) {
+    const uint32_t cw = lds_ld(ws + TBL_OFF_A32 + lane * PER + w * 4);
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[w * 4 + t] = (cw >> (8 * t)) & 0xFFu;
+  }
   uint32_t run = 0;
 #pragma unroll
-  for (int t = 0; t < 8; t++) { less[t] = run; run += c[t]; }
+  for (int t = 0; t < PER; t++) { less[t] = run; run += c[t]; }
   const int quarter = lane & 3;
   const uint32_t t1 = __shfl_up(run, 1, 4), t2 = __shfl_up(run, 2, 4), t3 = __shfl_up(run, 3, 4);
   const uint32_t before = (quarter >= 1 ? t1 : 0u) + (quarter >= 2 ? t2 : 0u) + (quarter >= 3 ? t3 : 0u);
   const uint32_t tot = __shfl(before + run, 3, 4); /* hits with this Y */
 #pragma unroll
-  for (int t = 0; t < 8; t++) {
+  for (int t = 0; t < PER; t++) {
     less[t] += before;
     more[t] = tot - less[t] - c[t];
   }
   const int yy = lane >> 2;
 #pragma unroll
-  for (int t = 0; t < 8; t++) {
+  for (int t = 0; t < PER; t++) {
     const uint32_t mprev = __shfl_up(more[t], 4);
     const uint32_t v = less[t] + (lane >= 4 ? mprev : 0u);
-    const uint32_t p = (uint32_t)(quarter * 8 + t);
+    const uint32_t p = (uint32_t)(quarter * PER + t);
     lds_st8(ws + p * AGG_ROW + yy, v);
     if (yy == AGG_NY - 1) lds_st8(ws + p * AGG_ROW + AGG_NY, more[t]);
   }
   wave_lds_fence();
-  /* cell ends: inclusive scan of the per-p counts; the scatter below counts them down to the cell starts */
+  /* cell ends: inclusive scan of the per-p counts (one cell per lane); the scatter below counts them down to the cell starts */
   uint32_t h = lane < AGG_Q ? lds_ld(ws + AGG_OFF_CE + lane * 4) : 0u;
 #pragma unroll
   for (int o = 1; o < AGG_Q; o <<= 1) {
@@ -965,17 +998,51 @@ __device__ __forceinline__ void agg_build(const AggConsts& k, const double* __re
   }
   wave_lds_fence();
   if (lane < AGG_Q) lds_st(ws + AGG_OFF_CE + lane * 4, h);
-  if (lane == AGG_Q) lds_st(ws + AGG_OFF_CE + AGG_Q * 4, (uint32_t)ms);
+  if (lane == 0) lds_st(ws + AGG_OFF_CE + AGG_Q * 4, (uint32_t)ms);
   wave_lds_fence();
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     if (cell[t] != 0xFFFFu) {
-      const uint32_t pos = lds_add_rtn(ws + AGG_OFF_CE + (cell[t] & (AGG_Q - 1)) * 4, 0xFFFFFFFFu) - 1u;
-      lds_st(ws + AGG_OFF_A32 + pos * 4, a32[t]);
-      lds_st8(ws + AGG_OFF_IDX + pos, (uint32_t)(lane + 64 * t));
+      const uint32_t pos = lds_add_rtn(ws + AGG_OFF_CE + (cell[t] % (uint32_t)AGG_Q) * 4, 0xFFFFFFFFu) - 1u;
+      lds_st(ws + TBL_OFF_A32 + pos * 4, a32[t]);
+      lds_st8(ws + TBL_OFF_IDX + pos, (uint32_t)(lane + 64 * t));
     }
   }
   wave_lds_fence();
+}
+
+/* guard band of the direct bin arithmetic (see k_vote): the folded offsets a table stores carry it */
+__device__ __forceinline__ float vote_guard_band(const int A) {
+#ifdef PPF_FORCE_EXACT
+  (void)A;
+  return 1.0f; /* test build: every direct vote takes the fp64 chain */
+#else
+  return PPF_GUARD_REL * (float)A;
+#endif
+}
+
+/* k_tables: the count tables of a batch's many-hit runs, one wave per table (k_group gave the tables out and wrote what
+ * each one covers: a run's hits, AGG_SUB at a time).  A wave builds its table in LDS and copies it out.  Built ONCE here,
+ * where k_vote used to rebuild it for every chunk of records, accumulator tile and half it met the run in. */
+__global__ __launch_bounds__(TABLE_BLOCK) void k_tables(MatchArgs a) {
+  __shared__ __align__(16) unsigned char tsm[(TABLE_BLOCK / 64) * TBL_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t t = blockIdx.x * (TABLE_BLOCK / 64) + (uint32_t)wave;
+  if (t >= a.table_cap) return;
+  const uint2 d = a.table_desc[t];
+  if (d.y == 0u) return; /* not given out (or its block of runs was left out: the call is repeated) */
+  const uint32_t ws = (uint32_t)(uintptr_t)(lds_byte*)(tsm + wave * TBL_BYTES);
+  const int A = a.num_angles;
+  const double s64 = (double)A / (4 * PPF_PI);
+  const float S = (float)s64, Og = (float)(0.5 * (double)A + (double)vote_guard_band(A));
+  table_build(ws, S, Og, a.s_a64 + d.x, a.s_cell + d.x, (int)d.y, lane);
+  const lds_u32x4* src = (const lds_u32x4*)(uintptr_t)ws;
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(a.tables + (size_t)t * TBL_BYTES);
+  for (int q = lane; q < TBL_BYTES / 16; q += 64) {
+    const u32x4_t v = src[q];
+    dst[q] = make_uint4(v.x, v.y, v.z, v.w);
+  }
 }
 
 /* cell of an entry: x = alpha_m*A/(4 pi) + A/2 = X + phi, q = floor(AGG_Q * phi) (row AGG_Q: the entry votes one by one) */
@@ -985,8 +1052,10 @@ __device__ __forceinline__ void agg_cell(const AggConsts& k, const float am, int
   const float qf = __builtin_amdgcn_fractf(x) * (float)AGG_Q;
   q = (int)qf;
   const float fq = __builtin_amdgcn_fractf(qf);
-  /* fp32 error of x: <= 1.5e-6 bins (S rounding 6e-8*7.5, fma 9.5e-7) = 4.8e-5 cells; band 1.5e-4 cells */
-  const bool near = !(fq > 1.5e-4f && fq < 1.0f - 1.5e-4f);
+  /* fp32 error of x: <= 1.5e-6 bins (S rounding 6e-8*7.5, fma 9.5e-7) = 1.5e-6 * AGG_Q cells (4.8e-5 at 32, 9.6e-5 at 64);
+   * band = three times that */
+  constexpr float band = 4.7e-6f * (float)AGG_Q;
+  const bool near = !(fq > band && fq < 1.0f - band);
   bool one_by_one = am < -3.1415925f; /* (float)-pi and below: x - y may be negative, where the reference truncates to 0 */
   if (__builtin_expect(__any(near), 0)) {
     if (near) {
@@ -1016,28 +1085,76 @@ __device__ uint32_t agg_cell_bits(const float am, const int A) {
   return ((uint32_t)X << ROW_X_SHIFT) | ((uint32_t)q << ROW_Q_SHIFT);
 }
 
-/* The two model entries of one pair record against the count table: 17 counted atomics each, then one vote per hit of
- * each entry's own cell (all hits for an entry that votes one by one) with the direct arithmetic -- both entries walk
- * their cells in one loop, so the LDS round trip of a hit's offset is shared.  `votes` counts the one-by-one votes. */
-__device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, const double* __restrict__ g_a64, const int ms,
-                                         uint32_t& votes) {
+/* four consecutive 32-bit words at a 4-byte aligned global address (global_load_dwordx4 needs no more) */
+struct __attribute__((packed, aligned(4))) gl_quad_t { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 gl_ld4(const uint32_t* __restrict__ p) {
+  const gl_quad_t q = *reinterpret_cast<const gl_quad_t*>(p);
+  return make_uint4(q.x, q.y, q.z, q.w);
+}
+
+/* one own-cell vote of each entry of a pair record (hit k of the entries' cells), guard band and exact fallback included */
+__device__ __forceinline__ void agg_own_vote(const AggConsts& k, const uint32_t rz, const uint32_t rw, const float am_a, const float am_b,
+                                             const uint32_t oa, const uint32_t ob, const bool da, const bool db, const uint32_t pa,
+                                             const uint32_t pb, const uint32_t inc_a, const uint32_t inc_b,
+                                             const unsigned char* __restrict__ tbl, const double* __restrict__ g_a64, const uint32_t ha,
+                                             const uint32_t hb) {
+  const float xa = __builtin_fmaf(am_a, k.S, __uint_as_float(oa)), xb = __builtin_fmaf(am_b, k.S, __uint_as_float(ob));
+  int ba = (int)xa, bb = (int)xb;
+  const float fa = da ? __builtin_amdgcn_fractf(xa) : 1.0f, fb = db ? __builtin_amdgcn_fractf(xb) : 1.0f;
+  if (__builtin_expect(__any(__builtin_fminf(fa, fb) < k.G2), 0)) { /* some lane may sit in the guard band of a bin edge */
+    uint32_t za = rz, zb = rw;
+    asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the loop */
+    if (fa < k.G2) ba = vote_bin_exact_4pi(__uint_as_float(za), g_a64[tbl[TBL_OFF_IDX + ha]], k.A);
+    if (fb < k.G2) bb = vote_bin_exact_4pi(__uint_as_float(zb), g_a64[tbl[TBL_OFF_IDX + hb]], k.A);
+  }
+  if (da) lds_add(pa + ((uint32_t)ba << 2), inc_a);
+  if (db) lds_add(pb + ((uint32_t)bb << 2), inc_b);
+}
+
+/* Own-cell state of the two entries of one pair record: the ranges of their cells in the table's cell-sorted hit list (an
+ * entry that votes one by one: all hits) and the first four folded offsets of each, read straight from the table `tbl`.
+ * Issued a block of records ahead of the votes that use it (the loads need the record's cells and the ranges in the wave's LDS). */
+struct AggOwn {
+  uint2 ca, cb; /* [first, end) in the cell-sorted list */
+  uint4 oa, ob; /* offsets of hits first .. first+3 (may run past the cell, never past the table) */
+};
+__device__ __forceinline__ void agg_own_fetch(const AggConsts& k, const uint4 rec, const unsigned char* __restrict__ tbl, const int ms, AggOwn& o) {
+  const int qa = (int)((rec.x >> ROW_Q_SHIFT) & ROW_Q_MASK), qb = (int)((rec.y >> ROW_Q_SHIFT) & ROW_Q_MASK);
+  o.ca = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qa, AGG_Q - 1) * 4);
+  o.cb = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qb, AGG_Q - 1) * 4);
+  if (qa == AGG_Q) { o.ca.x = 0u; o.ca.y = (uint32_t)ms; }
+  if (qb == AGG_Q) { o.cb.x = 0u; o.cb.y = (uint32_t)ms; }
+#if PPF_ABL_OWNCELL
+  const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
+  o.oa = gl_ld4(toff + o.ca.x);
+  o.ob = gl_ld4(toff + o.cb.x);
+#else
+  (void)tbl;
+#endif
+}
+
+/* The two model entries of one pair record against the count table (rows and cell ranges in the wave's LDS, copied from the
+ * table `tbl` the item works with): 17 counted atomics each, then one vote per hit of each entry's own cell (all hits for an
+ * entry that votes one by one) with the direct arithmetic.  The offsets of those hits come straight from the table, four
+ * per entry, fetched a block ahead (agg_own_fetch): at 64 cells an entry's cell holds three hits on average, so the LDS
+ * sees no reads for them and most blocks need no second fetch.  `votes` counts the one-by-one votes. */
+__device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, const AggOwn& own, const unsigned char* __restrict__ tbl,
+                                         const double* __restrict__ g_a64, uint32_t& votes) {
   const float am_a = __uint_as_float(rec.z), am_b = __uint_as_float(rec.w);
   /* X and cell of the two entries: evaluated by the table build (agg_cell_bits), carried in the row codes */
-  const int Xa = (int)((rec.x >> ROW_X_SHIFT) & 31u), qa = (int)((rec.x >> ROW_Q_SHIFT) & 63u);
-  const int Xb = (int)((rec.y >> ROW_X_SHIFT) & 31u), qb = (int)((rec.y >> ROW_Q_SHIFT) & 63u);
+  const int Xa = (int)((rec.x >> ROW_X_SHIFT) & 31u), qa = (int)((rec.x >> ROW_Q_SHIFT) & ROW_Q_MASK);
+  const int Xb = (int)((rec.y >> ROW_X_SHIFT) & 31u), qb = (int)((rec.y >> ROW_Q_SHIFT) & ROW_Q_MASK);
+  const uint2 ca = own.ca, cb = own.cb;
   const uint32_t ta = k.ws + (uint32_t)qa * AGG_ROW, tb = k.ws + (uint32_t)qb * AGG_ROW;
-  const uint2 a01 = lds_ld2(ta), a23 = lds_ld2(ta + 8), a45 = lds_ld2(ta + 16);
-  const uint2 b01 = lds_ld2(tb), b23 = lds_ld2(tb + 8), b45 = lds_ld2(tb + 16);
-  /* the cells' hit ranges in the cell-sorted copy */
-  uint2 ca = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qa, AGG_Q - 1) * 4), cb = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qb, AGG_Q - 1) * 4);
-  if (qa == AGG_Q) { ca.x = 0u; ca.y = (uint32_t)ms; }
-  if (qb == AGG_Q) { cb.x = 0u; cb.y = (uint32_t)ms; }
+  const uint2 a01 = lds_ld2(ta), a23 = lds_ld2(ta + 8);
+  const uint2 b01 = lds_ld2(tb), b23 = lds_ld2(tb + 8);
+  const uint32_t a4 = lds_ld(ta + 16), b4 = lds_ld(tb + 16);
   const uint32_t pa = k.acc_base + (rec.x & ROW_OFFSET_MASK), pb = k.acc_base + (rec.y & ROW_OFFSET_MASK);
   const bool ha = (rec.x & 1u) != 0, hb = (rec.y & 1u) != 0;
   const uint32_t inc_a = ha ? k.vi.hi : k.vi.lo, inc_b = hb ? k.vi.hi : k.vi.lo;
   uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
   asm volatile("" : "+v"(va), "+v"(vb)); /* keep these as the bases: every atomic below is base + immediate offset */
-  const uint32_t wa[5] = {a01.x, a01.y, a23.x, a23.y, a45.x}, wb[5] = {b01.x, b01.y, b23.x, b23.y, b45.x};
+  const uint32_t wa[5] = {a01.x, a01.y, a23.x, a23.y, a4}, wb[5] = {b01.x, b01.y, b23.x, b23.y, b4};
   uint32_t sa[4], sb[4]; /* one v_perm_b32 per count: byte jj of the table word -> the half this entry's row owns */
   {
     const uint32_t sa0 = ha ? k.sel_hi : k.sel_lo, sta = ha ? k.step_hi : k.step_lo;
@@ -1052,37 +1169,28 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
     lds_add(vb + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wb[j >> 2], sb[j & 3]));
   }
 #endif
-  votes += (ca.y - ca.x) + (cb.y - cb.x);
-  /* byte addresses into the cell-sorted offsets; reads past a lane's own range stay inside the workgroup's LDS and
-   * are never used */
-  const uint32_t base32 = k.ws + AGG_OFF_A32;
-  uint32_t ia = base32 + ca.x * 4, ib = base32 + cb.x * 4;
-  const uint32_t ea = base32 + ca.y * 4, eb = base32 + cb.y * 4;
-  /* two hits of each entry's cell per step: one ds_read2_b32 fetches both offsets (the LDS pipe is what this kernel runs
-   * out of, and a read with scattered addresses costs it as much as an atomic) */
-  while (PPF_ABL_OWNCELL && __any((ia < ea) | (ib < eb))) {
-    const bool da0 = ia < ea, da1 = ia + 4u < ea, db0 = ib < eb, db1 = ib + 4u < eb;
-    const uint2 oa = lds_ld2(ia), ob = lds_ld2(ib);
-    const float xa0 = __builtin_fmaf(am_a, k.S, __uint_as_float(oa.x)), xa1 = __builtin_fmaf(am_a, k.S, __uint_as_float(oa.y));
-    const float xb0 = __builtin_fmaf(am_b, k.S, __uint_as_float(ob.x)), xb1 = __builtin_fmaf(am_b, k.S, __uint_as_float(ob.y));
-    int ba0 = (int)xa0, ba1 = (int)xa1, bb0 = (int)xb0, bb1 = (int)xb1;
-    const float fa0 = __builtin_amdgcn_fractf(xa0), fa1 = __builtin_amdgcn_fractf(xa1);
-    const float fb0 = __builtin_amdgcn_fractf(xb0), fb1 = __builtin_amdgcn_fractf(xb1);
-    if (__builtin_expect(__any(__builtin_fminf(__builtin_fminf(fa0, fa1), __builtin_fminf(fb0, fb1)) < k.G2), 0)) { /* some lane may sit in the guard band of a bin edge */
-      uint32_t za = rec.z, zb = rec.w;
-      asm volatile("" : "+v"(za), "+v"(zb)); /* keep the fp64 conversions of the rare path out of the loop */
-      const uint32_t ha = k.ws + AGG_OFF_IDX + ((ia - base32) >> 2), hb = k.ws + AGG_OFF_IDX + ((ib - base32) >> 2);
-      if (da0 && fa0 < k.G2) ba0 = vote_bin_exact_4pi(__uint_as_float(za), g_a64[lds_ld8(ha)], k.A);
-      if (da1 && fa1 < k.G2) ba1 = vote_bin_exact_4pi(__uint_as_float(za), g_a64[lds_ld8(ha + 1u)], k.A);
-      if (db0 && fb0 < k.G2) bb0 = vote_bin_exact_4pi(__uint_as_float(zb), g_a64[lds_ld8(hb)], k.A);
-      if (db1 && fb1 < k.G2) bb1 = vote_bin_exact_4pi(__uint_as_float(zb), g_a64[lds_ld8(hb + 1u)], k.A);
+  const uint32_t na = ca.y - ca.x, nb = cb.y - cb.x;
+  votes += na + nb;
+#if PPF_ABL_OWNCELL
+  if (__any((na > 0u) | (nb > 0u))) {
+    const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
+    uint4 oa = own.oa, ob = own.ob;
+    for (uint32_t done = 0;;) {
+      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.x, ob.x, done + 0u < na, done + 0u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 0u, cb.x + done + 0u);
+      if (!__any((done + 1u < na) | (done + 1u < nb))) break;
+      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.y, ob.y, done + 1u < na, done + 1u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 1u, cb.x + done + 1u);
+      if (!__any((done + 2u < na) | (done + 2u < nb))) break;
+      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.z, ob.z, done + 2u < na, done + 2u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 2u, cb.x + done + 2u);
+      if (!__any((done + 3u < na) | (done + 3u < nb))) break;
+      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.w, ob.w, done + 3u < na, done + 3u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 3u, cb.x + done + 3u);
+      done += 4u;
+      if (!__any((done < na) | (done < nb))) break;
+      /* a cell with more than four hits (an entry that votes one by one: all of them): the next four; lanes that are done
+       * re-read their last words */
+      oa = gl_ld4(toff + min(ca.x + done, (uint32_t)AGG_SUB)); ob = gl_ld4(toff + min(cb.x + done, (uint32_t)AGG_SUB));
     }
-    if (da0) lds_add(pa + ((uint32_t)ba0 << 2), inc_a);
-    if (db0) lds_add(pb + ((uint32_t)bb0 << 2), inc_b);
-    if (da1) lds_add(pa + ((uint32_t)ba1 << 2), inc_a);
-    if (db1) lds_add(pb + ((uint32_t)bb1 << 2), inc_b);
-    ia += 8; ib += 8;
   }
+#endif
 }
 
 /* one work item of k_vote, located and with its first loads issued (wave-uniform fields live in scalar registers) */
@@ -1094,6 +1202,8 @@ struct VoteItem {
   bool agg;         /* votes through the count table */
   double a64;       /* direct items: alpha_s of hit g0 + lane (lanes < nh) */
   uint4 rec0;       /* record min(lane, c-1) (items of <= 32 records: record min(lane/2, c-1), the one-entry-per-lane layout) */
+  const unsigned char* tbl; /* count-table items: the table of the item's run and hit range (k_tables) */
+  uint4 t0, t1;     /* ... and its rows + cell ranges, 16 bytes per lane and half, on their way into the wave's LDS */
 };
 
 #ifndef PPF_PREFETCH
@@ -1105,11 +1215,17 @@ __device__ __forceinline__ void vote_fetch_hits(VoteItem& it, const int lane, co
 __device__ __forceinline__ void vote_fetch_records(VoteItem& it, const int lane) {
   const uint32_t idx = (!it.agg && it.c <= 32) ? ((uint32_t)lane >> 1) : (uint32_t)lane;
   it.rec0 = it.src[min(idx, it.c - 1)];
+  if (it.agg) { /* rows + cell ranges of the item's table: AGG_SCRATCH bytes, two 16-byte pieces per lane */
+    const uint4* __restrict__ t = reinterpret_cast<const uint4*>(it.tbl);
+    it.t0 = t[min(lane, AGG_SCRATCH / 16 - 1)];
+    it.t1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
+  }
 }
+static_assert(AGG_SCRATCH / 16 <= 128, "the table copy gives a lane two 16-byte pieces");
 
 __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, int& h, const uint32_t* seg_prefix, const uint32_t* seg_off,
-                                            const uint32_t* seg_cnt, const uint32_t* seg_hit, const uint32_t* seg_m, const int lane,
-                                            const MatchArgs& a, const uint4* __restrict__ records) {
+                                            const uint32_t* seg_cnt, const uint32_t* seg_hit, const uint32_t* seg_m, const uint32_t* seg_tbl,
+                                            const int lane, const MatchArgs& a, const uint4* __restrict__ records) {
   while (true) { /* advance h to the last position with prefix <= item */
     const uint32_t pv = seg_prefix[min(h + 1 + lane, RUN_SEG + 63)];
     const unsigned long long le = __ballot(pv <= item);
@@ -1134,6 +1250,7 @@ __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, i
   it.src = records + off0 + chunk * chunk_sz;
   it.g0 = hit0 + sub * group_sz;
   it.nh = (int)min(group_sz, m_all - sub * group_sz);
+  it.tbl = it.agg ? a.tables + (size_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_tbl[h]) + sub) * TBL_BYTES : nullptr;
 #if PPF_PREFETCH >= 1
   vote_fetch_hits(it, lane, a);
 #endif
@@ -1152,7 +1269,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   uint32_t* seg_cnt = seg_off + RUN_SEG;                                           /* RUN_SEG: records */
   uint32_t* seg_hit = seg_cnt + RUN_SEG;                                           /* RUN_SEG: first sorted hit */
   uint32_t* seg_m = seg_hit + RUN_SEG;                                             /* RUN_SEG: hits | count-table flag << 31 */
-  unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(seg_m + RUN_SEG); /* VOTE_WAVES x AGG_SCRATCH */
+  uint32_t* seg_tbl = seg_m + RUN_SEG;                                             /* RUN_SEG: first count table of the run (k_tables) */
+  unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(seg_tbl + RUN_SEG); /* VOTE_WAVES x AGG_SCRATCH */
   const int A = a.num_angles;
   const int P = vote_pitch(A);
   const int GW = vote_guard(A);
@@ -1196,13 +1314,9 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   const uint4* __restrict__ records = a.records;
   const double s64 = WRAP ? (double)A / (2 * PPF_PI) : (double)A / (4 * PPF_PI);
   const float S = (float)s64;
-#ifdef PPF_FORCE_EXACT
-  const float G = 1.0f; /* test build: every direct vote takes the fp64 chain */
-#else
   /* guard band: the fp32 error bound is 1.1e-7*A; with the 2 pi range q' reaches 2.5 A and its
-   * rounding steps are four times coarser (bound 3.7e-7*A) */
-  const float G = (WRAP ? 1.6e-6f : PPF_GUARD_REL) * (float)A;
-#endif
+   * rounding steps are four times coarser (bound 3.7e-7*A).  PPF_FORCE_EXACT (test build): 1, every direct vote takes the fp64 chain */
+  const float G = WRAP ? fmaxf(1.6e-6f * (float)A, vote_guard_band(A) >= 1.0f ? 1.0f : 0.0f) : vote_guard_band(A);
   const float G2 = 2.0f * G;
   const double og64 = (WRAP ? 1.5 : 0.5) * (double)A + (double)G; /* folded offsets are formed in fp64 and rounded once */
   const uint32_t tail_bytes = (uint32_t)(lane * 4 + 8); /* per-lane guard word for lanes past the end of a bucket (words 2..65: the count
@@ -1242,7 +1356,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       uint32_t items = 0;
       bool heavy_run = false; /* a run k_group filed under "many hits": those come first in every round's run list */
       if (tid < RUN_SEG) {
-        uint32_t off = 0, cnt = 0, hs = 0, mm = 0;
+        uint32_t off = 0, cnt = 0, hs = 0, mm = 0, tb0 = 0;
         if ((uint32_t)tid < n_seg) {
           const uint4 run = a.runs[rb.x + seg0 + tid];
           off = boff[run.x];
@@ -1254,6 +1368,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           }
           hs = run.y;
           mm = run.z;
+          tb0 = run.w;
           heavy_run = run.z >= agg_min;
           if (cnt) {
             if (run.z >= agg_min && cnt >= PPF_AGG_MIN_RECORDS) {
@@ -1264,7 +1379,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             }
           }
         }
-        seg_off[tid] = off; seg_cnt[tid] = cnt; seg_hit[tid] = hs; seg_m[tid] = mm;
+        seg_off[tid] = off; seg_cnt[tid] = cnt; seg_hit[tid] = hs; seg_m[tid] = mm; seg_tbl[tid] = tb0;
       }
       uint32_t incl = items;
 #pragma unroll
@@ -1332,19 +1447,19 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       uint32_t item = 0;
       int q_item = 0;
       bool have = claim(item, q_item);
-      if (have) vote_locate(cur, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+      if (have) vote_locate(cur, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
       while (have) {
         const bool have_next = claim(item, q_item);
-        if (have_next) vote_locate(nxt, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+        if (have_next) vote_locate(nxt, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
 #else
       int h = 0;
       uint32_t item = (uint32_t)wave;
       bool have = item < total;
-      if (have) vote_locate(cur, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+      if (have) vote_locate(cur, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
       while (have) {
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u));
         const bool have_next = item < total;
-        if (have_next) vote_locate(nxt, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, lane, a, records);
+        if (have_next) vote_locate(nxt, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
 #endif
 #if PPF_PREFETCH < 1
         vote_fetch_hits(cur, lane, a);
@@ -1357,18 +1472,32 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint32_t c = cur.c;
           const uint4* __restrict__ src = cur.src;
           uint4 rec_cur = cur.rec0;
-          agg_build(ak, a.s_a64 + cur.g0, a.s_cell + cur.g0, cur.nh, lane);
-#if PPF_ABL_BUILD == 2
-          agg_build(ak, a.s_a64 + cur.g0, a.s_cell + cur.g0, cur.nh, lane);
-#endif
+          { /* rows + cell ranges of the item's table (k_tables) into this wave's LDS */
+            lds_u32x4* w = (lds_u32x4*)(uintptr_t)ak.ws;
+            wave_lds_fence(); /* the previous item's reads of this scratch are done */
+            if (lane < AGG_SCRATCH / 16) w[lane] = u32x4_t{cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w};
+            if (lane + 64 < AGG_SCRATCH / 16) w[lane + 64] = u32x4_t{cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w};
+            wave_lds_fence();
+          }
+          const unsigned char* __restrict__ tbl = cur.tbl;
           const double* __restrict__ g_a64 = a.s_a64 + cur.g0;
+          /* two blocks of records in flight: block i+2's records and block i+1's own-cell offsets (which need that block's
+           * records and the cell ranges in LDS) are loaded under block i's votes, so a block waits for nothing issued in
+           * its own iteration */
+          AggOwn own_cur;
+          agg_own_fetch(ak, rec_cur, tbl, cur.nh, own_cur);
+          uint4 rec_n1 = src[min((uint32_t)lane + 64u, c - 1)];
           for (uint32_t e0 = 0; e0 < c; e0 += 64) {
             const uint32_t e = e0 + (uint32_t)lane;
-            const uint4 rec_nxt = src[min(e + 64, c - 1)]; /* next block's records in flight under this block's votes */
+            const uint4 rec_n2 = src[min(e + 128, c - 1)];
+            AggOwn own_n1;
+            agg_own_fetch(ak, rec_n1, tbl, cur.nh, own_n1);
             uint4 rec = rec_cur;
             if (e >= c) { rec.x = tail_bytes | (rec.x & ~ROW_CODE_MASK); rec.y = tail_bytes | (rec.y & ~ROW_CODE_MASK); } /* the clamped record's cells go with its alphas */
-            agg_pair(ak, rec, g_a64, cur.nh, agg_votes);
-            rec_cur = rec_nxt;
+            agg_pair(ak, rec, own_cur, tbl, g_a64, agg_votes);
+            rec_cur = rec_n1;
+            rec_n1 = rec_n2;
+            own_cur = own_n1;
           }
           ops += 2u * (AGG_NY + 1) * 64u * ((c + 63u) / 64u);
           issued += 128ull * ((c + 63u) / 64u) * (uint32_t)cur.nh; /* counted + one-by-one votes of an entry = its hits */
@@ -1551,6 +1680,6 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 }
 
 /* fixed LDS of k_vote: header + run staging + per-wave count tables (the guard and the cells are sized per model) */
-constexpr size_t VOTE_LDS_FIXED = LDS_HEADER + (size_t)(RUN_SEG + 64) * 4 + (size_t)RUN_SEG * 4 * 4 + (size_t)VOTE_WAVES * AGG_SCRATCH;
+constexpr size_t VOTE_LDS_FIXED = LDS_HEADER + (size_t)(RUN_SEG + 64) * 4 + (size_t)RUN_SEG * 5 * 4 + (size_t)VOTE_WAVES * AGG_SCRATCH;
 
 #endif /* PPF_MATCH_KERNELS_H */

@@ -124,7 +124,7 @@ static ppf_status build_table(ppf_model* m, hipStream_t st) {
   /* Dealing order inside a bucket (see "table layout" above): two levels (the accumulator-word half of the entry's row),
    * a level cut into up to gmax cell groups, inside a group every bank's entries in phase order, spread evenly over it. */
   const int levels = 2;
-  uint32_t gmax = 32; /* fewer groups when the class keys would not fit 32 bits or the group counters would be unreasonably big */
+  uint32_t gmax = (uint32_t)AGG_Q; /* one group per count-table cell at most; fewer groups when the class keys would not fit 32 bits or the group counters would be unreasonably big */
   while (gmax > 1 && (ncnt * (size_t)levels * gmax * DEAL_BANKS >= 0xFFFFFFF0ull || ncnt * (size_t)levels * gmax * sizeof(uint32_t) > ((size_t)1 << 30)))
     gmax >>= 1;
   if (ncnt * (size_t)levels * gmax * DEAL_BANKS >= 0xFFFFFFF0ull)
@@ -401,7 +401,7 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
 
 /* ---- model (de)serialisation: versioned binary CSR (the reference's XML format is defined by a
  * private OpenCV patch and unknown) ------------------------------------------------- */
-static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '3'}; /* 02: pair-record table; 03: ppf_train_params.feature */
+static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '4'}; /* 02: pair-record table; 03: ppf_train_params.feature; 04: 64 count-table cells (7-bit cell field), cell-grouped dealing */
 
 /* the model as a byte stream (what a model file holds), written to an open FILE */
 static ppf_status model_write(const ppf_model* m, FILE* f, const char* path) {
@@ -538,9 +538,9 @@ static ppf_status model_load_stream(FILE* f, const char* path, ppf_model** out, 
     for (uint64_t k = 0; k < ne; k++) {
       const uint32_t codes[2] = {ent[k].x, ent[k].y}, al[2] = {ent[k].z, ent[k].w};
       for (int sl = 0; sl < 2; sl++) {
-        const uint32_t row = codes[sl] & ROW_CODE_MASK, cx = (codes[sl] >> ROW_X_SHIFT) & 31u, cq = (codes[sl] >> ROW_Q_SHIFT) & 63u;
+        const uint32_t row = codes[sl] & ROW_CODE_MASK, cx = (codes[sl] >> ROW_X_SHIFT) & 31u, cq = (codes[sl] >> ROW_Q_SHIFT) & ROW_Q_MASK;
         if ((row & 2u) || row / 4 + (uint32_t)A + 1 > limit_words) return bad("record row"); /* bin A of the last row: the word behind the rows */
-        if ((codes[sl] >> 29) || cx > (uint32_t)A || cq > (uint32_t)AGG_Q) return bad("record cell");
+        if ((codes[sl] >> 30) || cx > (uint32_t)A || cq > (uint32_t)AGG_Q) return bad("record cell");
         float av;
         memcpy(&av, &al[sl], 4);
         if (!(std::fabs(av) <= 3.1416f)) return bad("record alpha");

@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void k_build_key_lut(const SlotWord* __restric
  *     entries are dealt in key order: every bank's entries are spread evenly, a bank with many entries (a model row
  *     that owns much of the bucket) as well as one with few -- dealing the banks round robin left the tail to the few
  *     heavy banks;
- *   - the level is first cut into up to 32 CELL GROUPS of at least PPF_DEAL_GROUP_MIN (256) entries each (deal_groups):
- *     group = the entry's count-table cell q (the 1/32 of an alpha bin its alpha_m sits in) scaled to the number of
+ *   - the level is first cut into up to 64 CELL GROUPS of at least PPF_DEAL_GROUP_MIN (256) entries each (deal_groups):
+ *     group = the entry's count-table cell q (the 1/64 of an alpha bin its alpha_m sits in) scaled to the number of
  *     groups; the spreading above happens inside each group.  A level of 8,192 entries or more is thereby sorted by cell
  *     exactly, so the 128 entries of a record block share one cell (two at a group boundary): the lanes of k_vote's
  *     own-cell loop then walk the same hits for the same number of steps and read the same table rows (round 2 ordered
@@ -242,13 +242,13 @@ constexpr uint32_t DEAL_BANKS = PPF_DEAL_BANKS; /* LDS banks the dealing order s
 #endif
 __host__ __device__ __forceinline__ uint32_t deal_groups(uint32_t n_level, uint32_t gmax) {
   uint32_t g = 1;
-  while (g < gmax && n_level >= 2u * PPF_DEAL_GROUP_MIN * g) g <<= 1;
+  while (2u * g <= gmax && n_level >= 2u * PPF_DEAL_GROUP_MIN * g) g <<= 1; /* a power of two, at most gmax */
   return g;
 }
 /* group of an entry: its count-table cell (0..AGG_Q-1, AGG_Q = votes one by one: last group) scaled to `groups` */
 __device__ __forceinline__ uint32_t deal_group_of(float alpha_m, int num_angles, uint32_t groups) {
-  const uint32_t q = min((agg_cell_bits(alpha_m, num_angles) >> ROW_Q_SHIFT) & 63u, 31u);
-  return (q * groups) >> 5;
+  const uint32_t q = min((agg_cell_bits(alpha_m, num_angles) >> ROW_Q_SHIFT) & ROW_Q_MASK, (uint32_t)AGG_Q - 1u);
+  return (q * groups) / (uint32_t)AGG_Q;
 }
 
 __device__ __forceinline__ void entry_class_level(uint32_t row_bytes, float alpha_m, int num_angles, int levels,
@@ -393,14 +393,14 @@ __global__ void k_record_counts(const uint32_t* __restrict__ counts, uint32_t* _
   if (i < n) rec_cnt[i] = records_for(counts[i]);
 }
 
-/* every slot starts as a dummy: row = one of the first 64 guard words (never a cell), alpha = 0.0065 (any value whose
- * alpha*A/(4 pi) sits in the middle of a 1/32 cell for the usual A: the count-table path of k_vote then treats it like any
+/* every slot starts as a dummy: row = one of the first 64 guard words (never a cell), alpha = 0.00327 (any value whose
+ * alpha*A/(4 pi) sits in the middle of a 1/64 cell for the usual A: the count-table path of k_vote then treats it like any
  * other entry instead of taking its on-a-cell-boundary route) */
 __global__ void k_record_init(uint4* __restrict__ records, size_t n, int num_angles) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const uint32_t w = (uint32_t)(i & 63u) * 4u | agg_cell_bits(0.0065f, num_angles);
-    const uint32_t al = __float_as_uint(0.0065f);
+    const uint32_t w = (uint32_t)(i & 63u) * 4u | agg_cell_bits(0.00327f, num_angles);
+    const uint32_t al = __float_as_uint(0.00327f);
     records[i] = make_uint4(w, w, al, al);
   }
 }
