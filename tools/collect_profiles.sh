@@ -3,6 +3,7 @@
 #   tools/collect_profiles.sh gpurun_out/r03_final lines    bench lines (c2 with host entry, C4 / C5 legs and the CPU baseline; c4; c5),
 #                                                           2-rank rehearsals, rocprofv3 kernel traces, the attribution builds
 #   tools/collect_profiles.sh gpurun_out/r03_final pmc      PMC passes of c2, c4, c5 (never combined with traces)
+#   tools/collect_profiles.sh gpurun_out/r03_final benchlines   only the bench lines and rehearsals again (publish with --lines)
 # then, in the repo:  python tools/publish_profiles.py gpurun_out/r03_final r03
 # The attribution builds (build_var/a_*.so) are made beforehand with tools/build_attribution.sh.
 set -e
@@ -11,7 +12,7 @@ WHAT=${2:-lines}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd "$ROOT"
-if [ "$WHAT" = lines ]; then
+if [ "$WHAT" = lines ] || [ "$WHAT" = benchlines ]; then
   python bench.py --steps 20 --warmup 5 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
   python bench.py --config c4 --cells 32 --steps 3 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
   python bench.py --config c5 --steps 3 --warmup 1 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
@@ -21,6 +22,7 @@ if [ "$WHAT" = lines ]; then
     python bench.py --gpus 2 --config c4 --shard refs --steps 2 --warmup 1 > "$OUT/bench_c4_refs_2ranks_one_device_gloo.json" 2>> "$OUT/bench_n2.err"
     python bench.py --gpus 2 --config c5 --steps 3 --warmup 1 > "$OUT/bench_c5_2ranks_one_device_gloo.json" 2>> "$OUT/bench_n2.err" )
   echo "2-rank rehearsals done"
+  [ "$WHAT" = benchlines ] && exit 0   # after publishing the PMC summaries: the lines again, so that their roofline objects read them
   ( cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c2" -o c2 -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > "$ROOT/$OUT/trace_c2.log" 2>&1
     rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c4" -o c4 -- python3 "$ROOT/bench.py" --config c4 --cells 32 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c4.log" 2>&1
