@@ -285,6 +285,7 @@ ppf_status ppf_workspace_destroy(ppf_workspace* ws);
 #define PPF_OPT_ACC32 4          /* != 0: 32-bit accumulator cells for every (reference point, tile) (otherwise 16-bit cells first, and 32-bit
                                    cells only for those the vote kernel saw overflow) */
 #define PPF_OPT_TABLE_FRACTION 5 /* expected count tables per hit (sizes the table pool of the next call; learned from then on) */
+#define PPF_OPT_BATCH_REFS 6     /* > 0: at most this many reference points per batch of a call (default: what 4 GB of hit scratch hold); a test knob */
 ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);
 /* record HIP events around the kernels of each call (read back through ppf_workspace_results' stats) */
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);

@@ -177,6 +177,22 @@ def test_several_group_rounds_give_the_same_votes(det, crop, oracle_crop):
     assert res["stats"]["n_votes"] == int(oracle_crop["votes_per_ref"].sum())
 
 
+def test_several_batches_of_reference_points_give_the_same_votes(det, crop, oracle_crop):
+    """A call whose hits exceed the scratch budget is cut into batches of reference points (C4 runs three); forced here with
+    37 points per batch: every batch reuses the hit pools, the run table and the count-table pool, results accumulate."""
+    ws = Workspace()
+    ws.set_option(_capi.PPF_OPT_BATCH_REFS, 37)
+    for mode in (0, 1):
+        res = _device_run(det, crop, ws, vote_mode=mode)
+        assert res["stats"]["n_batches"] == -(-res["stats"]["n_ref"] // 37) > 10
+        np.testing.assert_array_equal(res["triples"], oracle_crop["triples"])
+        assert res["stats"]["n_votes"] == int(oracle_crop["votes_per_ref"].sum())  # (small batches stray from the mean: a repeat may happen)
+    one = _device_run(det, crop)
+    assert one["stats"]["n_batches"] == 1 and one["stats"]["n_tables"] == _device_run(det, crop, ws)["stats"]["n_tables"]
+    for g, w in zip(res["raw_poses"][::11], one["raw_poses"][::11]):
+        assert np.array_equal(g.pose, w.pose)
+
+
 def test_two_host_threads_share_one_model(det, bottle):
     """B5: two host threads, one ppf_model, each with its own workspace and stream, 20 interleaved calls each on
     different crops: every result equals the single-thread one."""

@@ -250,6 +250,7 @@ struct ppf_workspace {
   double tbl_frac = TBL_FRAC_START;      /* expected count tables per hit, learned likewise (at most TBL_FRAC_MAX) */
   struct Learned { uint64_t model_serial; double hit, run, tbl; };
   std::vector<Learned> frac_by_model;    /* the three fractions remembered per model, at most 16 (batches alternate models): workspace_learned() */
+  int batch_refs_cap = 0;                /* 0 = what the scratch budget holds; tests lower it to force several batches per call */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
   bool acc32 = false;                    /* a 16-bit accumulator cell overflowed with this model: 32-bit cells until the model changes */
   bool force_acc32 = false;              /* PPF_OPT_ACC32 */

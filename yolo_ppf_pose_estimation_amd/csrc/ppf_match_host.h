@@ -37,6 +37,10 @@ ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value)
     case PPF_OPT_ACC32:
       ws->force_acc32 = value != 0;
       return PPF_OK;
+    case PPF_OPT_BATCH_REFS:
+      if (!(value >= 0 && value <= 1e9)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: bad batch size");
+      ws->batch_refs_cap = (int)value;
+      return PPF_OK;
     case PPF_OPT_TABLE_FRACTION:
       if (!(value > 0 && value <= 1)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: table fraction must be in (0, 1]");
       ws->tbl_frac = std::min(TBL_FRAC_MAX, value);
@@ -269,6 +273,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   int batch = (int)std::min<double>((double)n_ref, std::max(1.0, (double)HIT_BYTES_BUDGET / (hits_per_ref * (HIT_SCRATCH_BYTES + tbl_frac * TBL_BYTES))));
   batch = (int)std::min<double>((double)batch, std::max(1.0, 2.0e9 / hits_per_ref));
   batch = std::min(batch, 32768); /* grid.y of k_pairs */
+  if (ws->batch_refs_cap > 0) batch = std::min(batch, ws->batch_refs_cap);
   const bool worst_case = frac >= 1.0;
   const double est = hits_per_ref * (double)batch;
   /* a stripe receives whole workgroups of up to PAIR_BLOCK*PAIRS_PER_THREAD hits; at worst-case size every workgroup of
