@@ -854,7 +854,12 @@ __device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, 
 struct VoteInc {
   uint32_t lo, hi; /* 16-bit cells: 1, 0x10000; 32-bit cells, pass h: 1 for the rows of half h, 0 for the others */
 };
-__device__ __forceinline__ uint32_t vote_inc(const VoteInc& vi, const uint32_t row_code) { return (row_code & 1u) ? vi.hi : vi.lo; }
+/* bit select, not `bit ? vi.hi : vi.lo`: the compiler turns that select of two struct fields into an indexed load from the
+ * struct's stack copy (a scratch_load + s_waitcnt vmcnt(0) per entry, in the middle of the record prefetches) */
+__device__ __forceinline__ uint32_t vote_inc(const VoteInc& vi, const uint32_t row_code) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)row_code, 0u, 1u); /* 0 or all ones */
+  return (m & vi.hi) | (~m & vi.lo);
+}
 
 template <int U, bool WRAP>
 __device__ __forceinline__ void vote_hits(const uint32_t acc_base, const VoteInc& vi, const uint4* rec, const int n_valid, const float S,
@@ -1151,7 +1156,7 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   const uint32_t a4 = lds_ld(ta + 16), b4 = lds_ld(tb + 16);
   const uint32_t pa = k.acc_base + (rec.x & ROW_OFFSET_MASK), pb = k.acc_base + (rec.y & ROW_OFFSET_MASK);
   const bool ha = (rec.x & 1u) != 0, hb = (rec.y & 1u) != 0;
-  const uint32_t inc_a = ha ? k.vi.hi : k.vi.lo, inc_b = hb ? k.vi.hi : k.vi.lo;
+  const uint32_t inc_a = vote_inc(k.vi, rec.x), inc_b = vote_inc(k.vi, rec.y);
   uint32_t va = pa + (uint32_t)((Xa - 8) * 4), vb = pb + (uint32_t)((Xb - 8) * 4); /* bin X + 8 - j lives at v + (16 - j)*4 */
   asm volatile("" : "+v"(va), "+v"(vb)); /* keep these as the bases: every atomic below is base + immediate offset */
   const uint32_t wa[5] = {a01.x, a01.y, a23.x, a23.y, a4}, wb[5] = {b01.x, b01.y, b23.x, b23.y, b4};
