@@ -854,6 +854,11 @@ __device__ __forceinline__ void vote_stage(const uint4* rec, const int n_valid, 
 struct VoteInc {
   uint32_t lo, hi; /* 16-bit cells: 1, 0x10000; 32-bit cells, pass h: 1 for the rows of half h, 0 for the others */
 };
+/* mask ? b : a per bit (mask 0 or all ones).  Used where a plain `cond ? s.f1 : s.f0` on two fields of one struct would be
+ * turned into an indexed load from a stack copy of the struct, which drags the whole struct -- a prefetched record, say --
+ * through scratch memory with a wait for everything in flight. */
+__device__ __forceinline__ uint32_t bit_select(const uint32_t mask, const uint32_t a, const uint32_t b) { return (mask & b) | (~mask & a); }
+
 /* bit select, not `bit ? vi.hi : vi.lo`: the compiler turns that select of two struct fields into an indexed load from the
  * struct's stack copy (a scratch_load + s_waitcnt vmcnt(0) per entry, in the middle of the record prefetches) */
 __device__ __forceinline__ uint32_t vote_inc(const VoteInc& vi, const uint32_t row_code) {
@@ -1208,7 +1213,6 @@ struct VoteItem {
   double a64;       /* direct items: alpha_s of hit g0 + lane (lanes < nh) */
   uint4 rec0;       /* record min(lane, c-1) (items of <= 32 records: record min(lane/2, c-1), the one-entry-per-lane layout) */
   const unsigned char* tbl; /* count-table items: the table of the item's run and hit range (k_tables) */
-  uint4 t0, t1;     /* ... and its rows + cell ranges, 16 bytes per lane and half, on their way into the wave's LDS */
 };
 
 #ifndef PPF_PREFETCH
@@ -1220,11 +1224,6 @@ __device__ __forceinline__ void vote_fetch_hits(VoteItem& it, const int lane, co
 __device__ __forceinline__ void vote_fetch_records(VoteItem& it, const int lane) {
   const uint32_t idx = (!it.agg && it.c <= 32) ? ((uint32_t)lane >> 1) : (uint32_t)lane;
   it.rec0 = it.src[min(idx, it.c - 1)];
-  if (it.agg) { /* rows + cell ranges of the item's table: AGG_SCRATCH bytes, two 16-byte pieces per lane */
-    const uint4* __restrict__ t = reinterpret_cast<const uint4*>(it.tbl);
-    it.t0 = t[min(lane, AGG_SCRATCH / 16 - 1)];
-    it.t1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
-  }
 }
 static_assert(AGG_SCRATCH / 16 <= 128, "the table copy gives a lane two 16-byte pieces");
 
@@ -1477,11 +1476,15 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint32_t c = cur.c;
           const uint4* __restrict__ src = cur.src;
           uint4 rec_cur = cur.rec0;
-          { /* rows + cell ranges of the item's table (k_tables) into this wave's LDS */
+          { /* rows + cell ranges of the item's table (k_tables) into this wave's LDS: AGG_SCRATCH bytes, two 16-byte pieces per
+             * lane.  Loaded here, not with the item's prefetch: a reference point has some 60 count-table items among 600, and
+             * eight registers of table in every prefetched item cost the direct items more than this wait costs these */
+            const uint4* __restrict__ t = reinterpret_cast<const uint4*>(cur.tbl);
+            const uint4 t0 = t[min(lane, AGG_SCRATCH / 16 - 1)], t1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
             lds_u32x4* w = (lds_u32x4*)(uintptr_t)ak.ws;
             wave_lds_fence(); /* the previous item's reads of this scratch are done */
-            if (lane < AGG_SCRATCH / 16) w[lane] = u32x4_t{cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w};
-            if (lane + 64 < AGG_SCRATCH / 16) w[lane + 64] = u32x4_t{cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w};
+            if (lane < AGG_SCRATCH / 16) w[lane] = u32x4_t{t0.x, t0.y, t0.z, t0.w};
+            if (lane + 64 < AGG_SCRATCH / 16) w[lane + 64] = u32x4_t{t1.x, t1.y, t1.z, t1.w};
             wave_lds_fence();
           }
           const unsigned char* __restrict__ tbl = cur.tbl;
@@ -1510,6 +1513,11 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           /* ---- direct item: <= VOTE_MAX_HITS hits x <= VOTE_CHUNK records ---- */
           const uint32_t c = cur.c;
           const int nh = cur.nh;
+          /* the prefetched first records as plain register values: a `cond ? cur.rec0 : src[..]` further down would become a load
+           * through a selected POINTER, which needs cur.rec0 in memory: the whole item then lives on the stack and its prefetch is
+           * waited for and stored the moment it is issued */
+          uint4 rec0_reg = cur.rec0;
+          asm volatile("" : "+v"(rec0_reg.x), "+v"(rec0_reg.y), "+v"(rec0_reg.z), "+v"(rec0_reg.w));
           /* lane l holds the folded offset of hit g0+l: Ohg = A/2 + G - alpha_s*S */
           const float ohg_v = lane < nh ? (WRAP ? (float)(og64 - cur.a64 * s64) : (float)og64 - (float)cur.a64 * S) : 0.f;
           const double* __restrict__ asd = a.s_a64 + cur.g0; /* exact alpha_s, read on the guard path only */
@@ -1524,7 +1532,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
            * paths and force the compiler into a vmcnt that also waits for the prefetch. */
           uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
           if (nfull) {
-            ea[0] = cur.rec0;
+            ea[0] = rec0_reg;
 #pragma unroll
             for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = src[u * 64 + lane];
           }
@@ -1554,23 +1562,23 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint32_t e0 = nfull * B;
           if (c <= 32) { /* at most 64 entries: one entry per lane (rec0 was fetched for this layout) */
             const uint32_t e = (uint32_t)lane >> 1;
-            const uint4 rr = cur.rec0;
-            const bool second = (lane & 1) != 0;
-            const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            if (PPF_ABL_DIRECT_SMALL) vote_hits_single<WRAP>(acc_base, vi, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            const uint4 rr = rec0_reg;
+            const uint32_t odd = 0u - ((uint32_t)lane & 1u); /* the record's second entry */
+            const uint32_t row_bytes = e < c ? bit_select(odd, rr.x, rr.y) : tail_bytes;
+            if (PPF_ABL_DIRECT_SMALL) vote_hits_single<WRAP>(acc_base, vi, row_bytes, bit_select(odd, rr.z, rr.w), S, ohg_v, nh, asd, G2, A);
             issued += 64ull * (uint32_t)nh;
           } else if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
             const uint32_t e = e0 + ((uint32_t)lane >> 1);
             const uint4 rr = src[min(e, c - 1)];
-            const bool second = (lane & 1) != 0;
-            const uint32_t row_bytes = e < c ? (second ? rr.y : rr.x) : tail_bytes;
-            vote_hits_single<WRAP>(acc_base, vi, row_bytes, second ? rr.w : rr.z, S, ohg_v, nh, asd, G2, A);
+            const uint32_t odd = 0u - ((uint32_t)lane & 1u); /* the record's second entry */
+            const uint32_t row_bytes = e < c ? bit_select(odd, rr.x, rr.y) : tail_bytes;
+            vote_hits_single<WRAP>(acc_base, vi, row_bytes, bit_select(odd, rr.z, rr.w), S, ohg_v, nh, asd, G2, A);
             issued += 64ull * (uint32_t)nh;
           } else if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
 #pragma unroll
             for (int u = 0; u < VOTE_UNROLL; u++) {
               const uint32_t e = e0 + u * 64 + lane;
-              ea[u] = (u == 0 && e0 == 0) ? cur.rec0 : src[min(e, c - 1)];
+              if (u == 0 && e0 == 0) ea[u] = rec0_reg; else ea[u] = src[min(e, c - 1)];
               if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
             }
             const int n_valid = (int)((c - e0 + 63) / 64);
