@@ -1183,22 +1183,39 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   votes += na + nb;
 #if PPF_ABL_OWNCELL
   if (__any((na > 0u) | (nb > 0u))) {
-    const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
-    uint4 oa = own.oa, ob = own.ob;
-    for (uint32_t done = 0;;) {
-      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.x, ob.x, done + 0u < na, done + 0u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 0u, cb.x + done + 0u);
-      if (!__any((done + 1u < na) | (done + 1u < nb))) break;
-      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.y, ob.y, done + 1u < na, done + 1u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 1u, cb.x + done + 1u);
-      if (!__any((done + 2u < na) | (done + 2u < nb))) break;
-      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.z, ob.z, done + 2u < na, done + 2u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 2u, cb.x + done + 2u);
-      if (!__any((done + 3u < na) | (done + 3u < nb))) break;
-      agg_own_vote(k, rec.z, rec.w, am_a, am_b, oa.w, ob.w, done + 3u < na, done + 3u < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + done + 3u, cb.x + done + 3u);
-      done += 4u;
-      if (!__any((done < na) | (done < nb))) break;
-      /* a cell with more than four hits (an entry that votes one by one: all of them): the next four; lanes that are done
-       * re-read their last words */
-      oa = gl_ld4(toff + min(ca.x + done, (uint32_t)AGG_SUB)); ob = gl_ld4(toff + min(cb.x + done, (uint32_t)AGG_SUB));
+    /* the first four hits of the cells, from the offsets fetched a block ahead: straight-line code, so that the wait for
+     * them lets the loads issued since (the next blocks' records and offsets) stay in flight -- as the head of a loop that
+     * also re-fetches, it was a wait for everything */
+#define PPF_OWN_VOTE(OA, OB, J) \
+    agg_own_vote(k, rec.z, rec.w, am_a, am_b, OA, OB, (J) < na, (J) < nb, pa, pb, inc_a, inc_b, tbl, g_a64, ca.x + (J), cb.x + (J))
+    PPF_OWN_VOTE(own.oa.x, own.ob.x, 0u);
+    if (__any((1u < na) | (1u < nb))) {
+      PPF_OWN_VOTE(own.oa.y, own.ob.y, 1u);
+      if (__any((2u < na) | (2u < nb))) {
+        PPF_OWN_VOTE(own.oa.z, own.ob.z, 2u);
+        if (__any((3u < na) | (3u < nb))) {
+          PPF_OWN_VOTE(own.oa.w, own.ob.w, 3u);
+          if (__builtin_expect(__any((4u < na) | (4u < nb)), 0)) {
+            /* a cell with more than four hits (an entry that votes one by one: all of them): four more at a time; lanes that
+             * are done re-read their last words */
+            const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
+            for (uint32_t done = 4u;;) {
+              const uint4 oa = gl_ld4(toff + min(ca.x + done, (uint32_t)AGG_SUB)), ob = gl_ld4(toff + min(cb.x + done, (uint32_t)AGG_SUB));
+              PPF_OWN_VOTE(oa.x, ob.x, done + 0u);
+              if (!__any((done + 1u < na) | (done + 1u < nb))) break;
+              PPF_OWN_VOTE(oa.y, ob.y, done + 1u);
+              if (!__any((done + 2u < na) | (done + 2u < nb))) break;
+              PPF_OWN_VOTE(oa.z, ob.z, done + 2u);
+              if (!__any((done + 3u < na) | (done + 3u < nb))) break;
+              PPF_OWN_VOTE(oa.w, ob.w, done + 3u);
+              done += 4u;
+              if (!__any((done < na) | (done < nb))) break;
+            }
+          }
+        }
+      }
     }
+#undef PPF_OWN_VOTE
   }
 #endif
 }
@@ -1226,6 +1243,16 @@ __device__ __forceinline__ void vote_fetch_records(VoteItem& it, const int lane)
   it.rec0 = it.src[min(idx, it.c - 1)];
 }
 static_assert(AGG_SCRATCH / 16 <= 128, "the table copy gives a lane two 16-byte pieces");
+
+/* The first item of a segment: wait for its loads before the item loop is entered.  Inside the loop an item's loads were
+ * issued an item ago and are waited for where the item is handed over (cur = nxt); without this, the loop body would have
+ * to allow for the first item's loads still being in flight on the way in, and its wait for them -- counted back from the
+ * newest load -- would in every later round be a wait for the prefetch of the NEXT item, issued moments before. */
+__device__ __forceinline__ void vote_item_settle(VoteItem& it) {
+  uint32_t lo = (uint32_t)__double2loint(it.a64), hi = (uint32_t)__double2hiint(it.a64);
+  asm volatile("" : "+v"(lo), "+v"(hi), "+v"(it.rec0.x), "+v"(it.rec0.y), "+v"(it.rec0.z), "+v"(it.rec0.w));
+  it.a64 = __hiloint2double((int)hi, (int)lo);
+}
 
 __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, int& h, const uint32_t* seg_prefix, const uint32_t* seg_off,
                                             const uint32_t* seg_cnt, const uint32_t* seg_hit, const uint32_t* seg_m, const uint32_t* seg_tbl,
@@ -1452,7 +1479,14 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       int q_item = 0;
       bool have = claim(item, q_item);
       if (have) vote_locate(cur, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
+      vote_item_settle(cur);
       while (have) {
+        uint4 tbl0 = make_uint4(0u, 0u, 0u, 0u), tbl1 = tbl0;
+        if (cur.agg) {
+          const uint4* __restrict__ t = reinterpret_cast<const uint4*>(cur.tbl);
+          tbl0 = t[min(lane, AGG_SCRATCH / 16 - 1)];
+          tbl1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
+        }
         const bool have_next = claim(item, q_item);
         if (have_next) vote_locate(nxt, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
 #else
@@ -1460,7 +1494,16 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       uint32_t item = (uint32_t)wave;
       bool have = item < total;
       if (have) vote_locate(cur, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
+      vote_item_settle(cur);
       while (have) {
+        /* a count-table item: its table's rows and cell ranges (two 16-byte pieces per lane) set out first, ahead of the next
+         * item's prefetch, so that the wait for them is not also a wait for that */
+        uint4 tbl0 = make_uint4(0u, 0u, 0u, 0u), tbl1 = tbl0;
+        if (cur.agg) {
+          const uint4* __restrict__ t = reinterpret_cast<const uint4*>(cur.tbl);
+          tbl0 = t[min(lane, AGG_SCRATCH / 16 - 1)];
+          tbl1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
+        }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u));
         const bool have_next = item < total;
         if (have_next) vote_locate(nxt, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
@@ -1476,15 +1519,13 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint32_t c = cur.c;
           const uint4* __restrict__ src = cur.src;
           uint4 rec_cur = cur.rec0;
-          { /* rows + cell ranges of the item's table (k_tables) into this wave's LDS: AGG_SCRATCH bytes, two 16-byte pieces per
-             * lane.  Loaded here, not with the item's prefetch: a reference point has some 60 count-table items among 600, and
-             * eight registers of table in every prefetched item cost the direct items more than this wait costs these */
-            const uint4* __restrict__ t = reinterpret_cast<const uint4*>(cur.tbl);
-            const uint4 t0 = t[min(lane, AGG_SCRATCH / 16 - 1)], t1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
+          { /* rows + cell ranges of the item's table (k_tables) into this wave's LDS.  Loaded at the top of the round, not with
+             * the item's prefetch: a reference point has some 60 count-table items among 600, and eight registers of table in
+             * every prefetched item cost the direct items more than this wait costs these */
             lds_u32x4* w = (lds_u32x4*)(uintptr_t)ak.ws;
             wave_lds_fence(); /* the previous item's reads of this scratch are done */
-            if (lane < AGG_SCRATCH / 16) w[lane] = u32x4_t{t0.x, t0.y, t0.z, t0.w};
-            if (lane + 64 < AGG_SCRATCH / 16) w[lane + 64] = u32x4_t{t1.x, t1.y, t1.z, t1.w};
+            if (lane < AGG_SCRATCH / 16) w[lane] = u32x4_t{tbl0.x, tbl0.y, tbl0.z, tbl0.w};
+            if (lane + 64 < AGG_SCRATCH / 16) w[lane + 64] = u32x4_t{tbl1.x, tbl1.y, tbl1.z, tbl1.w};
             wave_lds_fence();
           }
           const unsigned char* __restrict__ tbl = cur.tbl;
@@ -1526,20 +1567,12 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           const uint32_t nfull = c / B;
           ops += 2ull * 64u * ((c + 63u) / 64u) * (uint32_t)nh;
           issued += 128ull * VOTE_UNROLL * nfull * (uint32_t)nh;
-          /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in
-           * flight while batch b is voted for every hit of the item.  The prefetch is unconditional
-           * (the last one re-reads the final batch): a conditional one would merge two control-flow
-           * paths and force the compiler into a vmcnt that also waits for the prefetch. */
-          uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
-          if (nfull) {
-            ea[0] = rec0_reg;
-#pragma unroll
-            for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = src[u * 64 + lane];
-          }
-          uint32_t b = 0;
+          /* Three self-contained cases, each with its own record registers: nothing loaded for one item is live (or still in
+           * flight) when the next one starts, so that the start of an item waits for its own prefetched record only */
 #if PPF_ABL_DIRECT_BIG != 1
           if (c > 32) { /* attribution build: these items without their votes (2: the record loads stay) */
 #if PPF_ABL_DIRECT_BIG == 2
+            uint4 eb[VOTE_UNROLL];
             for (uint32_t e0 = 0; e0 < c; e0 += 64 * VOTE_UNROLL) {
               load_records<VOTE_UNROLL>(eb, src, min(e0, c > 64u * VOTE_UNROLL ? c - 64u * VOTE_UNROLL : 0u), lane);
 #pragma unroll
@@ -1551,15 +1584,6 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             continue;
           }
 #endif
-          while (b < nfull) {
-            load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
-            vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
-            if (++b >= nfull) break;
-            load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
-            vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
-            ++b;
-          }
-          const uint32_t e0 = nfull * B;
           if (c <= 32) { /* at most 64 entries: one entry per lane (rec0 was fetched for this layout) */
             const uint32_t e = (uint32_t)lane >> 1;
             const uint4 rr = rec0_reg;
@@ -1567,30 +1591,62 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             const uint32_t row_bytes = e < c ? bit_select(odd, rr.x, rr.y) : tail_bytes;
             if (PPF_ABL_DIRECT_SMALL) vote_hits_single<WRAP>(acc_base, vi, row_bytes, bit_select(odd, rr.z, rr.w), S, ohg_v, nh, asd, G2, A);
             issued += 64ull * (uint32_t)nh;
-          } else if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
-            const uint32_t e = e0 + ((uint32_t)lane >> 1);
-            const uint4 rr = src[min(e, c - 1)];
-            const uint32_t odd = 0u - ((uint32_t)lane & 1u); /* the record's second entry */
-            const uint32_t row_bytes = e < c ? bit_select(odd, rr.x, rr.y) : tail_bytes;
-            vote_hits_single<WRAP>(acc_base, vi, row_bytes, bit_select(odd, rr.z, rr.w), S, ohg_v, nh, asd, G2, A);
-            issued += 64ull * (uint32_t)nh;
-          } else if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
+          } else {
+            uint32_t e0 = 0;
+            if (nfull) {
+              /* full batches, software-pipelined over two register sets: the loads of batch b+1 are in flight while batch b is
+               * voted for every hit of the item.  The prefetch is unconditional (the last one re-reads the final batch): a
+               * conditional one would merge two control-flow paths and force the compiler into a vmcnt that also waits for
+               * the prefetch. */
+              uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
+              ea[0] = rec0_reg;
 #pragma unroll
-            for (int u = 0; u < VOTE_UNROLL; u++) {
-              const uint32_t e = e0 + u * 64 + lane;
-              if (u == 0 && e0 == 0) ea[u] = rec0_reg; else ea[u] = src[min(e, c - 1)];
-              if (e >= c) { ea[u].x = tail_bytes; ea[u].y = tail_bytes; }
+              for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = src[u * 64 + lane];
+              uint32_t b = 0;
+              while (true) {
+                load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
+                vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, ea, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+                if (++b >= nfull) {
+#pragma unroll
+                  for (int u = 0; u < VOTE_UNROLL; u++) asm volatile("" ::"v"(eb[u].x), "v"(eb[u].y), "v"(eb[u].z), "v"(eb[u].w)); /* the re-read lands HERE, not under the next item */
+                  break;
+                }
+                load_records<VOTE_UNROLL>(ea, src, min(b + 1, nfull - 1) * B, lane);
+                vote_hits<VOTE_UNROLL, WRAP>(acc_base, vi, eb, VOTE_UNROLL, S, ohg_v, nh, asd, G2, A);
+                if (++b >= nfull) {
+#pragma unroll
+                  for (int u = 0; u < VOTE_UNROLL; u++) asm volatile("" ::"v"(ea[u].x), "v"(ea[u].y), "v"(ea[u].z), "v"(ea[u].w));
+                  break;
+                }
+              }
+              e0 = nfull * B;
             }
-            const int n_valid = (int)((c - e0 + 63) / 64);
-            issued += 128ull * (uint32_t)n_valid * (uint32_t)nh;
-            /* most buckets are smaller than a batch: only the 64-record groups that hold data get
-             * their bin arithmetic, through an instantiation per group count */
-            static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
-            switch (n_valid) {
-              case 1: vote_hits<1, WRAP>(acc_base, vi, ea, 1, S, ohg_v, nh, asd, G2, A); break;
-              case 2: vote_hits<2, WRAP>(acc_base, vi, ea, 2, S, ohg_v, nh, asd, G2, A); break;
-              case 3: vote_hits<3, WRAP>(acc_base, vi, ea, 3, S, ohg_v, nh, asd, G2, A); break;
-              default: vote_hits<4, WRAP>(acc_base, vi, ea, 4, S, ohg_v, nh, asd, G2, A); break;
+            if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
+              const uint32_t e = e0 + ((uint32_t)lane >> 1);
+              const uint4 rr = src[min(e, c - 1)];
+              const uint32_t odd = 0u - ((uint32_t)lane & 1u); /* the record's second entry */
+              const uint32_t row_bytes = e < c ? bit_select(odd, rr.x, rr.y) : tail_bytes;
+              vote_hits_single<WRAP>(acc_base, vi, row_bytes, bit_select(odd, rr.z, rr.w), S, ohg_v, nh, asd, G2, A);
+              issued += 64ull * (uint32_t)nh;
+            } else if (e0 < c) { /* tail: clamped addresses; lanes past the end vote into their guard word */
+              uint4 et[VOTE_UNROLL];
+#pragma unroll
+              for (int u = 0; u < VOTE_UNROLL; u++) {
+                const uint32_t e = e0 + u * 64 + lane;
+                if (u == 0 && e0 == 0) et[u] = rec0_reg; else et[u] = src[min(e, c - 1)];
+                if (e >= c) { et[u].x = tail_bytes; et[u].y = tail_bytes; }
+              }
+              const int n_valid = (int)((c - e0 + 63) / 64);
+              issued += 128ull * (uint32_t)n_valid * (uint32_t)nh;
+              /* most buckets are smaller than a batch: only the 64-record groups that hold data get
+               * their bin arithmetic, through an instantiation per group count */
+              static_assert(VOTE_UNROLL == 4, "tail dispatch below assumes 4 groups per batch");
+              switch (n_valid) {
+                case 1: vote_hits<1, WRAP>(acc_base, vi, et, 1, S, ohg_v, nh, asd, G2, A); break;
+                case 2: vote_hits<2, WRAP>(acc_base, vi, et, 2, S, ohg_v, nh, asd, G2, A); break;
+                case 3: vote_hits<3, WRAP>(acc_base, vi, et, 3, S, ohg_v, nh, asd, G2, A); break;
+                default: vote_hits<4, WRAP>(acc_base, vi, et, 4, S, ohg_v, nh, asd, G2, A); break;
+              }
             }
           }
         }
