@@ -179,6 +179,7 @@ typedef struct ppf_match_stats {
   uint64_t n_acc32_items;  /* (reference point, accumulator tile)s voted with 32-bit cells: those whose 16-bit cells overflowed, or all
                               of them once a workspace has seen a tenth of a call's votes cast in such ones (or with PPF_OPT_ACC32) */
   uint64_t n_tables;       /* count tables built for the runs of many hits (one per 191 hits of such a run) */
+  uint64_t phase_clocks[8]; /* zero, except in a diagnostic build of the library (-DPPF_PHASE_CLOCKS): shader clocks the voting kernel's waves spent per phase */
 } ppf_match_stats;
 
 /* totals of one ppf_batch_run */

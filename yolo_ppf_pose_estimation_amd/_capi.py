@@ -69,7 +69,16 @@ class MatchStats(C.Structure):
                 ("ms_vote_kernel", C.c_float), ("ms_pair_kernel", C.c_float), ("ms_total_device", C.c_float),
                 ("ms_group_kernel", C.c_float), ("n_hits", C.c_uint64), ("n_lds_atomics", C.c_uint64),
                 ("scratch_bytes", C.c_uint64), ("n_batches", C.c_int32), ("n_retries", C.c_int32),
-                ("n_acc32_items", C.c_uint64), ("n_tables", C.c_uint64)]
+                ("n_acc32_items", C.c_uint64), ("n_tables", C.c_uint64), ("phase_clocks", C.c_uint64 * 8)]
+
+
+def stats_dict(st):
+    """A stats structure as a plain dict (array fields as lists)."""
+    out = {}
+    for name, _ in st._fields_:
+        v = getattr(st, name)
+        out[name] = list(v) if isinstance(v, C.Array) else v
+    return out
 
 
 class BatchStats(C.Structure):

@@ -220,7 +220,7 @@ struct ppf_workspace {
   DevBuf<unsigned long long> work;
   DevBuf<uint32_t> perm;
   DevBuf<uint32_t> perm_group;
-  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[6] */
+  DevBuf<unsigned long long> counters; /* cellsum[n_ref*T] | pairs[n_ref] | totals[2] | tally[14] */
   DevBuf<ppf_vote> votes;
   DevBuf<ppf_pose> raw_poses;
   DevBuf<ppf_pose> d_final;

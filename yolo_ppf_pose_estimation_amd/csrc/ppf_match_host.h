@@ -200,7 +200,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->partial.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->half_edge.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->ovf_items.reserve((size_t)n_ref * T));
-  const size_t n_cnt = (size_t)n_ref * T + n_ref + 8; /* cellsum | pairs | totals[2] | tally[6]: LDS operations, hits, runs, 32-bit items, votes cast twice, count tables */
+  const size_t n_cnt = (size_t)n_ref * T + n_ref + 16; /* cellsum | pairs | totals[2] | tally[14]: LDS operations, hits, runs, 32-bit items, votes cast twice, count tables, 8 phase clocks (diagnostic build) */
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
   HIPCHK(ws->raw_poses.reserve(n_ref));
@@ -416,7 +416,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
   if (ws->checked || ws->n_ref == 0) { ws->checked = true; return PPF_OK; }
   for (;;) {
     const int T = ws->model->info.n_tiles;
-    unsigned long long tot[8];
+    unsigned long long tot[16];
     uint32_t ovf = 0;
     HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
@@ -433,6 +433,7 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       if (tot[3]) ws->run_frac = std::min(1.0, std::max(0.02, 1.10 * (double)tot[4] / (double)tot[3]));
       if (tot[3]) ws->tbl_frac = std::min(TBL_FRAC_MAX, std::max(1e-4, 1.15 * (double)tot[7] / (double)tot[3]));
       ws->stats.n_tables = tot[7];
+      for (int k = 0; k < 8; k++) ws->stats.phase_clocks[k] = tot[8 + k];
       ws->frac_known = true;
       if (ws->clustered) {
         uint32_t nf = 0;

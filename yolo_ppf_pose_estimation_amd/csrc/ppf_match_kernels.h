@@ -94,6 +94,20 @@
 #endif
 #define PPF_ABL_ANY (PPF_ABL_COUNTED != 1 || PPF_ABL_OWNCELL != 1 || PPF_ABL_DIRECT_SMALL != 1 || PPF_ABL_DIRECT_BIG != 1)
 
+/* Diagnostic build (-DPPF_PHASE_CLOCKS, never the product): every k_vote wave sums the shader clocks (s_memtime) it spends in
+ * each phase; ppf_match_stats.phase_clocks = the sums over all waves of the call (tools/vote_phases.py prints them).
+ * 0 staging (clear, run table, scans, barriers)  1 claim + look-up + prefetch of the next item  2 count-table items
+ * 3 direct items of more than 32 records  4 direct items of at most 32 records  5 end of segment: waiting for the other waves
+ * 6 scan, reductions, result  7 whole workgroup */
+#ifdef PPF_PHASE_CLOCKS
+#define PPF_PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); const unsigned long long ph_t0_ = ph_t_
+#define PPF_PHASE(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_t_; ph_t_ = t_; } while (0)
+#define PPF_PHASE_FLUSH(tally, lane) do { ph_[7] = __builtin_amdgcn_s_memtime() - ph_t0_; if ((lane) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&(tally)[6 + k_], ph_[k_]); } while (0)
+#else
+#define PPF_PHASE_DECL do { } while (0)
+#define PPF_PHASE(k) do { } while (0)
+#define PPF_PHASE_FLUSH(tally, lane) do { } while (0)
+#endif
 #ifndef PPF_TWO_QUEUES
 #define PPF_TWO_QUEUES 0 /* 1: k_vote claims count-table items and direct items from two queues, half of the waves preferring each (measured: +2 %, profiles/r03_vote_variants.md) */
 #endif
@@ -110,9 +124,9 @@ constexpr int VOTE_CHUNK = 64 * VOTE_UNROLL * 4; /* pair records per direct work
 constexpr int VOTE_MAX_HITS = PPF_AGG_MIN_HITS; /* hits of one run voted per direct work item: a run that votes directly on a bucket of some size has fewer,
                                                    so its records are read once (16 per item: +0.9 % on C2) */
 #ifndef PPF_AGG_CHUNK
-#define PPF_AGG_CHUNK 2048
+#define PPF_AGG_CHUNK 1024
 #endif
-constexpr int AGG_CHUNK = PPF_AGG_CHUNK; /* pair records per aggregated work item (each item copies its count table into LDS; 256 / 512 / 1024: +4 / +1 / 0 %) */
+constexpr int AGG_CHUNK = PPF_AGG_CHUNK; /* pair records per aggregated work item (each item copies its count table into LDS; 512 / 2048: +1 %) */
 constexpr int AGG_NY = 16;            /* integer parts Y + 8 of a hit */
 constexpr int AGG_SUB = 191;          /* hits per count table (counts are bytes; 3 hits per lane) */
 constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in [-8, 7] */
@@ -300,7 +314,7 @@ struct MatchArgs {
   uint32_t* edge;               /* [n_ref_all * n_tiles * 2] 32-bit cells only: pass 0: bin A of the last low-half row; pass 1: bin 0 of the first high-half row */
   unsigned long long* cellsum;  /* [n_ref_all * n_tiles] sum of the tile's accumulator == votes cast */
   unsigned long long* pairs;    /* [n_ref_all] pairs hashed */
-  unsigned long long* tally;    /* [6] LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group; (reference point, tile)s voted with 32-bit cells; votes the 16-bit launch cast for the ones it flagged; count tables handed out by k_group */
+  unsigned long long* tally;    /* [14] (8 of them: -DPPF_PHASE_CLOCKS only) LDS atomic lane-operations issued by k_vote; hits grouped, runs written by k_group; (reference point, tile)s voted with 32-bit cells; votes the 16-bit launch cast for the ones it flagged; count tables handed out by k_group */
   uint32_t* acc_dump;           /* optional [n_ref_all][n_model*num_angles] full accumulators (debug/tests) */
 };
 
@@ -1365,6 +1379,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   unsigned long long issued = 0; /* votes cast by this wave, wave-uniform: every lane slot of an item casts one vote per hit, into a cell or a guard word */
 
   const int pass = ACC32 ? (vt & 1) : 0;
+  PPF_PHASE_DECL;
   { /* clear guard + cells with 16-byte LDS stores (the region starts 16-byte aligned) */
     uint4* z = reinterpret_cast<uint4*>(lds_acc);
     for (int c = tid; c < words / 4; c += VOTE_BLOCK) z[c] = make_uint4(0u, 0u, 0u, 0u);
@@ -1383,6 +1398,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     for (uint32_t seg0 = 0; seg0 < rb.y; seg0 += RUN_SEG) {
       /* Stage a segment of the run table: this tile's record range of every run and its work items, exclusive scan */
       __syncthreads(); /* previous segment fully consumed (and the accumulator clear, first time) */
+      PPF_PHASE(seg0 ? 5 : 0);
       const uint32_t n_seg = min((uint32_t)RUN_SEG, rb.y - seg0);
       uint32_t items = 0;
       bool heavy_run = false; /* a run k_group filed under "many hits": those come first in every round's run list */
@@ -1448,6 +1464,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       if (tid == 0) red[48] = VOTE_WAVES; /* next unclaimed work item (each wave starts with item == its id) */
 #endif
       __syncthreads();
+      PPF_PHASE(0);
 
       /* Work items are claimed from an LDS counter as waves become free (items differ by orders of magnitude in
        * size); a wave's items still come in increasing order, so the owning run is found with a 64-wide look-ahead
@@ -1514,6 +1531,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 #if PPF_PREFETCH < 2
         vote_fetch_records(cur, lane);
 #endif
+        PPF_PHASE(1);
         if (cur.agg) {
           /* ---- count-table item: <= AGG_SUB hits x <= AGG_CHUNK records ---- */
           const uint32_t c = cur.c;
@@ -1550,6 +1568,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           }
           ops += 2u * (AGG_NY + 1) * 64u * ((c + 63u) / 64u);
           issued += 128ull * ((c + 63u) / 64u) * (uint32_t)cur.nh; /* counted + one-by-one votes of an entry = its hits */
+          PPF_PHASE(2);
         } else {
           /* ---- direct item: <= VOTE_MAX_HITS hits x <= VOTE_CHUNK records ---- */
           const uint32_t c = cur.c;
@@ -1649,6 +1668,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
               }
             }
           }
+          PPF_PHASE(c <= 32 ? 4 : 3);
         }
         cur = nxt;
         have = have_next;
@@ -1656,6 +1676,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     }
   }
   __syncthreads();
+  PPF_PHASE(5);
 
   /* Scan in the reference's order (model ref ascending, alpha bin ascending, strict >) == smallest
    * upstream flat index ref*A + bin among the maxima.  Also the exact vote total of the tile.  One thread per accumulator
@@ -1742,6 +1763,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   for (int o = 32; o > 0; o >>= 1) wops += __shfl_down(wops, o);
   wops += ops;
   if (lane == 0 && wops) atomicAdd(&a.tally[0], wops);
+  PPF_PHASE(6);
+  PPF_PHASE_FLUSH(a.tally, lane);
   if (!ACC32) break;
   wid += gridDim.x;
   if (wid < n_work) __syncthreads(); /* the next unit clears the accumulator this one's last readers are done with */

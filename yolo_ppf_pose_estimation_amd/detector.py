@@ -284,7 +284,7 @@ class PPF3DDetector:
         nr = n.value
         triples = np.array([[votes[i].ref_ind_max, votes[i].alpha_ind_max, votes[i].max_votes] for i in range(nr)],
                            dtype=np.uint32).reshape(nr, 3)
-        self.last_stats = {k: getattr(st, k) for k, _ in MatchStats._fields_}
+        self.last_stats = _capi.stats_dict(st)
         return {"n_ref": nr, "triples": triples, "raw_poses": [Pose3D(poses[i]) for i in range(nr)],
                 "stats": self.last_stats}
 

@@ -10,6 +10,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import _capi
 from ._capi import BatchStats, MatchStats, Pose, Vote, check, lib
 from .detector import Pose3D, PPF3DDetector
 
@@ -59,7 +60,7 @@ class Workspace:
         tri = np.frombuffer(votes, dtype=np.uint32)[: 3 * nr].reshape(nr, 3).copy()
         return {"n_ref": nr, "triples": tri, "raw_poses": [Pose3D(raw[i]) for i in range(nr)],
                 "poses": [Pose3D(fin[i]) for i in range(n_pose.value)] if want_poses else [],
-                "stats": {k: getattr(st, k) for k, _ in MatchStats._fields_}}
+                "stats": _capi.stats_dict(st)}
 
     def top_poses(self, k: int):
         """Wait for the call and fetch only the clustered poses (as a ctypes array of ppf_pose records, at most
@@ -70,14 +71,14 @@ class Workspace:
         st = MatchStats()
         check(lib().ppf_workspace_results(self.ptr, None, None, 0, None, self._fin, self._cap_hint, C.byref(n_pose),
                                           C.byref(st)))
-        return self._fin, min(n_pose.value, k), n_pose.value, {f: getattr(st, f) for f, _ in MatchStats._fields_}
+        return self._fin, min(n_pose.value, k), n_pose.value, _capi.stats_dict(st)
 
     _cap_hint = 65536
 
     def stats(self) -> dict:
         st = MatchStats()
         check(lib().ppf_workspace_results(self.ptr, None, None, 0, None, None, 0, None, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in MatchStats._fields_}
+        return _capi.stats_dict(st)
 
     def ref_counters(self, cap: int):
         v = np.zeros(cap, dtype=np.uint64)
