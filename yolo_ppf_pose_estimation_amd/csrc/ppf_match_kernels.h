@@ -216,15 +216,17 @@ __device__ __forceinline__ void pair_key(const ppf_vec3& p1, const ppf_vec3& n1,
   /* |d| and 1/|d| from one v_rsq_f64 and two Newton steps (a few ulp: far inside the guards below) instead of the
    * correctly rounded sqrt + a reciprocal; |d| = 0, denormal or huge makes r infinite or NaN and sends the lane to the
    * exact chain through the checks on f3 and q3 */
-  const double d2 = dx * dx + dy * dy + dz * dz;
+  /* fused multiply-adds here (the build has -ffp-contract=off for the exact chain's sake): this path only estimates, a
+   * rounding more or less is far inside its guards, and it is 10 fp64 instructions of 115 fewer per pair */
+  const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
   const double hd = 0.5 * d2;
   double rinv = __builtin_amdgcn_rsq(d2);
-  rinv = rinv * (1.5 - hd * rinv * rinv);
-  rinv = rinv * (1.5 - hd * rinv * rinv);
+  rinv = rinv * __builtin_fma(-(hd * rinv), rinv, 1.5);
+  rinv = rinv * __builtin_fma(-(hd * rinv), rinv, 1.5);
   const double f3 = d2 * rinv;
-  const double x0 = (n1.x * dx + n1.y * dy + n1.z * dz) * rinv;
-  const double x1 = (n2.x * dx + n2.y * dy + n2.z * dz) * rinv;
-  const double x2 = ppf_dot3(n1, n2); /* same expression as the exact path: bit-identical */
+  const double x0 = __builtin_fma(n1.z, dz, __builtin_fma(n1.y, dy, n1.x * dx)) * rinv;
+  const double x1 = __builtin_fma(n2.z, dz, __builtin_fma(n2.y, dy, n2.x * dx)) * rinv;
+  const double x2 = __builtin_fma(n1.z, n2.z, __builtin_fma(n1.y, n2.y, n1.x * n2.x));
   bool slow = !(f3 > 2.0 * PPF_EPS) || !(ppf_fabs(x0) <= 1.0 - 1e-12) || !(ppf_fabs(x1) <= 1.0 - 1e-12) || !(ppf_fabs(x2) <= 1.0);
   {
     const float q0 = acos32_estimate(x0) * fk.rstep32, q1 = acos32_estimate(x1) * fk.rstep32,
@@ -506,6 +508,8 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
   const int r = a.perm_group ? (int)a.perm_group[blockIdx.x] : (int)blockIdx.x; /* most hits first: no long block at the tail */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t* cpre = gcnt + ((a.round_buckets + 1) & ~1);                     /* pair_chunks + 1 (even offsets: the doubles behind stay 8-byte aligned) */
+  uint32_t* cbase = cpre + ((a.pair_chunks + 2) & ~1);                      /* pair_chunks: where each piece starts in the raw pool (a copy of desc[].x: the
+                                                                               walk below would otherwise wait for a global read before every pool read) */
   const uint32_t n_raw = (uint32_t)a.hit_count[r];
   const uint2* __restrict__ desc = a.chunk_desc + (size_t)r * a.pair_chunks;
   if (tid == 0) {
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
         const uint32_t y = __shfl_up(incl, o);
         if (lane >= o) incl += y;
       }
-      if (c < a.pair_chunks) cpre[c] = run + incl - v;
+      if (c < a.pair_chunks) { cpre[c] = run + incl - v; cbase[c] = desc[c].x; }
       run += __shfl(incl, 63);
     }
     if (lane == 0) cpre[a.pair_chunks] = run;
@@ -558,19 +562,19 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
           const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
-          key[u] = make_uint2(0xFFFFFFFFu, 0u);
-          at[u] = 0u;
-          if (g < n_list) {
-            while (g >= cpre[c + 1]) c++;
-            at[u] = desc[c].x + (g - cpre[c]);
-            key[u] = a.raw[at[u]];
-          }
+          /* unconditional reads at a clamped position (n_list > 0 here): the GROUP_MLP pool reads go out back to back, where
+           * reads under `if (g < n_list)` were each waited for before the next one was issued */
+          const uint32_t gc = min(g, n_list - 1u);
+          while (gc >= cpre[c + 1]) c++;
+          at[u] = cbase[c] + (gc - cpre[c]);
+          key[u] = a.raw[at[u]];
+          if (g >= n_list) key[u].x = 0xFFFFFFFFu;
         }
         ppf_vec3 p2[GROUP_MLP];
         bool in[GROUP_MLP];
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
-          in[u] = key[u].x - b0 < nb; /* retired hits (0xFFFFFFFF) and other rounds' buckets fall out here */
+          in[u] = key[u].x - b0 < nb; /* retired hits (0xFFFFFFFF), the clamped repeats and other rounds' buckets fall out here */
           p2[u] = ppf_mk3(0.0, 0.0, 0.0);
           if (in[u] && check_alpha) p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
         }
@@ -663,11 +667,10 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
 #pragma unroll
         for (int u = 0; u < GROUP_MLP; u++) {
           const uint32_t g = g0 + (uint32_t)u * GROUP_BLOCK;
-          key[u] = make_uint2(0xFFFFFFFFu, 0u);
-          if (g < n_list) {
-            while (g >= cpre[c + 1]) c++;
-            key[u] = a.raw[desc[c].x + (g - cpre[c])];
-          }
+          const uint32_t gc = min(g, n_list - 1u);
+          while (gc >= cpre[c + 1]) c++;
+          key[u] = a.raw[cbase[c] + (gc - cpre[c])];
+          if (g >= n_list) key[u].x = 0xFFFFFFFFu;
         }
         double as[GROUP_MLP];
         ppf_vec3 p2[GROUP_MLP];
@@ -676,8 +679,7 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
         for (int u = 0; u < GROUP_MLP; u++) {
           in[u] = key[u].x - b0 < nb;
           as[u] = 0.0;
-          p2[u] = ppf_mk3(0.0, 0.0, 0.0);
-          if (in[u]) p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y);
+          p2[u] = ld3(a.paired.x, a.paired.y, a.paired.z, (int)key[u].y); /* every hit names a paired point: read all, use those of this round */
         }
         uint32_t gi[GROUP_MLP];
 #pragma unroll
