@@ -38,13 +38,14 @@ def main():
         ws.match_device(det, d.data_ptr(), scene.shape[0], 6, W.SCENE_STEP, W.REL_DISTANCE, presampled=True)
         st = ws.results(scene.shape[0])["stats"]
     ph = st["phase_clocks"]
-    tot = float(ph[7]) or 1.0
-    out = {"config": cfg, "k_vote_ms": st["ms_vote_kernel"], "phase_clocks": ph,
+    tot = float(sum(ph[:7])) or 1.0
+    resident = ph[7] / 100e6 / (16 * 256 * st["ms_vote_kernel"] * 1e-3)  # phase 7 is in 100 MHz ticks, summed over 16 waves per workgroup
+    out = {"config": cfg, "k_vote_ms": st["ms_vote_kernel"], "phase_clocks": ph, "cu_time_with_a_workgroup_resident": resident,
            "shares": {NAMES[k]: ph[k] / tot for k in range(7)}}
     print(json.dumps(out))
     for k in range(7):
         print("%5.1f %%  %s" % (100.0 * ph[k] / tot, NAMES[k]), file=sys.stderr)
-    print("k_vote %.3f ms; accounted %.1f %%" % (st["ms_vote_kernel"], 100.0 * sum(ph[:7]) / tot), file=sys.stderr)
+    print("k_vote %.3f ms; a workgroup was resident for %.1f %% of the CUs' time" % (st["ms_vote_kernel"], 100.0 * resident), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -98,15 +98,30 @@
  * each phase; ppf_match_stats.phase_clocks = the sums over all waves of the call (tools/vote_phases.py prints them).
  * 0 staging (clear, run table, scans, barriers)  1 claim + look-up + prefetch of the next item  2 count-table items
  * 3 direct items of more than 32 records  4 direct items of at most 32 records  5 end of segment: waiting for the other waves
- * 6 scan, reductions, result  7 whole workgroup */
+ * 6 scan, reductions, result  7 whole workgroup, in ticks of the constant 100 MHz clock (s_memrealtime): summed over the waves
+ * and divided by 16 waves x 256 CUs x the kernel's time it is the share of the CUs' time a workgroup was resident.
+ * -DPPF_PHASE_CLOCKS=2 records only that one. */
 #ifdef PPF_PHASE_CLOCKS
-#define PPF_PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); const unsigned long long ph_t0_ = ph_t_
+#define PPF_PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); const unsigned long long ph_rt0_ = __builtin_amdgcn_s_memrealtime()
+#if PPF_PHASE_CLOCKS == 2 /* only phase 7, the workgroup's wall time: the stamps of the other phases slow the kernel by a third */
+#define PPF_PHASE(k) do { } while (0)
+#else
 #define PPF_PHASE(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_t_; ph_t_ = t_; } while (0)
-#define PPF_PHASE_FLUSH(tally, lane) do { ph_[7] = __builtin_amdgcn_s_memtime() - ph_t0_; if ((lane) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&(tally)[6 + k_], ph_[k_]); } while (0)
+#endif
+#define PPF_PHASE_FLUSH(tally, lane) do { ph_[7] = __builtin_amdgcn_s_memrealtime() - ph_rt0_; (void)ph_t_; if ((lane) == 0) for (int k_ = (PPF_PHASE_CLOCKS == 2 ? 7 : 0); k_ < 8; k_++) atomicAdd(&(tally)[6 + k_], ph_[k_]); } while (0)
 #else
 #define PPF_PHASE_DECL do { } while (0)
 #define PPF_PHASE(k) do { } while (0)
 #define PPF_PHASE_FLUSH(tally, lane) do { } while (0)
+#endif
+#ifndef PPF_COST_TABLE
+#define PPF_COST_TABLE 16   /* k_vote's launch order: what one count table costs a pair record, in direct hits */
+#endif
+#ifndef PPF_COST_MIN_HITS
+#define PPF_COST_MIN_HITS 8 /* ... and the least a direct run costs it (loading and unpacking the record) */
+#endif
+#ifndef PPF_COST_ITEM
+#define PPF_COST_ITEM 512     /* ... and a run's fixed cost (claim, look-up, first loads), in record-hits */
 #endif
 #ifndef PPF_TWO_QUEUES
 #define PPF_TWO_QUEUES 0 /* 1: k_vote claims count-table items and direct items from two queues, half of the waves preferring each (measured: +2 %, profiles/r03_vote_variants.md) */
@@ -654,7 +669,9 @@ __global__ __launch_bounds__(GROUP_BLOCK) void k_group(MatchArgs a) {
             for (uint32_t h0 = 0; h0 < c; h0 += AGG_SUB, tt++)
               if (okr) a.table_desc[tt] = make_uint2(hit_base + placed + pos + h0, min((uint32_t)AGG_SUB, c - h0));
           }
-          w += (unsigned long long)c * a.bucket_total[b0 + k]; /* votes this run will cast (the launch order of k_vote) */
+          /* what this run will cost k_vote (its launch order: longest first), in direct votes: a run that votes through count
+           * tables pays per table what PPF_AGG_MIN_HITS direct hits would, whatever its hits */
+          w += (unsigned long long)(many ? ((c + AGG_SUB - 1) / AGG_SUB) * (uint32_t)PPF_COST_TABLE : max(c, (uint32_t)PPF_COST_MIN_HITS)) * a.bucket_total[b0 + k] + (uint32_t)PPF_COST_ITEM;
         }
         pos += c;
       }
