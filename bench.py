@@ -27,7 +27,7 @@ The ONE line printed by rank 0 carries
   value          whole-job pair-matches (accumulator increments the reference would make, exact integer) per second
   roofline       the voting kernel against HBM: measured fabric traffic per step (committed PMC pass of THIS source
                  tree: the pass records a hash of the kernel sources and its own kernel time; another tree or a kernel time
-                 more than 5 % away makes traffic_stale true and frac null) / its device time in this run (HIP events on
+                 more than 20 % away makes traffic_stale true and frac null; the ratio is reported as time_vs_collection) / its device time in this run (HIP events on
                  the launch stream); the SURVEY section 8d figure stays beside it as algorithmic_bytes_per_launch
   issue_roofline / lds_roofline   what actually bounds k_vote: LDS wave-instructions and atomic lane-operations per second
   host_entry     (N = 1, c2) the call the reference really makes: ppf_match from HOST memory, upload and read-back
@@ -55,7 +55,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 LDS_ATOMIC_PEAK_UBENCH = 8.97e12  # profiles/r01_ubench_valu_lds.txt: ds_add_u32 14.6 lanes/clk/CU x 256 CUs x 2.4 GHz
 LDS_ATOMIC_PEAK_GUIDE = 9.83e12   # MI355X_MICROARCH.md LDS section: 16 lanes/clk/CU x 256 x 2.4 GHz
 LDS_INSTR_PEAK = 256 * 2.4e9 / 4.38  # ds_add_u32: one 64-lane wave-instruction per 4.38 cycles per CU (r01 / r02 ubench)
-STALE_KERNEL_TIME = 0.05  # a PMC pass whose own k_vote time differs by more than this from the run's is not this kernel
+STALE_KERNEL_TIME = 0.20  # boxes of the pool run the same binary up to 11 % apart (k_vote 3.81 and 4.21 ms minutes apart, round 3): the source
+# hash is what ties a counter pass to the kernel; the time check only catches a pass that cannot be about this kernel at all
 
 
 def parse_args(argv=None):
@@ -190,7 +191,7 @@ def committed_counters(workload, n_votes_per_step):
 
 def counter_rooflines(workload, n_votes_per_step, k_vote_ms, abytes, atomics_per_step, src_hash):
     """roofline / issue_roofline / lds_roofline of k_vote from the committed counter pass of this workload, refused when the
-    pass does not describe the kernel that just ran (other source tree, or a kernel time more than 5 % away)."""
+    pass does not describe the kernel that just ran (other source tree, or a kernel time more than 20 % away: boxes of the pool differ by up to 11 % on one binary)."""
     pmc = committed_counters(workload, n_votes_per_step)
     k_vote_s = k_vote_ms * 1e-3
     stale, why = False, None
@@ -210,6 +211,7 @@ def counter_rooflines(workload, n_votes_per_step, k_vote_ms, abytes, atomics_per
         "frac": achieved / HBM_PEAK_GBS if achieved else None,
         "traffic": traffic, "traffic_source": pmc["file"] if pmc else None,
         "traffic_stale": stale, "traffic_stale_reason": why,
+        "time_vs_collection": (k_vote_ms / pmc["k_vote_ms_per_step_at_collection"]) if pmc and pmc.get("k_vote_ms_per_step_at_collection") else None,
         "avg_kernel_ms": k_vote_ms,
         "algorithmic_bytes_per_launch": abytes,
         "note": "achieved = measured fabric bytes of k_vote per step (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC pass, "
