@@ -387,19 +387,23 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   const int n = a.paired.n;
   /* the point of the next iteration is fetched while the current pair is hashed */
   float nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0, nx4 = 0, nx5 = 0;
+  /* a 32-bit BYTE offset next to the scalar base pointer: the load takes it as is (global_load ... v_off, s[base]); with an
+   * index the compiler forms a 64-bit address per array and load (it cannot know that 4 * index stays below 2^32): 7 VALU
+   * instructions of address arithmetic per point */
+  auto ldf = [](const float* __restrict__ base, const uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
   {
-    const uint32_t jc = (uint32_t)min(j0, n - 1); /* unsigned index: scalar base + 32-bit lane offset, no 64-bit address arithmetic */
-    nx0 = a.paired.x[jc]; nx1 = a.paired.y[jc]; nx2 = a.paired.z[jc];
-    nx3 = a.paired.nx[jc]; nx4 = a.paired.ny[jc]; nx5 = a.paired.nz[jc];
+    const uint32_t jc = (uint32_t)min(j0, n - 1) * 4u;
+    nx0 = ldf(a.paired.x, jc); nx1 = ldf(a.paired.y, jc); nx2 = ldf(a.paired.z, jc);
+    nx3 = ldf(a.paired.nx, jc); nx4 = ldf(a.paired.ny, jc); nx5 = ldf(a.paired.nz, jc);
   }
 #pragma unroll 2
   for (int it = 0; it < PAIRS_PER_THREAD; it++) {
     const int j = j0 + it * PAIR_BLOCK;
     const ppf_vec3 p2 = ppf_mk3((double)nx0, (double)nx1, (double)nx2), n2 = ppf_mk3((double)nx3, (double)nx4, (double)nx5);
     {
-      const uint32_t jn = (uint32_t)min(j + PAIR_BLOCK, n - 1);
-      nx0 = a.paired.x[jn]; nx1 = a.paired.y[jn]; nx2 = a.paired.z[jn];
-      nx3 = a.paired.nx[jn]; nx4 = a.paired.ny[jn]; nx5 = a.paired.nz[jn];
+      const uint32_t jn = (uint32_t)min(j + PAIR_BLOCK, n - 1) * 4u;
+      nx0 = ldf(a.paired.x, jn); nx1 = ldf(a.paired.y, jn); nx2 = ldf(a.paired.z, jn);
+      nx3 = ldf(a.paired.nx, jn); nx4 = ldf(a.paired.ny, jn); nx5 = ldf(a.paired.nz, jn);
     }
     if (j < n && (S2B || j != i_ref)) {
       /* match_S2B: the reference point itself is never paired, even when the edge cloud contains it
@@ -805,10 +809,15 @@ __device__ __forceinline__ int vote_bin_exact(const float am, const double as, c
   else return vote_bin_exact_4pi(am, as, A);
 }
 
+/* record `idx` behind a wave-uniform pointer: the index goes in as a 32-bit byte offset next to the scalar base (an item has at
+ * most a few thousand records), not as a 64-bit address formed per load */
+__device__ __forceinline__ uint4 rec_at(const uint4* __restrict__ base, const uint32_t idx) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + idx * 16u);
+}
 template <int U>
 __device__ __forceinline__ void load_records(uint4* rec, const uint4* __restrict__ src, const uint32_t e0, const int lane) {
 #pragma unroll
-  for (int u = 0; u < U; u++) rec[u] = src[e0 + u * 64 + lane];
+  for (int u = 0; u < U; u++) rec[u] = rec_at(src, e0 + (uint32_t)(u * 64 + lane));
 }
 
 /* the bins of 2U votes against one hit; frmin = smallest fractional part (guard-band check) */
@@ -1134,6 +1143,10 @@ __device__ __forceinline__ uint4 gl_ld4(const uint32_t* __restrict__ p) {
   const gl_quad_t q = *reinterpret_cast<const gl_quad_t*>(p);
   return make_uint4(q.x, q.y, q.z, q.w);
 }
+/* ... word `w` behind a wave-uniform base, as a 32-bit byte offset */
+__device__ __forceinline__ uint4 gl_ld4_at(const uint32_t* __restrict__ base, const uint32_t w) {
+  return gl_ld4(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + w * 4u));
+}
 
 /* one own-cell vote of each entry of a pair record (hit k of the entries' cells), guard band and exact fallback included */
 __device__ __forceinline__ void agg_own_vote(const AggConsts& k, const uint32_t rz, const uint32_t rw, const float am_a, const float am_b,
@@ -1169,8 +1182,8 @@ __device__ __forceinline__ void agg_own_fetch(const AggConsts& k, const uint4 re
   if (qb == AGG_Q) { o.cb.x = 0u; o.cb.y = (uint32_t)ms; }
 #if PPF_ABL_OWNCELL
   const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
-  o.oa = gl_ld4(toff + o.ca.x);
-  o.ob = gl_ld4(toff + o.cb.x);
+  o.oa = gl_ld4_at(toff, o.ca.x);
+  o.ob = gl_ld4_at(toff, o.cb.x);
 #else
   (void)tbl;
 #endif
@@ -1233,7 +1246,7 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
              * are done re-read their last words */
             const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
             for (uint32_t done = 4u;;) {
-              const uint4 oa = gl_ld4(toff + min(ca.x + done, (uint32_t)AGG_SUB)), ob = gl_ld4(toff + min(cb.x + done, (uint32_t)AGG_SUB));
+              const uint4 oa = gl_ld4_at(toff, min(ca.x + done, (uint32_t)AGG_SUB)), ob = gl_ld4_at(toff, min(cb.x + done, (uint32_t)AGG_SUB));
               PPF_OWN_VOTE(oa.x, ob.x, done + 0u);
               if (!__any((done + 1u < na) | (done + 1u < nb))) break;
               PPF_OWN_VOTE(oa.y, ob.y, done + 1u);
@@ -1273,7 +1286,7 @@ __device__ __forceinline__ void vote_fetch_hits(VoteItem& it, const int lane, co
 }
 __device__ __forceinline__ void vote_fetch_records(VoteItem& it, const int lane) {
   const uint32_t idx = (!it.agg && it.c <= 32) ? ((uint32_t)lane >> 1) : (uint32_t)lane;
-  it.rec0 = it.src[min(idx, it.c - 1)];
+  it.rec0 = rec_at(it.src, min(idx, it.c - 1));
 }
 static_assert(AGG_SCRATCH / 16 <= 128, "the table copy gives a lane two 16-byte pieces");
 
@@ -1520,8 +1533,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         uint4 tbl0 = make_uint4(0u, 0u, 0u, 0u), tbl1 = tbl0;
         if (cur.agg) {
           const uint4* __restrict__ t = reinterpret_cast<const uint4*>(cur.tbl);
-          tbl0 = t[min(lane, AGG_SCRATCH / 16 - 1)];
-          tbl1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
+          tbl0 = rec_at(t, (uint32_t)min(lane, AGG_SCRATCH / 16 - 1));
+          tbl1 = rec_at(t, (uint32_t)min(lane + 64, AGG_SCRATCH / 16 - 1));
         }
         const bool have_next = claim(item, q_item);
         if (have_next) vote_locate(nxt, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
@@ -1537,8 +1550,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         uint4 tbl0 = make_uint4(0u, 0u, 0u, 0u), tbl1 = tbl0;
         if (cur.agg) {
           const uint4* __restrict__ t = reinterpret_cast<const uint4*>(cur.tbl);
-          tbl0 = t[min(lane, AGG_SCRATCH / 16 - 1)];
-          tbl1 = t[min(lane + 64, AGG_SCRATCH / 16 - 1)];
+          tbl0 = rec_at(t, (uint32_t)min(lane, AGG_SCRATCH / 16 - 1));
+          tbl1 = rec_at(t, (uint32_t)min(lane + 64, AGG_SCRATCH / 16 - 1));
         }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u));
         const bool have_next = item < total;
@@ -1572,10 +1585,10 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
            * its own iteration */
           AggOwn own_cur;
           agg_own_fetch(ak, rec_cur, tbl, cur.nh, own_cur);
-          uint4 rec_n1 = src[min((uint32_t)lane + 64u, c - 1)];
+          uint4 rec_n1 = rec_at(src, min((uint32_t)lane + 64u, c - 1));
           for (uint32_t e0 = 0; e0 < c; e0 += 64) {
             const uint32_t e = e0 + (uint32_t)lane;
-            const uint4 rec_n2 = src[min(e + 128, c - 1)];
+            const uint4 rec_n2 = rec_at(src, min(e + 128, c - 1));
             AggOwn own_n1;
             agg_own_fetch(ak, rec_n1, tbl, cur.nh, own_n1);
             uint4 rec = rec_cur;
@@ -1639,7 +1652,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
               uint4 ea[VOTE_UNROLL], eb[VOTE_UNROLL];
               ea[0] = rec0_reg;
 #pragma unroll
-              for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = src[u * 64 + lane];
+              for (int u = 1; u < VOTE_UNROLL; u++) ea[u] = rec_at(src, (uint32_t)(u * 64 + lane));
               uint32_t b = 0;
               while (true) {
                 load_records<VOTE_UNROLL>(eb, src, min(b + 1, nfull - 1) * B, lane);
@@ -1661,7 +1674,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             }
             if (e0 < c && c - e0 <= 32) { /* at most 64 entries left: one entry per lane */
               const uint32_t e = e0 + ((uint32_t)lane >> 1);
-              const uint4 rr = src[min(e, c - 1)];
+              const uint4 rr = rec_at(src, min(e, c - 1));
               const uint32_t odd = 0u - ((uint32_t)lane & 1u); /* the record's second entry */
               const uint32_t row_bytes = e < c ? bit_select(odd, rr.x, rr.y) : tail_bytes;
               vote_hits_single<WRAP>(acc_base, vi, row_bytes, bit_select(odd, rr.z, rr.w), S, ohg_v, nh, asd, G2, A);
@@ -1671,7 +1684,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 #pragma unroll
               for (int u = 0; u < VOTE_UNROLL; u++) {
                 const uint32_t e = e0 + u * 64 + lane;
-                if (u == 0 && e0 == 0) et[u] = rec0_reg; else et[u] = src[min(e, c - 1)];
+                if (u == 0 && e0 == 0) et[u] = rec0_reg; else et[u] = rec_at(src, min(e, c - 1));
                 if (e >= c) { et[u].x = tail_bytes; et[u].y = tail_bytes; }
               }
               const int n_valid = (int)((c - e0 + 63) / 64);

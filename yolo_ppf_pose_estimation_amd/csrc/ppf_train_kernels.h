@@ -44,8 +44,13 @@ __global__ void k_aos_to_soa(const float* __restrict__ src, int n, int stride, i
   }
 }
 
+/* row i of three arrays of a cloud.  The index goes in as a 32-bit BYTE offset next to each (scalar) base pointer, which a
+ * global load takes as it is; from `a[i]` the compiler builds a 64-bit address per array (clouds have far fewer than 2^30 rows) */
 __device__ __forceinline__ ppf_vec3 ld3(const float* a, const float* b, const float* c, int i) {
-  return ppf_mk3((double)a[i], (double)b[i], (double)c[i]);
+  const uint32_t o = (uint32_t)i * 4u;
+  return ppf_mk3((double)*reinterpret_cast<const float*>(reinterpret_cast<const char*>(a) + o),
+                 (double)*reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + o),
+                 (double)*reinterpret_cast<const float*>(reinterpret_cast<const char*>(c) + o));
 }
 
 /* ---- training: one workgroup per model reference point i, threads sweep j (row A5-train) ---- */
