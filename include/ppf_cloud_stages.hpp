@@ -34,7 +34,10 @@ class Cloud {
     return Cloud(c);
   }
   static Cloud fromXYZ(const float* xyz, int n, int strideFloats = 3) { return fromRows(xyz, n, strideFloats, 3); }
-  template <class M> static Cloud fromMat(const M& m) { return fromRows(m.template ptr<float>(0), m.rows, m.cols, m.cols >= 6 ? 6 : 3); }
+  /* an N x 3 or N x 6 float32 Mat (cv::Mat when OpenCV is present: rows read through step1()) */
+  static Cloud fromMat(const ppf_match_3d::Mat& m) {
+    return fromRows(m.ptr<float>(0), m.rows, ppf_match_3d::detail::stride_of(m), m.cols >= 6 ? 6 : 3);
+  }
 
   bool empty() const { return size() == 0; }
   int size() const {
@@ -67,7 +70,7 @@ class Cloud {
     ppf_match_3d::check(ppf_prep_to_mat(need(), &o));
     Cloud tmp(o);
     const int n = tmp.size();
-    ppf_match_3d::Mat m(n, 6);
+    ppf_match_3d::Mat m = ppf_match_3d::detail::new_cloud(n, 6);
     if (n) ppf_match_3d::check(ppf_cloud_download(tmp.handle(), m.ptr<float>(0), nullptr, n));
     return m;
   }

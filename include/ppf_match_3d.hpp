@@ -12,9 +12,15 @@
  *     Pose3D (.pose, printPose), Pose3DPtr             src:122-125
  *     loadPLYSimple / transformPCPose / writePLY       src:114,125,127
  *
- * It compiles WITHOUT OpenCV: clouds are ppf_match_3d::Mat (rows x cols float32, row-major, the
- * layout of the N x 6 CV_32FC1 Mat the reference builds at CloudProcessing.h:163-190).  When
- * <opencv2/core.hpp> is available the same calls also take cv::Mat (zero-copy).
+ * With <opencv2/core.hpp> available (the reference's situation) the facade introduces NO second matrix type:
+ * ppf_match_3d::Mat, Matx44d, Vec3d, Vec4d ARE cv::Mat, cv::Matx44d, cv::Vec3d, cv::Vec4d (using-declarations) and
+ * Pose3DPtr is cv::Ptr<Pose3D>, so the reference's file-scope `using namespace cv; using namespace ppf_match_3d;`
+ * (Camera.h:10, CloudProcessing.h:28-29) and its unqualified `Mat` (clouds AND images) stay unambiguous and
+ * loadPLYSimple / transformPCPose / writePLY / samplePCByQuantization take and return cv::Mat (N x 6 or N x 3 CV_32FC1,
+ * rows read through step1()).  -DPPF_MATCH_3D_AS_CV additionally makes the namespace visible as cv::ppf_match_3d, the
+ * name the reference spells (tests/cpp/reference_call_shapes.cpp compiles both ways, C++11, -Werror).
+ * WITHOUT OpenCV (this build container) the same names are small stand-alone types with the same members
+ * (rows / cols / ptr<float>(i) / at<float>(i, j) / empty / clone; val[16] / operator()(i, j) / eye()).
  *
  * Failures of the C-ABI become exceptions (ppf_match_3d::Error carries the status and the
  * library's message), which is how CV_Error / CV_Assert surface in the reference's library.
@@ -64,18 +70,14 @@ inline void check(ppf_status st) {
   throw Error(st, buf);
 }
 
-namespace detail {
-/* row pitch in floats: cols for the facade's own Mat; step1() (and a CV_32FC1 check) for cv::Mat, so that a
- * non-continuous view (a column range, a row stride) is read correctly and a double Mat is refused */
-template <class M> inline int stride_of(const M& m) { return m.cols; }
 #ifdef PPF_MATCH_3D_HAVE_OPENCV
-inline int stride_of(const cv::Mat& m) {
-  if (m.depth() != CV_32F || m.channels() != 1) throw Error(PPF_ERR_INVALID, "expected a CV_32FC1 cloud (N x 6 float32)");
-  return (int)m.step1();
-}
-#endif
-}  // namespace detail
-
+/* the reference's types themselves: a using-declaration names the same entity, so `using namespace cv;` next to
+ * `using namespace ppf_match_3d;` never makes `Mat` ambiguous */
+using cv::Mat;
+using cv::Matx44d;
+using cv::Vec3d;
+using cv::Vec4d;
+#else
 /* Minimal float32 matrix with the accessors the reference uses on cv::Mat for point clouds. */
 class Mat {
  public:
@@ -84,45 +86,91 @@ class Mat {
   Mat(int r, int c, const float* src) : rows(r), cols(c), data_(new std::vector<float>(src, src + (size_t)r * c)) {}
   int rows, cols;
   bool empty() const { return rows == 0 || !data_; }
-  template <class T = float> T* ptr(int i = 0) { return reinterpret_cast<T*>(data_->data() + (size_t)i * cols); }
-  template <class T = float> const T* ptr(int i = 0) const { return reinterpret_cast<const T*>(data_->data() + (size_t)i * cols); }
-  float& at(int i, int j) { return (*data_)[(size_t)i * cols + j]; }
-  float at(int i, int j) const { return (*data_)[(size_t)i * cols + j]; }
+  template <class T> T* ptr(int i = 0) { return reinterpret_cast<T*>(data_->data() + (size_t)i * cols); }
+  template <class T> const T* ptr(int i = 0) const { return reinterpret_cast<const T*>(data_->data() + (size_t)i * cols); }
+  template <class T> T& at(int i, int j) { return reinterpret_cast<T*>(data_->data() + (size_t)i * cols)[j]; }
+  template <class T> const T& at(int i, int j) const { return reinterpret_cast<const T*>(data_->data() + (size_t)i * cols)[j]; }
   Mat clone() const { return empty() ? Mat() : Mat(rows, cols, data_->data()); }
 
  private:
   std::shared_ptr<std::vector<float>> data_;
 };
 
-typedef std::array<double, 16> Matx44d; /* row-major 4x4 */
+/* row-major fixed-size matrices with cv::Matx's members: val[], operator()(i, j), eye(), == */
+template <int M, int N> struct MatxD {
+  double val[M * N];
+  MatxD() { for (int k = 0; k < M * N; k++) val[k] = 0; }
+  static MatxD eye() { MatxD m; for (int k = 0; k < (M < N ? M : N); k++) m.val[k * N + k] = 1; return m; }
+  double& operator()(int i, int j) { return val[i * N + j]; }
+  const double& operator()(int i, int j) const { return val[i * N + j]; }
+  double& operator[](int i) { return val[i]; } /* cv::Vec */
+  const double& operator[](int i) const { return val[i]; }
+  bool operator==(const MatxD& o) const { for (int k = 0; k < M * N; k++) if (val[k] != o.val[k]) return false; return true; }
+  bool operator!=(const MatxD& o) const { return !(*this == o); }
+};
+typedef MatxD<4, 4> Matx44d;
+typedef MatxD<3, 1> Vec3d;
+typedef MatxD<4, 1> Vec4d;
+#endif
 
-/* cv::ppf_match_3d::Pose3D */
+namespace detail {
+/* row pitch in floats: cols for the stand-alone Mat; step1() (and a CV_32FC1 check) for cv::Mat, so that a
+ * non-continuous view (a column range, a row stride) is read correctly and a double Mat is refused */
+#ifdef PPF_MATCH_3D_HAVE_OPENCV
+inline int stride_of(const Mat& m) {
+  if (m.depth() != CV_32F || m.channels() != 1) throw Error(PPF_ERR_INVALID, "expected a CV_32FC1 cloud (N x 6 float32)");
+  return (int)m.step1();
+}
+inline Mat new_cloud(int rows, int cols) { return Mat(rows, cols, CV_32FC1); }
+#else
+inline int stride_of(const Mat& m) { return m.cols; }
+inline Mat new_cloud(int rows, int cols) { return Mat(rows, cols); }
+#endif
+}  // namespace detail
+
+/* cv::ppf_match_3d::Pose3D: the fields and methods of the library's class (pose_3d.hpp), filled from the engine's ppf_pose */
+class Pose3D;
+#ifdef PPF_MATCH_3D_HAVE_OPENCV
+typedef cv::Ptr<Pose3D> Pose3DPtr;
+#else
+typedef std::shared_ptr<Pose3D> Pose3DPtr; /* cv::Ptr<T> derives from std::shared_ptr<T> in OpenCV 4 */
+#endif
+
 class Pose3D {
  public:
-  Pose3D() : alpha(0), residual(0), modelIndex(0), numVotes(0), angle(0) {
-    pose.fill(0); pose[0] = pose[5] = pose[10] = pose[15] = 1;
-    t[0] = t[1] = t[2] = 0; q[0] = 1; q[1] = q[2] = q[3] = 0;
-  }
+  Pose3D() : alpha(0), residual(0), modelIndex(0), numVotes(0), pose(Matx44d::eye()), angle(0) { q[0] = 1; }
+  Pose3D(double Alpha, size_t ModelIndex = 0, size_t NumVotes = 0)
+      : alpha(Alpha), residual(0), modelIndex(ModelIndex), numVotes(NumVotes), pose(Matx44d::eye()), angle(0) { q[0] = 1; }
   explicit Pose3D(const ppf_pose& p) : alpha(p.alpha), residual(p.residual), modelIndex(p.model_index),
                                        numVotes(p.num_votes), angle(p.angle) {
-    std::memcpy(pose.data(), p.pose, sizeof(p.pose));
-    std::memcpy(t, p.t, sizeof(t));
-    std::memcpy(q, p.q, sizeof(q));
+    std::memcpy(pose.val, p.pose, sizeof(p.pose));
+    std::memcpy(t.val, p.t, sizeof(p.t));
+    std::memcpy(q.val, p.q, sizeof(p.q));
+  }
+  /* the engine's record of this pose (what ppf_icp_refine and ppf_cluster_poses take) */
+  ppf_pose record() const {
+    ppf_pose r;
+    std::memset(&r, 0, sizeof(r));
+    std::memcpy(r.pose, pose.val, sizeof(r.pose));
+    std::memcpy(r.q, q.val, sizeof(r.q));
+    std::memcpy(r.t, t.val, sizeof(r.t));
+    r.angle = angle; r.alpha = alpha; r.residual = residual;
+    r.model_index = (uint32_t)modelIndex; r.num_votes = (uint32_t)numVotes;
+    return r;
   }
   void printPose() const {
-    std::printf("\n-- Pose to Model Index %u: NumVotes = %u, Residual = %f\n", modelIndex, numVotes, residual);
-    for (int i = 0; i < 4; i++) std::printf("[%g, %g, %g, %g]\n", pose[i * 4], pose[i * 4 + 1], pose[i * 4 + 2], pose[i * 4 + 3]);
+    std::printf("\n-- Pose to Model Index %u: NumVotes = %u, Residual = %f\n", (unsigned)modelIndex, (unsigned)numVotes, residual);
+    for (int i = 0; i < 4; i++) std::printf("[%g, %g, %g, %g]\n", pose(i, 0), pose(i, 1), pose(i, 2), pose(i, 3));
   }
-  std::shared_ptr<Pose3D> clone() const { return std::make_shared<Pose3D>(*this); }
+  Pose3DPtr clone() const { return Pose3DPtr(new Pose3D(*this)); }
 
   double alpha, residual;
-  unsigned modelIndex, numVotes;
+  size_t modelIndex, numVotes;
   Matx44d pose;
   double angle;
-  double t[3];
-  double q[4];
+  Vec3d t;
+  Vec4d q;
 };
-typedef std::shared_ptr<Pose3D> Pose3DPtr; /* cv::Ptr<T> is std::shared_ptr<T> in OpenCV 4 */
 
 class PPF3DDetector {
  public:
@@ -175,18 +223,17 @@ class PPF3DDetector {
     run(scene, rows, stride, normalOffset, edge, erows, estride, edgeNormalOffset, results, relativeSceneSampleStep, relativeSceneDistance);
   }
 
-  /* anything with rows / cols / ptr<float>(i): ppf_match_3d::Mat, cv::Mat */
-  template <class M> void trainModel(const M& pc) { require_cloud(pc, "trainModel"); trainModel(pc.template ptr<float>(0), pc.rows, stride_of(pc)); }
-  template <class M>
-  void match(const M& pc, std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 1.0 / 5.0, double relativeSceneDistance = 0.03) {
-    require_cloud(pc, "match");
-    match(pc.template ptr<float>(0), pc.rows, stride_of(pc), results, relativeSceneSampleStep, relativeSceneDistance);
+  /* the calls the reference makes (CloudProcessing.h:236, 442, 495): N x 6 CV_32FC1 clouds, rows read through step1() */
+  void trainModel(const Mat& Model) { require_cloud(Model, "trainModel"); trainModel(Model.ptr<float>(0), Model.rows, detail::stride_of(Model)); }
+  void match(const Mat& scene, std::vector<Pose3DPtr>& results, const double relativeSceneSampleStep = 1.0 / 5.0,
+             const double relativeSceneDistance = 0.03) {
+    require_cloud(scene, "match");
+    match(scene.ptr<float>(0), scene.rows, detail::stride_of(scene), results, relativeSceneSampleStep, relativeSceneDistance);
   }
-  template <class M>
-  void match_S2B(const M& scene, const M& edge, std::vector<Pose3DPtr>& results, double relativeSceneSampleStep = 0.05,
-                 double relativeSceneDistance = 0.05) {
+  void match_S2B(const Mat& scene, const Mat& edge, std::vector<Pose3DPtr>& results, const double relativeSceneSampleStep = 0.05,
+                 const double relativeSceneDistance = 0.05) {
     require_cloud(scene, "match_S2B"); require_cloud(edge, "match_S2B");
-    match_S2B(scene.template ptr<float>(0), scene.rows, stride_of(scene), edge.template ptr<float>(0), edge.rows, stride_of(edge), results,
+    match_S2B(scene.ptr<float>(0), scene.rows, detail::stride_of(scene), edge.ptr<float>(0), edge.rows, detail::stride_of(edge), results,
               relativeSceneSampleStep, relativeSceneDistance);
   }
 
@@ -234,8 +281,7 @@ class PPF3DDetector {
   const ppf_model* handle() const { return model_; }
 
  private:
-  template <class M> static int stride_of(const M& m) { return detail::stride_of(m); }
-  template <class M> static void require_cloud(const M& m, const char* who) {
+  static void require_cloud(const Mat& m, const char* who) {
     if (m.rows <= 0 || m.cols < 6) throw Error(PPF_ERR_INVALID, std::string(who) + ": expected an N x 6 float32 cloud (x y z nx ny nz)");
   }
   void require_trained() const {
@@ -254,7 +300,7 @@ class PPF3DDetector {
     check(ppf_match(model_, scene, rows, stride, noff, edge, erows, estride, enoff, &p, out.data(), cap, &n));
     results.clear();
     results.reserve((size_t)n);
-    for (int i = 0; i < n; i++) results.push_back(std::make_shared<Pose3D>(out[(size_t)i]));
+    for (int i = 0; i < n; i++) results.push_back(Pose3DPtr(new Pose3D(out[(size_t)i])));
   }
 
   ppf_train_params tp_;
@@ -283,32 +329,25 @@ class ICP {
   virtual ~ICP() {}
 
   /* one registration from the identity: returns 0, fills residual and the 4x4 src -> dst */
-  template <class M> int registerModelToScene(const M& srcPC, const M& dstPC, double& residual, Matx44d& pose) {
+  int registerModelToScene(const Mat& srcPC, const Mat& dstPC, double& residual, Matx44d& pose) {
     require_cloud(srcPC); require_cloud(dstPC);
-    check(ppf_icp_register(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), PPF_NOFF_MAT, dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC), PPF_NOFF_MAT,
-                           &prm_, pose.data(), &residual, nullptr));
+    check(ppf_icp_register(srcPC.ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), PPF_NOFF_MAT, dstPC.ptr<float>(0), dstPC.rows,
+                           detail::stride_of(dstPC), PPF_NOFF_MAT, &prm_, pose.val, &residual, nullptr));
     return 0;
   }
   /* every pose: move the model by it, register to the scene, pose <- poseICP * pose, residual set */
-  template <class M> int registerModelToScene(const M& srcPC, const M& dstPC, std::vector<Pose3DPtr>& poses) {
+  int registerModelToScene(const Mat& srcPC, const Mat& dstPC, std::vector<Pose3DPtr>& poses) {
     require_cloud(srcPC); require_cloud(dstPC);
     std::vector<ppf_pose> recs(poses.size());
-    for (size_t i = 0; i < poses.size(); i++) {
-      ppf_pose& r = recs[i];
-      const Pose3D& p = *poses[i];
-      std::memcpy(r.pose, p.pose.data(), sizeof(r.pose));
-      std::memcpy(r.q, p.q, sizeof(r.q));
-      std::memcpy(r.t, p.t, sizeof(r.t));
-      r.angle = p.angle; r.alpha = p.alpha; r.residual = p.residual; r.model_index = p.modelIndex; r.num_votes = p.numVotes;
-    }
-    check(ppf_icp_refine(srcPC.template ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), PPF_NOFF_MAT, dstPC.template ptr<float>(0), dstPC.rows, detail::stride_of(dstPC), PPF_NOFF_MAT, &prm_,
-                         recs.data(), (int)recs.size(), nullptr));
+    for (size_t i = 0; i < poses.size(); i++) recs[i] = poses[i]->record();
+    check(ppf_icp_refine(srcPC.ptr<float>(0), srcPC.rows, detail::stride_of(srcPC), PPF_NOFF_MAT, dstPC.ptr<float>(0), dstPC.rows,
+                         detail::stride_of(dstPC), PPF_NOFF_MAT, &prm_, recs.data(), (int)recs.size(), nullptr));
     for (size_t i = 0; i < poses.size(); i++) *poses[i] = Pose3D(recs[i]);
     return 0;
   }
 
  private:
-  template <class M> static void require_cloud(const M& m) {
+  static void require_cloud(const Mat& m) {
     if (m.rows <= 0 || m.cols < 6) throw Error(PPF_ERR_INVALID, "ICP: expected an N x 6 float32 cloud (x y z nx ny nz)");
   }
   ppf_icp_params prm_;
@@ -332,7 +371,7 @@ inline Mat loadPLYSimple(const char* fileName, int withNormals = 0) {
   }
   const int cols = withNormals ? 6 : 3;
   if (numProps < cols) throw Error(PPF_ERR_IO, "loadPLYSimple: not enough vertex properties");
-  Mat cloud(numVertices, cols);
+  Mat cloud = detail::new_cloud(numVertices, cols);
   for (int i = 0; i < numVertices; i++) {
     float* row = cloud.ptr<float>(i);
     std::getline(ifs, line);
@@ -346,36 +385,47 @@ inline Mat loadPLYSimple(const char* fileName, int withNormals = 0) {
   return cloud;
 }
 
-inline void writePLY(const Mat& pc, const char* fileName) {
+inline void writePLY(Mat PC, const char* fileName) {
+  const int stride = detail::stride_of(PC);
+  (void)stride; /* the CV_32FC1 check */
   std::ofstream out(fileName);
   if (!out) throw Error(PPF_ERR_IO, std::string("Error opening output file: ") + fileName);
-  out << "ply\nformat ascii 1.0\nelement vertex " << pc.rows << "\nproperty float x\nproperty float y\nproperty float z\n";
-  if (pc.cols >= 6) out << "property float nx\nproperty float ny\nproperty float nz\n";
+  out << "ply\nformat ascii 1.0\nelement vertex " << PC.rows << "\nproperty float x\nproperty float y\nproperty float z\n";
+  if (PC.cols >= 6) out << "property float nx\nproperty float ny\nproperty float nz\n";
   out << "end_header\n";
-  for (int i = 0; i < pc.rows; i++) {
-    const float* r = pc.ptr<float>(i);
+  for (int i = 0; i < PC.rows; i++) {
+    const float* r = PC.ptr<float>(i);
     out << r[0] << " " << r[1] << " " << r[2];
-    if (pc.cols >= 6) out << " " << r[3] << " " << r[4] << " " << r[5];
+    if (PC.cols >= 6) out << " " << r[3] << " " << r[4] << " " << r[5];
     out << "\n";
   }
 }
 
-inline Mat transformPCPose(const Mat& pc, const Matx44d& pose) {
+/* src/YOLO_cropping_ppf_test.cpp:125: Mat object_trans = transformPCPose(bottle, result_pose.pose); */
+inline Mat transformPCPose(Mat pc, const Matx44d& Pose) {
   if (pc.cols < 6) throw Error(PPF_ERR_INVALID, "transformPCPose: expected an N x 6 cloud");
-  Mat out(pc.rows, 6);
-  check(ppf_transform_pc_pose(pc.ptr<float>(0), pc.rows, pc.cols, PPF_NOFF_MAT, pose.data(), out.ptr<float>(0)));
+  Mat out = detail::new_cloud(pc.rows, 6);
+  if (pc.rows > 0) check(ppf_transform_pc_pose(pc.ptr<float>(0), pc.rows, detail::stride_of(pc), PPF_NOFF_MAT, Pose.val, out.ptr<float>(0)));
   return out;
 }
 
-inline Mat samplePCByQuantization(const Mat& pc, float sampleStep) {
+inline Mat samplePCByQuantization(Mat pc, float sampleStep) {
+  if (pc.rows <= 0 || pc.cols < 6) throw Error(PPF_ERR_INVALID, "samplePCByQuantization: expected an N x 6 cloud");
   int n = 0;
-  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, PPF_NOFF_MAT, sampleStep, nullptr, 0, &n));
-  Mat out(n, 6);
-  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, pc.cols, PPF_NOFF_MAT, sampleStep, out.ptr<float>(0), n, &n));
+  const int stride = detail::stride_of(pc);
+  check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, stride, PPF_NOFF_MAT, sampleStep, nullptr, 0, &n));
+  Mat out = detail::new_cloud(n, 6);
+  if (n > 0) check(ppf_sample_cloud(pc.ptr<float>(0), pc.rows, stride, PPF_NOFF_MAT, sampleStep, out.ptr<float>(0), n, &n));
   return out;
 }
 
 }  // namespace ppf_match_3d
 }  // namespace ppfhip
+
+#if defined(PPF_MATCH_3D_HAVE_OPENCV) && defined(PPF_MATCH_3D_AS_CV)
+/* the name the reference spells: cv::ppf_match_3d (`using namespace cv; using namespace ppf_match_3d;`, CloudProcessing.h:28-29,
+ * and `ppf_match_3d::PPF3DDetector`, :205).  Only for builds that no longer include <opencv2/surface_matching.hpp>. */
+namespace cv { namespace ppf_match_3d = ::ppfhip::ppf_match_3d; }
+#endif
 
 #endif /* PPF_MATCH_3D_HPP */

@@ -12,10 +12,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "yolo_ppf_pose_estimation_amd", "csrc")
 
 
-def _build(tmp_path, name="cloud_processor_demo"):
+def _build(tmp_path, name="cloud_processor_demo", std="c++17", with_opencv_stand_in=False):
     exe = str(tmp_path / name)
-    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", name + ".cpp"), "-L", CSRC, "-lppf_hip",
+    inc = ["-I", os.path.join(ROOT, "include")] + (["-I", os.path.join(ROOT, "tests", "mock_opencv")] if with_opencv_stand_in else [])
+    subprocess.run(["g++", f"-std={std}", "-Wall", "-Wextra", "-Werror"] + inc +
+                   [os.path.join(ROOT, "examples", name + ".cpp"), "-L", CSRC, "-lppf_hip",
+                    f"-Wl,-rpath,{CSRC}", "-o", exe], check=True)
+    return exe
+
+
+def _build_call_shapes(tmp_path, recipe, compiler="g++"):
+    """tests/cpp/reference_call_shapes.cpp: the reference's call shapes with file-scope using directives and unqualified
+    names only, as C++11 (the reference's standard, CMakeLists.txt:60) with warnings as errors."""
+    exe = str(tmp_path / f"reference_call_shapes_{recipe}")
+    subprocess.run([compiler, "-std=c++11", "-Wall", "-Wextra", "-Werror", f"-DSHAPES_RECIPE={recipe}",
+                    "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "mock_opencv"),
+                    os.path.join(ROOT, "tests", "cpp", "reference_call_shapes.cpp"), "-L", CSRC, "-lppf_hip",
                     f"-Wl,-rpath,{CSRC}", "-o", exe], check=True)
     return exe
 
@@ -59,6 +71,61 @@ def test_facade_matches_python_binding(tmp_path, bottle):
     # S2B through the facade: edge == scene gives the same top pose
     r2 = subprocess.run([exe, m, s, s, out, "0.05"], capture_output=True, text=True)
     assert r2.returncode == 0 and int(r2.stdout.split("RESULT votes=")[1].split()[0]) == votes
+
+
+@pytest.mark.parametrize("recipe", [1, 2])
+def test_reference_call_shapes_compile_unqualified_under_both_recipes(tmp_path, bottle, recipe):
+    """`using namespace cv;` next to the facade's namespace, unqualified Mat / Pose3D / PPF3DDetector / ICP / FileStorage:
+    recipe 1 = include swap only (PPF_MATCH_3D_AS_CV), recipe 2 = include swap + two using directives.
+    Without a GPU the program must stop at the first compute call with PPF_ERR_HIP."""
+    exe = _build_call_shapes(tmp_path, recipe)
+    if _capi.lib().ppf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    m, s = _inputs(tmp_path, bottle)
+    r = subprocess.run([exe, m, s, "-", str(tmp_path), str(tmp_path / "moved.ply")], capture_output=True, text=True)
+    assert r.returncode == 10 + _capi.PPF_ERR_HIP, r.stdout + r.stderr
+    assert "no HIP device" in r.stderr
+
+
+def test_reference_call_shapes_compile_with_clang_too(tmp_path):
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ in this image")
+    for recipe in (1, 2):
+        _build_call_shapes(tmp_path, recipe, compiler=clang)
+
+
+def test_examples_compile_as_cxx11_with_and_without_the_opencv_stand_in(tmp_path):
+    """the reference is C++11 (CMakeLists.txt:60); with OpenCV present the facade's Mat IS cv::Mat"""
+    for name in ("cloud_processor_demo", "cloud_stages_demo", "pcl_pipeline_demo"):
+        _build(tmp_path, name, std="c++11")
+        _build(tmp_path, name, std="c++11", with_opencv_stand_in=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("recipe,edge", [(1, False), (2, True)])
+def test_reference_call_shapes_run_and_equal_the_python_binding(tmp_path, bottle, recipe, edge):
+    """the call-shape program (train -> FileStorage write -> read -> by-value copy -> match / match_S2B -> ICP top 5 ->
+    transformPCPose -> writePLY) gives the votes, residual and moved cloud of the Python binding"""
+    from yolo_ppf_pose_estimation_amd.detector import ICP, PPF3DDetector
+    exe = _build_call_shapes(tmp_path, recipe)
+    m, s = _inputs(tmp_path, bottle)
+    out = str(tmp_path / "moved.ply")
+    r = subprocess.run([exe, m, s, s if edge else "-", str(tmp_path), out, "0.05"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = dict(kv.split("=") for kv in r.stdout.split("RESULT ")[1].split())
+    assert res["loaded_equals_trained"] == "1" and res["untrained_refused"] == "1" and float(res["depth"]) == float(np.float32(0.635))
+    model, scene = ply.load_ply_simple(m), ply.load_ply_simple(s)
+    det = PPF3DDetector(0.05, 0.05).trainModel(model)
+    poses = (det.match_S2B(scene, scene, 0.05, 0.05) if edge else det.match(scene, 0.05, 0.05))[:5]
+    ICP(100, 0.005, 2.5, 8).registerModelToScene(model, scene, poses)
+    assert int(res["votes"]) == poses[0].numVotes
+    assert float(res["residual"]) == poses[0].residual
+    assert float(res["p03"]) == poses[0].pose[0, 3] and float(res["t0"]) == poses[0].t[0] and float(res["q0"]) == poses[0].q[0]
+    assert int(res["moved_rows"]) == model.shape[0]
+    moved = ply.load_ply_simple(out)
+    np.testing.assert_allclose(moved[:, :3], ply.transform_pc_pose(model, poses[0].pose)[:, :3], atol=2e-5)
+    assert os.path.getsize(tmp_path / "detector_bottle.xml") > 1000
 
 
 def test_pcl_shaped_facade_compiles_and_fails_loudly_without_gpu(tmp_path, bottle):
@@ -141,12 +208,14 @@ OPENCV_OVERLOADS = r'''
 // The reference's own calls on cv::FileStorage / cv::FileNode (CloudProcessing.h:111-113, 249-251) and a cv::Mat view
 // whose row step is larger than its column count, through the OpenCV overloads of the facade.
 #include <cstdio>
+#include <type_traits>
 #include "ppf_match_3d.hpp"
 using namespace ppfhip::ppf_match_3d;
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
   try {
-    ppfhip::ppf_match_3d::Mat model = loadPLYSimple(argv[1], 1), scene = loadPLYSimple(argv[2], 1);
+    Mat model = loadPLYSimple(argv[1], 1), scene = loadPLYSimple(argv[2], 1); /* cv::Mat: the facade adds no second Mat */
+    static_assert(std::is_same<Mat, cv::Mat>::value && std::is_same<Matx44d, cv::Matx44d>::value, "facade types are the cv types");
     // a 9-column CV_32F buffer whose first 6 columns are the cloud: step1() == 9, cols == 6
     cv::Mat wide(scene.rows, 9, CV_32F);
     for (int i = 0; i < scene.rows; i++) {
