@@ -201,12 +201,16 @@ typedef struct ppf_icp_params {
   float tolerance;       /* arg 2 (0.005f) */
   float rejection_scale; /* arg 3 (2.5f); <= 0 disables the median+MAD rejection */
   int32_t num_levels;    /* arg 4 (8) */
-  int32_t flags;         /* 0; PPF_ICP_NO_SMALL_LEVELS: coarse levels run kernel by kernel instead of in one workgroup;
-                            PPF_ICP_ONE_STREAM: the poses of one call share the caller's stream.  Same results either way. */
+  int32_t flags;         /* 0: all poses of a call advance through the same launches, two per iteration, neighbours from a
+                            grid search.  PPF_ICP_LEGACY: the earlier schedule (one stream per pose, seven launches per
+                            iteration, exhaustive neighbour search); with it PPF_ICP_NO_SMALL_LEVELS (coarse levels kernel by
+                            kernel instead of in one workgroup) and PPF_ICP_ONE_STREAM (the poses share the caller's stream).
+                            Same results whichever way (tests/test_gpu_robustness.py). */
   int32_t reserved[3];
 } ppf_icp_params;
 #define PPF_ICP_NO_SMALL_LEVELS 1
 #define PPF_ICP_ONE_STREAM 2
+#define PPF_ICP_LEGACY 4
 
 void ppf_default_train_params(ppf_train_params* p);
 void ppf_default_match_params(ppf_match_params* p);

@@ -369,13 +369,15 @@ def test_serial_and_matrix_clustering_agree(det, crop):
 
 
 def test_icp_schedules_agree(det, bottle, crop):
-    """ppf_icp_params.flags: coarse levels kernel by kernel instead of in one workgroup, all poses on one stream: the
-    refined poses, residuals and iteration counts do not change."""
+    """ppf_icp_params.flags: the default schedule (all poses through the same launches, grid neighbour search) against the
+    legacy one (a stream per pose, exhaustive search) with its own switches (coarse levels kernel by kernel instead of in
+    one workgroup, all poses on one stream): the refined poses, residuals and iteration counts do not change."""
     from yolo_ppf_pose_estimation_amd.detector import ICP
     poses = det.match(crop, 1.0 / 10.0, 0.05, presampled=True)[:3]
     ref = ICP(100, 0.005, 2.5, 8)
     want = ref.registerModelToScene(bottle, crop, [p.clone() for p in poses])
-    for flags in (_capi.PPF_ICP_NO_SMALL_LEVELS, _capi.PPF_ICP_ONE_STREAM, _capi.PPF_ICP_NO_SMALL_LEVELS | _capi.PPF_ICP_ONE_STREAM):
+    L = _capi.PPF_ICP_LEGACY
+    for flags in (L, L | _capi.PPF_ICP_NO_SMALL_LEVELS, L | _capi.PPF_ICP_ONE_STREAM, L | _capi.PPF_ICP_NO_SMALL_LEVELS | _capi.PPF_ICP_ONE_STREAM):
         icp = ICP(100, 0.005, 2.5, 8, flags=flags)
         got = icp.registerModelToScene(bottle, crop, [p.clone() for p in poses])
         assert icp.last_iterations == ref.last_iterations

@@ -22,12 +22,14 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle on the first pose and compare")
     ap.add_argument("--scene-points", type=int, default=50000)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--legacy", action="store_true", help="the earlier schedule (PPF_ICP_LEGACY): a stream per pose, exhaustive search")
     a = ap.parse_args()
     bottle = np.load(os.path.join(ROOT, "tests", "golden", "bottle_model_xyzn.npy"))
     scene, Ts = synth.make_scene(bottle, n_points=a.scene_points, seed=12345)
     det = PPF3DDetector(0.036, 0.05).trainModel(bottle)
     poses = det.match(scene, 1.0 / 20.0, 0.05)[:5]
-    icp = ICP(100, 0.005, 2.5, 8)
+    from yolo_ppf_pose_estimation_amd import _capi
+    icp = ICP(100, 0.005, 2.5, 8, flags=_capi.PPF_ICP_LEGACY if a.legacy else 0)
     best = None
     for _ in range(a.repeat):
         work = [p.clone() for p in poses]
@@ -36,7 +38,8 @@ def main():
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     out = {"model_rows": int(bottle.shape[0]), "scene_rows": int(scene.shape[0]), "poses": len(work),
-           "iterations": icp.last_iterations, "residuals": [p.residual for p in work], "gpu_seconds": best}
+           "iterations": icp.last_iterations, "residuals": [p.residual for p in work], "gpu_seconds": best,
+           "schedule": "legacy" if a.legacy else "batched"}
     if a.oracle:
         import oracle_lib as O
         t0 = time.perf_counter()

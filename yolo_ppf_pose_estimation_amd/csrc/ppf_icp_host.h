@@ -19,7 +19,10 @@ struct IcpScratch {
 };
 
 constexpr int ICP_BATCH = 2;     /* iterations enqueued between two reads of the done flag (measured best of 1..6) */
-constexpr int ICP_MAX_JOBS = 8;  /* poses refined concurrently, one HIP stream each */
+/* ICP_MAX_JOBS (ppf_icp_kernels.h): poses refined per batch of launches (legacy path: concurrently, one HIP stream each) */
+#ifndef PPF_ICP_BATCH2
+#define PPF_ICP_BATCH2 2         /* batched path: iterations (two launches each) enqueued between two reads of the done flags */
+#endif
 
 inline long icp_round(double v) { return std::lrint(v); } /* cvRound */
 
@@ -251,6 +254,160 @@ ppf_status icp_make_jobs(int count, hipStream_t user, std::vector<IcpJob*>& jobs
   return PPF_OK;
 }
 
+/* ---- batched path (default; kernels k_icp2_*) ------------------------------------------------------------------- */
+struct IcpBatchScratch {
+  DevBuf<float> src0, dst0, src_pct;
+  DevBuf<unsigned long long> best, owner;
+  DevBuf<int2> sel;
+  DevBuf<double> parts, sum_src, sum_dst;
+  DevBuf<float4> g_pts, g_box2;
+  DevBuf<uint32_t> g_start, g_cur, g_box1u;
+  DevBuf<IcpState2> state;
+  int* h_done = nullptr;        /* pinned: one flag per job, written by the kernels */
+  IcpState2* h_state = nullptr; /* pinned: the jobs' final loop states */
+  ~IcpBatchScratch() {
+    if (h_done) (void)hipHostFree(h_done);
+    if (h_state) (void)hipHostFree(h_state);
+  }
+};
+
+/* registerModelToScene for `jobs` initial poses at once (init_poses NULL: one registration from the identity): every
+ * launch covers all jobs, an iteration is two launches (k_icp2_nn, k_icp2_tail), the host reads the jobs' done flags once
+ * per PPF_ICP_BATCH2 iterations.  Everything runs on `st`. */
+ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff, const float* d_dst, int nd_all, int dstride, int dnoff,
+                              const ppf_icp_params& prm, const double* const* init_poses, int jobs, IcpBatchScratch& sc, hipStream_t st,
+                              double* poses_out /* jobs x 16 */, double* residuals, int* iters_total) {
+  const size_t chunks_src = ((size_t)n + ICP_CHUNK - 1) / ICP_CHUNK, chunks_dst = ((size_t)nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
+  const size_t J = (size_t)jobs;
+  IcpBatch B;
+  memset(&B, 0, sizeof(B));
+  B.p_sel = (size_t)std::min(n, nd_all);
+  B.p_parts = ((size_t)std::min(n, nd_all) + ICP_CHUNK - 1) / ICP_CHUNK * ICP_ENTRIES;
+  B.p_sums = chunks_src * 3;
+  B.p_sumd = chunks_dst * 3;
+  HIPCHK(sc.src0.reserve(J * n * 6));
+  HIPCHK(sc.src_pct.reserve(J * n * 6));
+  HIPCHK(sc.dst0.reserve(J * nd_all * 6));
+  HIPCHK(sc.best.reserve(J * n));
+  HIPCHK(sc.owner.reserve(J * nd_all));
+  HIPCHK(sc.sel.reserve(J * B.p_sel));
+  HIPCHK(sc.parts.reserve(J * B.p_parts));
+  HIPCHK(sc.sum_src.reserve(J * B.p_sums));
+  HIPCHK(sc.sum_dst.reserve(J * B.p_sumd));
+  HIPCHK(sc.g_pts.reserve(J * nd_all));
+  HIPCHK(sc.g_start.reserve(J * (ICP_LEAVES + 64)));
+  HIPCHK(sc.g_cur.reserve(J * ICP_LEAVES));
+  HIPCHK(sc.g_box2.reserve(J * ICP_LEAVES * 2));
+  HIPCHK(sc.g_box1u.reserve(J * 64 * 8));
+  HIPCHK(sc.state.reserve(ICP_MAX_JOBS));
+  if (!sc.h_done) HIPCHK(hipHostMalloc((void**)&sc.h_done, ICP_MAX_JOBS * sizeof(int), hipHostMallocDefault));
+  if (!sc.h_state) HIPCHK(hipHostMalloc((void**)&sc.h_state, ICP_MAX_JOBS * sizeof(IcpState2), hipHostMallocDefault));
+  B.src = d_src; B.dst = d_dst;
+  B.n = n; B.sstride = sstride; B.snoff = snoff; B.nd_all = nd_all; B.dstride = dstride; B.dnoff = dnoff;
+  B.src0 = sc.src0.p; B.dst0 = sc.dst0.p; B.src_pct = sc.src_pct.p;
+  B.best = sc.best.p; B.owner = sc.owner.p; B.sel = sc.sel.p;
+  B.parts = sc.parts.p; B.sum_src = sc.sum_src.p; B.sum_dst = sc.sum_dst.p;
+  B.g_pts = sc.g_pts.p; B.g_start = sc.g_start.p; B.g_cur = sc.g_cur.p; B.g_box2 = sc.g_box2.p; B.g_box1u = sc.g_box1u.p;
+  B.state = sc.state.p;
+  B.h_done = sc.h_done;
+  B.has_init = init_poses ? 1 : 0;
+  for (int j = 0; j < jobs; j++)
+    for (int k = 0; k < 16; k++) B.T0[j][k] = init_poses && init_poses[j] ? init_poses[j][k] : ((k % 5 == 0) ? 1.0 : 0.0);
+  static std::once_flag once_tail;
+  static hipError_t attr_tail = hipSuccess;
+  std::call_once(once_tail, [] {
+    attr_tail = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_icp2_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+  });
+  HIPCHK(attr_tail);
+  const unsigned uj = (unsigned)jobs;
+  /* the two clouds packed (the source moved by its job's initial pose), centred on the average of the two means, scaled to
+   * unit average distance from the origin; the search grid over each job's scene */
+  k_icp2_reset<<<dim3(uj), dim3(256), 0, st>>>(B);
+  k_icp2_pack_sums<<<dim3((unsigned)(chunks_src + chunks_dst), uj), dim3(64), 0, st>>>(B);
+  k_icp2_mean<<<dim3(uj), dim3(256), 0, st>>>(B);
+  k_icp2_dist_sums<<<dim3((unsigned)(chunks_src + chunks_dst), uj), dim3(64), 0, st>>>(B);
+  k_icp2_scale<<<dim3(uj), dim3(256), 0, st>>>(B);
+  k_icp2_rows<<<dim3((unsigned)(((size_t)n + nd_all + 255) / 256), uj), dim3(256), 0, st>>>(B);
+  k_icp2_grid_scan<<<dim3(uj), dim3(1024), 0, st>>>(B);
+  k_icp2_grid_scatter<<<dim3((unsigned)((nd_all + 255) / 256), uj), dim3(256), 0, st>>>(B);
+  k_icp2_grid_boxes<<<dim3(ICP_LEAVES / 4, uj), dim3(256), 0, st>>>(B);
+  HIPCHK(hipGetLastError());
+  const int robust = prm.rejection_scale > 0 ? 1 : 0;
+  for (int level = prm.num_levels - 1; level >= 0; level--) {
+    const double div = std::pow(2.0, (double)level);
+    const int num_samples = (int)icp_round((double)n / div);
+    const double tol_p = (double)prm.tolerance * (double)(level + 1) * (level + 1);
+    const int max_iter = (int)icp_round((double)prm.iterations / (level + 1));
+    const int step = std::max(1, (int)icp_round((double)n / (double)std::max(num_samples, 1)));
+    const int ns = (n + step - 1) / step, nd = (nd_all + step - 1) / step;
+    int step_shift = -1;
+    if ((step & (step - 1)) == 0) { step_shift = 0; while ((1 << step_shift) < step) step_shift++; }
+    k_icp2_level_begin<<<dim3((unsigned)((ns + 255) / 256), uj), dim3(256), 0, st>>>(B, step, ns, tol_p, max_iter, robust);
+    const int staged = ns <= 32768 ? 1 : 0; /* the level's distances fit LDS (4 bytes each): the selection passes read them there */
+    const size_t tail_lds = std::max<size_t>(staged ? (size_t)ns * 4 : 0, (size_t)ICP_TAIL_VAL_BYTES);
+    const unsigned nn_blocks = (unsigned)((ns + 3) / 4);
+    int launched = 0;
+    while (true) {
+      const int batch = std::min((int)PPF_ICP_BATCH2, max_iter - launched);
+      for (int b = 0; b < batch; b++) {
+        k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift);
+        k_icp2_tail<<<dim3(uj), dim3(1024), tail_lds, st>>>(B, ns, nd, step, prm.rejection_scale, staged);
+      }
+      launched += std::max(batch, 0);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(st));
+      bool all = true;
+      for (int j = 0; j < jobs; j++) all &= sc.h_done[j] != 0;
+      if (all || launched >= max_iter) break;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(sc.h_state, sc.state.p, J * sizeof(IcpState2), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int j = 0; j < jobs; j++) {
+    /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
+    const IcpState2& h = sc.h_state[j];
+    double pose[16];
+    memcpy(pose, h.pose, sizeof(pose));
+    double Rm[3];
+    for (int r = 0; r < 3; r++) Rm[r] = pose[r * 4] * h.mean_avg[0] + pose[r * 4 + 1] * h.mean_avg[1] + pose[r * 4 + 2] * h.mean_avg[2];
+    for (int r = 0; r < 3; r++) pose[r * 4 + 3] = pose[r * 4 + 3] / h.scale + h.mean_avg[r] - Rm[r];
+    memcpy(poses_out + (size_t)j * 16, pose, sizeof(pose));
+    if (residuals) residuals[j] = h.fval_min;
+    if (iters_total) iters_total[j] = h.total;
+#ifdef PPF_ICP_CLOCKS
+    fprintf(stderr, "icp job %d: threshold %.1f  ownership %.1f  compaction %.1f  chunks %.1f  sums %.1f  solve %.1f us (iterations %d)\n", j, h.ph[0] * 0.01,
+            h.ph[1] * 0.01, h.ph[2] * 0.01, h.ph[3] * 0.01, h.ph[4] * 0.01, h.ph[5] * 0.01, h.total);
+#endif
+  }
+  return PPF_OK;
+}
+
+/* one process-wide scratch for the batched path (buffers only grow); a second concurrent caller works on a private one */
+struct IcpBatchPool {
+  std::mutex mu;
+  IcpBatchScratch sc;
+  int device = -1;
+};
+IcpBatchPool& g_icp_batch_pool = *new IcpBatchPool(); /* never destroyed: nothing is freed after the HIP runtime has shut down */
+
+ppf_status icp_batch_run(const float* d_src, int n, int sstride, int snoff, const float* d_dst, int nd_all, int dstride, int dnoff,
+                         const ppf_icp_params& prm, const double* const* init_poses, int jobs, hipStream_t st, double* poses_out,
+                         double* residuals, int* iters_total) {
+  std::unique_lock<std::mutex> lock(g_icp_batch_pool.mu, std::try_to_lock);
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (lock.owns_lock() && (g_icp_batch_pool.device == dev || g_icp_batch_pool.device < 0)) {
+    g_icp_batch_pool.device = dev;
+    return icp_register_batch(d_src, n, sstride, snoff, d_dst, nd_all, dstride, dnoff, prm, init_poses, jobs, g_icp_batch_pool.sc, st,
+                              poses_out, residuals, iters_total);
+  }
+  IcpBatchScratch priv;
+  const ppf_status s = icp_register_batch(d_src, n, sstride, snoff, d_dst, nd_all, dstride, dnoff, prm, init_poses, jobs, priv, st, poses_out,
+                                          residuals, iters_total);
+  (void)hipStreamSynchronize(st); /* the private scratch goes back to the block cache */
+  return s;
+}
+
 ppf_status icp_check(const char* who, const void* src, int n, int sstride, int snoff, const void* dst, int nd, int dstride, int dnoff,
                      const ppf_icp_params* prm) {
   if (!src || !dst || !prm || n <= 0 || nd <= 0 || bad_layout(sstride, snoff) || bad_layout(dstride, dnoff))
@@ -277,6 +434,19 @@ ppf_status icp_refine_device(const float* d_model, int n, int mstride, int mnoff
                              const ppf_icp_params* prm, ppf_pose* poses, int n_poses, int* iters, hipStream_t st) {
   for (int k0 = 0; k0 < n_poses; k0 += ICP_MAX_JOBS) {
     const int cnt = std::min(ICP_MAX_JOBS, n_poses - k0);
+    if (!(prm->flags & PPF_ICP_LEGACY)) {
+      const double* init[ICP_MAX_JOBS];
+      double inc[ICP_MAX_JOBS * 16], res[ICP_MAX_JOBS];
+      int it[ICP_MAX_JOBS];
+      for (int j = 0; j < cnt; j++) init[j] = poses[k0 + j].pose;
+      const ppf_status s = icp_batch_run(d_model, n, mstride, mnoff, d_scene, nd, sstride, snoff, *prm, init, cnt, st, inc, res, it);
+      if (s != PPF_OK) return s;
+      for (int j = 0; j < cnt; j++) {
+        icp_append_pose(&poses[k0 + j], inc + j * 16, res[j]);
+        if (iters) iters[k0 + j] = it[j];
+      }
+      continue;
+    }
     std::vector<IcpJob*> jobs;
     std::vector<std::unique_ptr<IcpJob>> owned;
     std::unique_lock<std::mutex> pool_lock;
@@ -350,6 +520,8 @@ ppf_status ppf_icp_register(const float* src, int n_src, int sstride, int snoff,
   DevBuf<float> dsrc, ddst;
   if ((s = icp_upload(src, n_src, sstride, snoff, dsrc)) != PPF_OK) return s;
   if ((s = icp_upload(dst, n_dst, dstride, dnoff, ddst)) != PPF_OK) return s;
+  if (!(params->flags & PPF_ICP_LEGACY))
+    return icp_batch_run(dsrc.p, n_src, 6, 3, ddst.p, n_dst, 6, 3, *params, nullptr, 1, nullptr, pose16_out, residual_out, iterations_out);
   std::vector<IcpJob*> jobs;
   std::vector<std::unique_ptr<IcpJob>> owned;
   std::unique_lock<std::mutex> pool_lock;

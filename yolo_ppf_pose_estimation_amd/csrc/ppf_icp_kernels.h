@@ -652,4 +652,789 @@ __global__ __launch_bounds__(1024) void k_icp_level_small(const float* __restric
   }
 }
 
+
+/* ============================================================================================================
+ * Batched path (the default): every pose of a call is one "job"; all jobs advance in lock-step through the SAME
+ * launches (blockIdx.y or blockIdx.x = job), so a call costs the launches of one registration whatever the number of
+ * poses, and an iteration is TWO launches instead of seven:
+ *   k_icp2_nn    exact nearest neighbours, one WAVE per model point.  Fine levels search a two-level 4x4x4 grid over the
+ *                job's scene (64 nodes, 4,096 leaves, boxes = the real extent of the points inside): lane l tests node l,
+ *                passing nodes are opened in turn (lane l tests child l), passing leaves are scanned 64 points at a
+ *                time.  A box is skipped only when its lower bound, shrunk by 1e-4, still exceeds the best distance found,
+ *                so the result is the exhaustive search's (smallest float d2, then smallest scene index) -- the key
+ *                (distance bits, index) is min-reduced whatever the visiting order.  Coarse levels (few scene rows) scan
+ *                them all, 64 per step.  Also clears the ownership keys.
+ *   k_icp2_tail  one workgroup per job: rejection threshold (radix select over LDS), picky ownership (atomicMin; a wave
+ *                whose points all chose the same scene point -- a model thrown off the data -- sends one atomic, not
+ *                64 to one address), ordered compaction, chunk sums, 6x6 solve, loop state; when the level ends it
+ *                folds PoseX into the job's pose.  Same arithmetic and orders as the kernels above.
+ * The host reads one flag per job (pinned memory, written by k_icp2_tail) after every batch of iterations.
+ * ============================================================================================================ */
+constexpr int ICP_MAX_JOBS = 8;     /* poses refined per batch of launches */
+constexpr int ICP_LEAVES = 4096;    /* 16 x 16 x 16 cells, grouped 4 x 4 x 4 under 64 nodes */
+constexpr int ICP_BRUTE_ND = 4096;  /* levels with at most this many scene rows scan them all */
+constexpr float ICP_LB_SHRINK = 0.9999f;
+
+struct IcpState2 {
+  double pose[16];  /* product of the finished levels' PoseX */
+  double PoseX[16]; /* the running level's incremental pose */
+  double mean_avg[3];
+  double scale;
+  double fval_old, fval_perc, fval_min, tol_p;
+  float thr;
+  float org[3], inv_h; /* grid: cell = (int)((p - org) * inv_h) clamped to 0..15 */
+  int n_sel, iter, max_iter, done, robust, total, pad0;
+  uint32_t raw_lo[3], raw_hi[3]; /* extent of the scene rows as given (ordered-uint coded floats; NaN left out) */
+#ifdef PPF_ICP_CLOCKS
+  unsigned long long ph[8];      /* diagnostic build: ticks of the 100 MHz clock k_icp2_tail's thread 0 spent per phase */
+#endif
+};
+#ifdef PPF_ICP_CLOCKS
+#define ICP_PH_DECL unsigned long long ph_t_ = __builtin_amdgcn_s_memrealtime()
+#define ICP_PH(st, k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); (st)->ph[k] += t_ - ph_t_; ph_t_ = t_; } } while (0)
+#else
+#define ICP_PH_DECL do { } while (0)
+#define ICP_PH(st, k) do { } while (0)
+#endif
+
+/* floats as unsigned integers of the same order (atomicMin / atomicMax on floats of either sign) */
+__device__ __forceinline__ uint32_t icp_f2o(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float icp_o2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+
+struct IcpBatch {
+  const float* src; /* the model as given (rows of sstride floats, normal at snoff) */
+  const float* dst;
+  int n, sstride, snoff, nd_all, dstride, dnoff;
+  /* per-job arrays: job j starts at base + j * pitch */
+  float *src0, *dst0, *src_pct;       /* n*6, nd_all*6, n*6 */
+  unsigned long long *best, *owner;   /* n, nd_all */
+  int2* sel;                          /* min(n, nd_all) */
+  double *parts, *sum_src, *sum_dst;  /* p_parts, p_sums, p_sumd */
+  float4* g_pts;                      /* nd_all: x y z + original row index (bits) in leaf order */
+  uint32_t* g_start;                  /* ICP_LEAVES + 1 (pitch ICP_LEAVES + 64) */
+  uint32_t* g_cur;                    /* ICP_LEAVES: rows per leaf, then the scatter cursors */
+  float4* g_box2;                     /* 2 per leaf: lo, hi */
+  uint32_t* g_box1u;                  /* 8 per node: lo xyz -, hi xyz - as ordered-uint coded floats */
+  IcpState2* state;
+  int* h_done;                        /* pinned host memory: done flag per job */
+  size_t p_sel, p_parts, p_sums, p_sumd;
+  int has_init;
+  double T0[ICP_MAX_JOBS][16];        /* initial poses */
+};
+
+__device__ __forceinline__ float icp_wave_minf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ unsigned long long icp_wave_min64(unsigned long long k) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)k, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), o);
+    const unsigned long long y = ((unsigned long long)hi << 32) | lo;
+    k = y < k ? y : k;
+  }
+  return k;
+}
+
+/* prologue 1: src0 = T0 * src (or a copy), dst0 = a copy, and the per-chunk coordinate sums (rows of a chunk in order) */
+__global__ __launch_bounds__(64) void k_icp2_pack_sums(IcpBatch B) {
+  __shared__ float xyz[64][3];
+  const int job = blockIdx.y, lane = threadIdx.x;
+  const int chunks_src = (B.n + ICP_CHUNK - 1) / ICP_CHUNK;
+  const bool is_dst = (int)blockIdx.x >= chunks_src;
+  const int c = is_dst ? (int)blockIdx.x - chunks_src : (int)blockIdx.x;
+  const int rows_all = is_dst ? B.nd_all : B.n;
+  const int i = c * ICP_CHUNK + lane;
+  float o[6] = {0, 0, 0, 0, 0, 0};
+  if (i < rows_all) {
+    const float* p = is_dst ? B.dst + (size_t)i * B.dstride : B.src + (size_t)i * B.sstride;
+    const int noff = is_dst ? B.dnoff : B.snoff;
+    if (!is_dst && B.has_init) {
+      double M[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) M[k] = B.T0[job][k];
+      icp_transform_row(p, p + noff, M, o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { o[k] = p[k]; o[3 + k] = p[noff + k]; }
+    }
+    float* out = is_dst ? B.dst0 + ((size_t)job * B.nd_all + i) * 6 : B.src0 + ((size_t)job * B.n + i) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[k] = o[k];
+  }
+  xyz[lane][0] = o[0]; xyz[lane][1] = o[1]; xyz[lane][2] = o[2];
+  __syncthreads();
+  if (lane == 0) {
+    const int rows = min(ICP_CHUNK, rows_all - c * ICP_CHUNK);
+    double s[3] = {0, 0, 0};
+    for (int k = 0; k < rows; k++) { s[0] += (double)xyz[k][0]; s[1] += (double)xyz[k][1]; s[2] += (double)xyz[k][2]; }
+    double* parts = is_dst ? B.sum_dst + (size_t)job * B.p_sumd + (size_t)c * 3 : B.sum_src + (size_t)job * B.p_sums + (size_t)c * 3;
+    parts[0] = s[0]; parts[1] = s[1]; parts[2] = s[2];
+  }
+  if (is_dst) { /* extent of the scene rows (the centring and scaling that follow are monotone: the grid's extent follows from it) */
+    const bool v = i < rows_all;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = v ? o[k] : __builtin_inff(); hi[k] = v ? o[k] : -__builtin_inff(); }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], sh)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], sh)); }
+    }
+    if (lane == 0) {
+      IcpState2* st = B.state + job;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { /* a thousand blocks per job: only those that move the extent send an atomic (a stale read only lets a redundant one through) */
+        const uint32_t l = icp_f2o(lo[k]), h = icp_f2o(hi[k]);
+        if (l < __hip_atomic_load(&st->raw_lo[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&st->raw_lo[k], l);
+        if (h > __hip_atomic_load(&st->raw_hi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->raw_hi[k], h);
+      }
+    }
+  }
+}
+
+/* before the prologue: the extent accumulators and the leaf counters of every job */
+__global__ __launch_bounds__(256) void k_icp2_reset(IcpBatch B) {
+  const int job = blockIdx.x, tid = threadIdx.x;
+  uint32_t* cur = B.g_cur + (size_t)job * ICP_LEAVES;
+  for (int k = tid; k < ICP_LEAVES; k += 256) cur[k] = 0u;
+  if (tid < 3) { B.state[job].raw_lo[tid] = 0xFFFFFFFFu; B.state[job].raw_hi[tid] = 0u; }
+  for (int k = tid; k < 64 * 8; k += 256) B.g_box1u[(size_t)job * 64 * 8 + k] = (k & 4) ? icp_f2o(-__builtin_inff()) : icp_f2o(__builtin_inff());
+}
+
+/* sums of chunk partials (3 per chunk) in chunk order: thread c < 3 of the block returns the sum of component c.  The partials
+ * go through LDS a tile at a time, loaded by the whole block (one thread reading them from memory one after the other is a
+ * chain of a thousand load latencies).  Called by every thread of the block. */
+constexpr int ICP_SUM_TILE = 1024; /* chunks per tile */
+__device__ __forceinline__ double icp_sum_staged(const double* __restrict__ parts, int chunks, double* lds, int tid, int nthreads) {
+  double acc = 0;
+  for (int c0 = 0; c0 < chunks; c0 += ICP_SUM_TILE) {
+    const int cn = min(ICP_SUM_TILE, chunks - c0);
+    __syncthreads();
+    for (int k = tid; k < cn * 3; k += nthreads) lds[k] = parts[(size_t)c0 * 3 + k];
+    __syncthreads();
+    if (tid < 3)
+      for (int c = 0; c < cn; c++) acc += lds[c * 3 + tid];
+  }
+  return acc;
+}
+
+/* prologue 2: mean_avg = 0.5 * (mean(src0) + mean(dst0)) */
+__global__ __launch_bounds__(256) void k_icp2_mean(IcpBatch B) {
+  __shared__ double m_parts[ICP_SUM_TILE * 3];
+  __shared__ double tot[6];
+  const int job = blockIdx.x, tid = threadIdx.x;
+  const double a_src = icp_sum_staged(B.sum_src + (size_t)job * B.p_sums, (B.n + ICP_CHUNK - 1) / ICP_CHUNK, m_parts, tid, 256);
+  const double a_dst = icp_sum_staged(B.sum_dst + (size_t)job * B.p_sumd, (B.nd_all + ICP_CHUNK - 1) / ICP_CHUNK, m_parts, tid, 256);
+  if (tid < 3) { tot[tid] = a_src; tot[3 + tid] = a_dst; }
+  __syncthreads();
+  if (tid == 0) {
+    IcpState2* st = B.state + job;
+    for (int k = 0; k < 3; k++) {
+      const double ms = tot[k] / (double)B.n, md = tot[3 + k] / (double)B.nd_all;
+      st->mean_avg[k] = 0.5 * (ms + md);
+    }
+  }
+}
+
+/* the centred row as the sequential version stores it: (float)((double)p - mean) */
+__device__ __forceinline__ void icp_centred(const float* __restrict__ p, const double* __restrict__ mean, float* c) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) c[k] = (float)((double)p[k] - mean[k]);
+}
+
+/* prologue 3: per-chunk sums of the centred rows' distances from the origin (rows of a chunk in order) */
+__global__ __launch_bounds__(64) void k_icp2_dist_sums(IcpBatch B) {
+  __shared__ double dist[64];
+  const int job = blockIdx.y, lane = threadIdx.x;
+  const int chunks_src = (B.n + ICP_CHUNK - 1) / ICP_CHUNK;
+  const bool is_dst = (int)blockIdx.x >= chunks_src;
+  const int c = is_dst ? (int)blockIdx.x - chunks_src : (int)blockIdx.x;
+  const int rows_all = is_dst ? B.nd_all : B.n;
+  const int i = c * ICP_CHUNK + lane;
+  const IcpState2* st = B.state + job;
+  double d = 0;
+  if (i < rows_all) {
+    const float* p = is_dst ? B.dst0 + ((size_t)job * B.nd_all + i) * 6 : B.src0 + ((size_t)job * B.n + i) * 6;
+    float cf[3];
+    icp_centred(p, st->mean_avg, cf);
+    d = ppf_sqrt((double)cf[0] * (double)cf[0] + (double)cf[1] * (double)cf[1] + (double)cf[2] * (double)cf[2]);
+  }
+  dist[lane] = d;
+  __syncthreads();
+  if (lane == 0) {
+    const int rows = min(ICP_CHUNK, rows_all - c * ICP_CHUNK);
+    double s = 0;
+    for (int k = 0; k < rows; k++) s += dist[k];
+    double* parts = is_dst ? B.sum_dst + (size_t)job * B.p_sumd + (size_t)c * 3 : B.sum_src + (size_t)job * B.p_sums + (size_t)c * 3;
+    parts[0] = s;
+  }
+}
+
+/* hierarchical leaf id of a cell (cx, cy, cz in 0..15): node (cx/4, cy/4, cz/4) * 64 + child (cx%4, cy%4, cz%4) */
+__device__ __forceinline__ int icp_leaf_id(int cx, int cy, int cz) {
+  return ((((cx >> 2) * 4 + (cy >> 2)) * 4 + (cz >> 2)) << 6) | (((cx & 3) * 4 + (cy & 3)) * 4 + (cz & 3));
+}
+__device__ __forceinline__ int icp_cell_of(float v, float org, float inv_h) {
+  const int c = (int)((v - org) * inv_h); /* NaN -> 0 */
+  return min(max(c, 0), 15);
+}
+
+/* prologue 4, one block per job: scale = n / (0.5 * (sum |src0| + sum |dst0|)), the job's loop state, the grid's geometry
+ * (from the extent of the rows as given, taken through the centring and scaling: both are monotone) */
+__global__ __launch_bounds__(256) void k_icp2_scale(IcpBatch B) {
+  __shared__ double m_parts[ICP_SUM_TILE * 3];
+  __shared__ double tot[2];
+  const int job = blockIdx.x, tid = threadIdx.x;
+  const double a_src = icp_sum_staged(B.sum_src + (size_t)job * B.p_sums, (B.n + ICP_CHUNK - 1) / ICP_CHUNK, m_parts, tid, 256);
+  const double a_dst = icp_sum_staged(B.sum_dst + (size_t)job * B.p_sumd, (B.nd_all + ICP_CHUNK - 1) / ICP_CHUNK, m_parts, tid, 256);
+  if (tid == 0) { tot[0] = a_src; tot[1] = a_dst; } /* component 0: the distance sums */
+  __syncthreads();
+  if (tid != 0) return;
+  IcpState2* st = B.state + job;
+  const double scale = (double)B.n / ((tot[0] + tot[1]) * 0.5);
+  st->scale = scale;
+  float lo[3], hi[3];
+  for (int k = 0; k < 3; k++) {
+    lo[k] = (float)((double)(float)((double)icp_o2f(st->raw_lo[k]) - st->mean_avg[k]) * scale);
+    hi[k] = (float)((double)(float)((double)icp_o2f(st->raw_hi[k]) - st->mean_avg[k]) * scale);
+  }
+  const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  const bool ok = ext > 0.f && ext < 1e30f; /* otherwise every row falls into cell 0 of each axis: still exact, just slow */
+  for (int k = 0; k < 3; k++) st->org[k] = ok ? lo[k] : 0.f;
+  st->inv_h = ok ? 16.0f / (ext * 1.0001f) : 0.f;
+  for (int k = 0; k < 16; k++) { st->pose[k] = (k % 5 == 0) ? 1.0 : 0.0; st->PoseX[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+  st->fval_old = 9999999999.0; st->fval_perc = 0; st->fval_min = 9999999999.0; st->tol_p = 0;
+  st->thr = 0.f; st->n_sel = 0; st->iter = 0; st->max_iter = 0; st->done = 1; st->robust = 0; st->total = 0;
+#ifdef PPF_ICP_CLOCKS
+  for (int k = 0; k < 8; k++) st->ph[k] = 0;
+#endif
+  B.h_done[job] = 1;
+}
+
+/* counter[leaf] += 1 for the active lanes (valid), returning each lane's slot: lanes that name the same leaf as the first
+ * active one share an atomic (scene rows come in scan order: neighbours in memory are neighbours in space), two rounds of
+ * that, the rest one atomic each */
+__device__ __forceinline__ uint32_t icp_leaf_take(uint32_t* __restrict__ counters, const int leaf, bool valid) {
+  uint32_t pos = 0;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    const unsigned long long m = __ballot(valid);
+    if (!m) return pos;
+    const int first = __builtin_ctzll(m);
+    const int l0 = __shfl(leaf, first);
+    const unsigned long long same = __ballot(valid && leaf == l0);
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&counters[l0], (uint32_t)__popcll(same));
+    base = (uint32_t)__shfl((int)base, first);
+    if (valid && leaf == l0) { pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); valid = false; }
+  }
+  if (valid) pos = atomicAdd(&counters[leaf], 1u);
+  return pos;
+}
+
+/* prologue 5: the final rows (centred, scaled) of both clouds, and the scene rows counted per leaf */
+__global__ __launch_bounds__(256) void k_icp2_rows(IcpBatch B) {
+  const int job = blockIdx.y;
+  const IcpState2* st = B.state + job;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double scale = st->scale;
+  int leaf = 0;
+  bool is_scene = false;
+  if (i < B.n) {
+    float* p = B.src0 + ((size_t)job * B.n + i) * 6;
+    float cf[3];
+    icp_centred(p, st->mean_avg, cf);
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = (float)((double)cf[k] * scale);
+  } else if (i - B.n < B.nd_all) {
+    float* p = B.dst0 + ((size_t)job * B.nd_all + (i - B.n)) * 6;
+    float cf[3], v[3];
+    icp_centred(p, st->mean_avg, cf);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v[k] = (float)((double)cf[k] * scale); p[k] = v[k]; }
+    leaf = icp_leaf_id(icp_cell_of(v[0], st->org[0], st->inv_h), icp_cell_of(v[1], st->org[1], st->inv_h), icp_cell_of(v[2], st->org[2], st->inv_h));
+    is_scene = true;
+  }
+  (void)icp_leaf_take(B.g_cur + (size_t)job * ICP_LEAVES, leaf, is_scene);
+}
+
+/* prologue 6, one workgroup per job: where every leaf starts in the leaf-ordered row list */
+__global__ __launch_bounds__(1024) void k_icp2_grid_scan(IcpBatch B) {
+  __shared__ uint32_t wsum[16];
+  const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* cur = B.g_cur + (size_t)job * ICP_LEAVES;
+  uint32_t* g_start = B.g_start + (size_t)job * (ICP_LEAVES + 64);
+  uint32_t c[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { c[k] = cur[tid * 4 + k]; s += c[k]; }
+  uint32_t incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  uint32_t run = base + incl - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { g_start[tid * 4 + k] = run; cur[tid * 4 + k] = run; run += c[k]; }
+  if (tid == 1023) g_start[ICP_LEAVES] = run;
+}
+
+/* prologue 7: the scene rows in leaf order (any order inside a leaf), each with its row index */
+__global__ __launch_bounds__(256) void k_icp2_grid_scatter(IcpBatch B) {
+  const int job = blockIdx.y;
+  const IcpState2* st = B.state + job;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < B.nd_all;
+  const float* p = B.dst0 + ((size_t)job * B.nd_all + (valid ? i : 0)) * 6;
+  const float x = p[0], y = p[1], z = p[2];
+  const int leaf = icp_leaf_id(icp_cell_of(x, st->org[0], st->inv_h), icp_cell_of(y, st->org[1], st->inv_h), icp_cell_of(z, st->org[2], st->inv_h));
+  const uint32_t pos = icp_leaf_take(B.g_cur + (size_t)job * ICP_LEAVES, leaf, valid);
+  if (valid) B.g_pts[(size_t)job * B.nd_all + pos] = make_float4(x, y, z, __int_as_float(i));
+}
+
+/* prologue 8: the real extent of the rows of every leaf (one WAVE per leaf: a leaf on a dense surface holds a thousand rows)
+ * and of every node (ordered-uint atomics on the node's box, reset by k_icp2_reset); an empty one is (+inf, -inf): its lower
+ * bound is +inf */
+__global__ __launch_bounds__(256) void k_icp2_grid_boxes(IcpBatch B) {
+  const int job = blockIdx.y, lane = threadIdx.x & 63;
+  const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6); /* grid.x = ICP_LEAVES / 4 */
+  const uint32_t* g_start = B.g_start + (size_t)job * (ICP_LEAVES + 64);
+  const float4* g_pts = B.g_pts + (size_t)job * B.nd_all;
+  float l[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, h[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  const uint32_t s = g_start[leaf], e = g_start[leaf + 1];
+  for (uint32_t q = s + (uint32_t)lane; q < e; q += 64) {
+    const float4 v = g_pts[q];
+    l[0] = fminf(l[0], v.x); l[1] = fminf(l[1], v.y); l[2] = fminf(l[2], v.z);
+    h[0] = fmaxf(h[0], v.x); h[1] = fmaxf(h[1], v.y); h[2] = fmaxf(h[2], v.z);
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], __shfl_xor(l[k], sh)); h[k] = fmaxf(h[k], __shfl_xor(h[k], sh)); }
+  }
+  if (lane != 0) return;
+  float4* box2 = B.g_box2 + (size_t)job * ICP_LEAVES * 2;
+  box2[leaf * 2] = make_float4(l[0], l[1], l[2], 0.f);
+  box2[leaf * 2 + 1] = make_float4(h[0], h[1], h[2], 0.f);
+  if (e > s) {
+    uint32_t* nb = B.g_box1u + ((size_t)job * 64 + (leaf >> 6)) * 8;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { atomicMin(&nb[k], icp_f2o(l[k])); atomicMax(&nb[4 + k], icp_f2o(h[k])); }
+  }
+}
+
+/* a level starts: its source rows = pose * src0[a * step]; block 0 resets the level's loop state */
+__global__ __launch_bounds__(256) void k_icp2_level_begin(IcpBatch B, int step, int ns, double tol_p, int max_iter, int robust) {
+  const int job = blockIdx.y;
+  IcpState2* st = B.state + job;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < ns) {
+    double M[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M[k] = st->pose[k];
+    const float* p = B.src0 + ((size_t)job * B.n + (size_t)a * step) * 6;
+    float o[6];
+    icp_transform_row(p, p + 3, M, o);
+    float* out = B.src_pct + ((size_t)job * B.n + a) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[k] = o[k];
+  }
+  if (a == 0) {
+    for (int k = 0; k < 16; k++) st->PoseX[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    st->fval_old = 9999999999.0;
+    st->fval_perc = 0;
+    st->fval_min = 9999999999.0;
+    st->tol_p = tol_p;
+    st->iter = 0;
+    st->max_iter = max_iter;
+    st->n_sel = 0;
+    st->robust = robust;
+    st->thr = 0.f;
+    const double fp = 0.0;
+    const int done = (!(fp < (1 + tol_p) && fp > (1 - tol_p)) && 0 < max_iter) ? 0 : 1;
+    st->done = done;
+    B.h_done[job] = done;
+  }
+}
+
+/* squared distance from q to a box (0 inside); an empty box (lo = +inf, hi = -inf) gives +inf */
+__device__ __forceinline__ float icp_box_lb2(const float4 lo, const float4 hi, float qx, float qy, float qz) {
+  const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f), dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f), dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* exact nearest neighbour of every source row of the level: one wave per row (see the header of this section) */
+__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int step, int step_shift) {
+  const int job = blockIdx.y;
+  const IcpState2* st = B.state + job;
+  if (st->done) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long* owner = B.owner + (size_t)job * B.nd_all;
+  for (int b = blockIdx.x * 256 + tid; b < nd; b += gridDim.x * 256) owner[b] = ICP_NONE;
+  const int a = blockIdx.x * 4 + wave;
+  if (a >= ns) return;
+  float qx, qy, qz;
+  {
+    const float* p = B.src_pct + ((size_t)job * B.n + a) * 6;
+    if (st->iter == 0) { /* the level's first pass searches from its rows as they are (`moved = srcPCT`) */
+      qx = p[0]; qy = p[1]; qz = p[2];
+    } else {             /* later passes from PoseX * row: the xyz of transformPCPose */
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = st->PoseX[r * 4] * (double)p[0] + st->PoseX[r * 4 + 1] * (double)p[1] + st->PoseX[r * 4 + 2] * (double)p[2] + st->PoseX[r * 4 + 3];
+      if (ppf_fabs(v[3]) > PPF_EPS) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
+      qx = (float)v[0]; qy = (float)v[1]; qz = (float)v[2];
+    }
+  }
+  unsigned long long key = (unsigned long long)ICP_FLT_MAX_BITS << 32; /* nothing closer than FLT_MAX: index 0, as the sequential loop leaves it */
+  const float* dst0 = B.dst0 + (size_t)job * B.nd_all * 6;
+  if (nd <= ICP_BRUTE_ND) {
+    for (int b = lane; b < nd; b += 64) {
+      const float* q = dst0 + (size_t)b * step * 6;
+      const float dx = qx - q[0], dy = qy - q[1], dz = qz - q[2];
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
+      key = k < key ? k : key;
+    }
+    key = icp_wave_min64(key);
+  } else {
+    const float4* __restrict__ pts = B.g_pts + (size_t)job * B.nd_all;
+    const uint32_t* __restrict__ g_start = B.g_start + (size_t)job * (ICP_LEAVES + 64);
+    const float4* __restrict__ box2 = B.g_box2 + (size_t)job * ICP_LEAVES * 2;
+    const uint32_t* __restrict__ box1u = B.g_box1u + ((size_t)job * 64 + lane) * 8;
+    float ubest = 3.402823466e+38f; /* wave-uniform: smallest distance found so far */
+    auto scan_leaf = [&](const int leaf) {
+      const uint32_t s = g_start[leaf], e = g_start[leaf + 1];
+      for (uint32_t i = s + (uint32_t)lane; i < e; i += 64) {
+        const float4 q = pts[i];
+        const int idx = __float_as_int(q.w);
+        int b;
+        bool in;
+        if (step_shift >= 0) { b = idx >> step_shift; in = (idx & (step - 1)) == 0; }
+        else { b = idx / step; in = b * step == idx; }
+        const float dx = qx - q.x, dy = qy - q.y, dz = qz - q.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
+        if (in) key = k < key ? k : key;
+      }
+      key = icp_wave_min64(key);
+      ubest = __uint_as_float((uint32_t)(key >> 32));
+    };
+    const int own = icp_leaf_id(icp_cell_of(qx, st->org[0], st->inv_h), icp_cell_of(qy, st->org[1], st->inv_h), icp_cell_of(qz, st->org[2], st->inv_h));
+    scan_leaf(own);
+    /* nodes, then the children of an opened node, nearest first: the first one whose bound exceeds the best distance ends
+     * its list (a query far from the data would otherwise open box after box in index order, each a little closer) */
+    float lb1 = icp_box_lb2(make_float4(icp_o2f(box1u[0]), icp_o2f(box1u[1]), icp_o2f(box1u[2]), 0.f),
+                            make_float4(icp_o2f(box1u[4]), icp_o2f(box1u[5]), icp_o2f(box1u[6]), 0.f), qx, qy, qz);
+    lb1 = lb1 != lb1 ? 0.f : lb1; /* a NaN query: every box is opened */
+    while (true) {
+      const float m = icp_wave_minf(lb1);
+      if (m * ICP_LB_SHRINK > ubest) break;
+      const int k1 = __builtin_ctzll(__ballot(lb1 == m));
+      if (lane == k1) lb1 = __builtin_inff();
+      const int c0 = k1 * 64 + lane;
+      float lb2 = icp_box_lb2(box2[c0 * 2], box2[c0 * 2 + 1], qx, qy, qz);
+      lb2 = lb2 != lb2 ? 0.f : lb2;
+      if (c0 == own) lb2 = __builtin_inff(); /* already scanned */
+      while (true) {
+        const float m2 = icp_wave_minf(lb2);
+        if (m2 * ICP_LB_SHRINK > ubest) break;
+        const int k2 = __builtin_ctzll(__ballot(lb2 == m2));
+        if (lane == k2) lb2 = __builtin_inff();
+        scan_leaf(k1 * 64 + k2);
+      }
+    }
+  }
+  if (lane == 0) B.best[(size_t)job * B.n + a] = key;
+}
+
+/* icp_block_select with the histogram updates of a wave combined for its most frequent digit: the distances of one level
+ * share their leading byte (and, for a model thrown off the data, all their bits), and 64 lanes adding to one LDS counter
+ * are 64 serial updates */
+template <class F>
+__device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* hist, uint32_t* sh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t prefix = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int k = tid; k < 256; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      const uint32_t v = i < n ? val(i) : 0u;
+      const bool act = i < n && (v & mask) == prefix;
+      const uint32_t digit = (v >> shift) & 255u;
+      const unsigned long long m = __ballot(act);
+      if (m) {
+        const int first = __builtin_ctzll(m);
+        const uint32_t d0 = (uint32_t)__shfl((int)digit, first);
+        const unsigned long long same = __ballot(act && digit == d0);
+        if (lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+        if (act && digit != d0) atomicAdd(&hist[digit], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) { /* 4 bins per lane, wave scan, the lane whose range holds `rank` picks the bin */
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { c[k] = hist[tid * 4 + k]; s += c[k]; }
+      uint32_t incl = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (tid >= o) incl += up;
+      }
+      uint32_t excl = incl - s;
+      if (rank >= excl && rank < incl) {
+        int b = 0;
+        for (; b < 3; b++) { if (rank < excl + c[b]) break; excl += c[b]; }
+        sh[0] = prefix | ((uint32_t)(tid * 4 + b) << shift);
+        sh[1] = rank - excl;
+      }
+    }
+    __syncthreads();
+    prefix = sh[0];
+    rank = sh[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+/* everything of an iteration after the neighbour search, one workgroup per job (see the header of this section).
+ * Dynamic LDS: max(ns * 4 when staged, 16 waves x 64 x 9 doubles of chunk rows). */
+constexpr int ICP_TAIL_VAL_BYTES = 16 * ICP_CHUNK * 9 * 8;
+__global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, int step, float rej_scale, int staged) {
+  extern __shared__ __align__(16) unsigned char t_dyn[];
+  __shared__ uint32_t hist[256], sh[2], wsum[16];
+  __shared__ double s_tot[ICP_ENTRIES], s_M[6][7];
+  __shared__ float s_thr;
+  __shared__ int s_done, s_nsel;
+  const int job = blockIdx.x;
+  IcpState2* st = B.state + job;
+  if (st->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int robust = st->robust;
+  const unsigned long long* best = B.best + (size_t)job * B.n;
+  unsigned long long* owner = B.owner + (size_t)job * B.nd_all;
+  int2* sel = B.sel + (size_t)job * B.p_sel;
+  double* parts = B.parts + (size_t)job * B.p_parts;
+  const float* src_pct = B.src_pct + (size_t)job * B.n * 6;
+  const float* dst0 = B.dst0 + (size_t)job * B.nd_all * 6;
+  uint32_t* s_bits = reinterpret_cast<uint32_t*>(t_dyn);
+  ICP_PH_DECL;
+  /* 1. rejection threshold */
+  if (robust) {
+    if (staged) {
+      for (int i = tid; i < ns; i += 1024) s_bits[i] = (uint32_t)(best[i] >> 32);
+      __syncthreads();
+    }
+    const uint32_t rank = (uint32_t)((ns - 1) / 2);
+    auto dist_bits = [&](int i) { return staged ? s_bits[i] : (uint32_t)(best[i] >> 32); };
+    const uint32_t med_bits = icp_block_select2(dist_bits, ns, rank, hist, sh);
+    const float med = __uint_as_float(med_bits);
+    const uint32_t mad_bits = icp_block_select2(
+        [&](int i) { return __float_as_uint((float)ppf_fabs((double)__uint_as_float(dist_bits(i)) - (double)med)); }, ns, rank, hist, sh);
+    if (tid == 0) {
+      const float sc = 1.48257968f * __uint_as_float(mad_bits);
+      s_thr = rej_scale * sc + med;
+    }
+    __syncthreads();
+  }
+  ICP_PH(st, 0);
+  /* 2. picky ownership: the closest model row per scene row (ties: smallest model row) */
+  const float thr = robust ? s_thr : 0.f;
+  for (int a0 = 0; a0 < ns; a0 += 1024) {
+    const int a = a0 + tid;
+    const bool valid = a < ns;
+    const unsigned long long k0 = valid ? best[a] : 0ull;
+    const uint32_t dbits = (uint32_t)(k0 >> 32), b = (uint32_t)k0;
+    bool ok = valid && (!robust || __uint_as_float(dbits) < thr);
+    const unsigned long long k = ((unsigned long long)dbits << 32) | (unsigned)a;
+    /* lanes that chose the same scene row as the first pending lane send ONE atomic (their smallest key); four rounds of that,
+     * then one atomic per lane.  A model thrown off the data sends all its rows to a handful of scene rows: without this,
+     * twenty thousand atomics queue up on a few addresses. */
+#pragma unroll 1
+    for (int round = 0; round < 4; round++) {
+      const unsigned long long mask = __ballot(ok);
+      if (!mask) break;
+      const int first = __builtin_ctzll(mask);
+      const uint32_t b_first = (uint32_t)__shfl((int)b, first);
+      const bool mine = ok && b == b_first;
+      const unsigned long long grp = __ballot(mine);
+      if (__popcll(grp) == 1 && round > 0) break; /* the choices differ: no point in peeling them off one by one */
+      const unsigned long long kmin = icp_wave_min64(mine ? k : ICP_NONE);
+      if (lane == first) atomicMin(&owner[b_first], kmin);
+      ok = ok && !mine;
+    }
+    if (ok) atomicMin(&owner[b], k);
+  }
+  __syncthreads();
+  ICP_PH(st, 1);
+  /* 3. ordered compaction by scene row.  The keys were produced by atomics: they are read at the coherence point, coalesced
+   * (thread t reads rows t, t + 1024, ...), 16 loads in flight per thread; a byte per row in LDS says whether it has an owner,
+   * and each thread then walks its own contiguous range of those bytes: only owned rows (a few hundred) are read again. */
+  {
+    unsigned char* s_flag = t_dyn; /* the distance bits staged above are no longer needed */
+    const int cap = (int)(max(staged ? (size_t)ns * 4 : (size_t)0, (size_t)ICP_TAIL_VAL_BYTES));
+    uint32_t done_rows = 0; /* rows of earlier rounds, their owners already written: sel[0 .. done_rows) */
+    for (int r0 = 0; r0 < nd; r0 += cap) {
+      const int rn = min(cap, nd - r0);
+      __syncthreads();
+      for (int b0 = 0; b0 < rn; b0 += 16 * 1024) {
+        unsigned long long o[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) o[u] = icp_ld(&owner[r0 + min(b0 + u * 1024 + tid, rn - 1)]);
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (b0 + u * 1024 + tid < rn) s_flag[b0 + u * 1024 + tid] = o[u] != ICP_NONE ? 1 : 0;
+      }
+      __syncthreads();
+      const int per = (rn + 1023) / 1024;
+      const int b0 = min(rn, tid * per), b1 = min(rn, b0 + per);
+      uint32_t cnt = 0;
+      for (int bb = b0; bb < b1; bb++) cnt += s_flag[bb];
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t base = 0, total = 0;
+      for (int w = 0; w < 16; w++) {
+        if (w < wave) base += wsum[w];
+        total += wsum[w];
+      }
+      uint32_t pos = done_rows + base + incl - cnt;
+      for (int bb = b0; bb < b1; bb++)
+        if (s_flag[bb]) sel[pos++] = make_int2((int)(uint32_t)icp_ld(&owner[r0 + bb]), r0 + bb);
+      done_rows += total;
+    }
+    if (tid == 0) {
+      s_nsel = (int)done_rows;
+      s_done = done_rows <= 6 ? 1 : 0; /* `if (selInd <= 6) break;` */
+    }
+    __syncthreads();
+  }
+  const int n_sel = s_nsel;
+  ICP_PH(st, 2);
+  if (!s_done) {
+    /* 4. chunk sums: wave w takes chunks w, w + 16, ...; rows in parallel, the 28 sums in row order */
+    const int n_chunks = (n_sel + ICP_CHUNK - 1) / ICP_CHUNK;
+    double (*val)[9] = reinterpret_cast<double (*)[9]>(t_dyn + (size_t)wave * ICP_CHUNK * 9 * 8);
+    for (int c = wave; c < n_chunks; c += 16) {
+      const int c0 = c * ICP_CHUNK, rows = min(ICP_CHUNK, n_sel - c0);
+      if (lane < rows) {
+        const int2 ab = sel[c0 + lane];
+        const float* sp_ = src_pct + (size_t)ab.x * 6;
+        const float* d = dst0 + (size_t)ab.y * step * 6;
+        const double sp[3] = {(double)sp_[0], (double)sp_[1], (double)sp_[2]}, dp[3] = {(double)d[0], (double)d[1], (double)d[2]},
+                     nr[3] = {(double)d[3], (double)d[4], (double)d[5]};
+        const double sub[3] = {dp[0] - sp[0], dp[1] - sp[1], dp[2] - sp[2]};
+        val[lane][0] = sp[1] * nr[2] - sp[2] * nr[1];
+        val[lane][1] = sp[2] * nr[0] - sp[0] * nr[2];
+        val[lane][2] = sp[0] * nr[1] - sp[1] * nr[0];
+        val[lane][3] = nr[0]; val[lane][4] = nr[1]; val[lane][5] = nr[2];
+        val[lane][6] = sub[0] * nr[0] + sub[1] * nr[1] + sub[2] * nr[2];
+        double e = 0;
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) { const double df = (double)sp_[cc] - (double)d[cc]; e += df * df; }
+        val[lane][7] = e;
+        val[lane][8] = 1.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < ICP_ENTRIES) {
+        int i = 0, j = 0;
+        if (lane < 21) {
+          int t = lane;
+          while (t >= 6 - i) { t -= 6 - i; i++; }
+          j = i + t;
+        } else if (lane < 27) { i = lane - 21; j = 6; }
+        else { i = 7; j = 8; }
+        double acc = 0;
+        for (int k = 0; k < rows; k++) acc += val[k][i] * val[k][j];
+        parts[(size_t)c * ICP_ENTRIES + lane] = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    ICP_PH(st, 3);
+    /* 5. chunk sums in chunk order, solve, loop state */
+    if (tid < ICP_ENTRIES) s_tot[tid] = icp_sum_parts(parts + tid, n_chunks, ICP_ENTRIES);
+    __syncthreads();
+  }
+  ICP_PH(st, 4);
+  if (tid != 0) return;
+  st->n_sel = n_sel;
+  int done = s_done;
+  if (!done) {
+    int e = 0;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) { s_M[i][j] = s_tot[e]; s_M[j][i] = s_tot[e]; e++; }
+    for (int i = 0; i < 6; i++) s_M[i][6] = s_tot[21 + i];
+    const double fsum = s_tot[27];
+    double trace = 0;
+    for (int i = 0; i < 6; i++) trace += s_M[i][i];
+    bool ok = trace > 0.0;
+    if (ok) {
+      const double lambda = 1e-10 * trace;
+      for (int i = 0; i < 6; i++) s_M[i][i] += lambda;
+      for (int c = 0; c < 6 && ok; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (ppf_fabs(s_M[r][c]) > ppf_fabs(s_M[piv][c])) piv = r;
+        if (ppf_fabs(s_M[piv][c]) < 1e-300) { ok = false; break; }
+        if (piv != c) for (int k = 0; k < 7; k++) { const double tmp = s_M[c][k]; s_M[c][k] = s_M[piv][k]; s_M[piv][k] = tmp; }
+        for (int r = c + 1; r < 6; r++) {
+          const double f = s_M[r][c] / s_M[c][c];
+          for (int k = c; k < 7; k++) s_M[r][k] -= f * s_M[c][k];
+        }
+      }
+    }
+    if (ok) {
+      for (int c = 5; c >= 0; c--) {
+        double sacc = s_M[c][6];
+        for (int k = c + 1; k < 6; k++) sacc -= s_M[c][k] * s_M[k][6];
+        s_M[c][6] = sacc / s_M[c][c];
+      }
+      const double rpy[3] = {s_M[0][6], s_M[1][6], s_M[2][6]}, t[3] = {s_M[3][6], s_M[4][6], s_M[5][6]};
+      if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) ok = false;
+      if (ok) {
+        double P[16];
+        icp_transform_from_euler(rpy, t, P);
+        for (int k = 0; k < 16; k++) st->PoseX[k] = P[k];
+        const double fval = ppf_sqrt(fsum) / (double)ns;
+        const double perc = fval / st->fval_old;
+        st->fval_perc = perc;
+        st->fval_old = fval;
+        if (fval < st->fval_min) st->fval_min = fval;
+        const int it = st->iter + 1;
+        st->iter = it;
+        const double tp = st->tol_p;
+        done = (!(perc < (1 + tp) && perc > (1 - tp)) && it < st->max_iter) ? 0 : 1;
+      }
+    }
+    if (!ok) done = 1;
+  }
+  if (done) { /* the level is over: pose = PoseX * pose (what the host did between levels) */
+    double tmp[16];
+    ppf_mat44_mul(st->PoseX, st->pose, tmp);
+    for (int k = 0; k < 16; k++) st->pose[k] = tmp[k];
+    st->total += st->iter;
+    st->done = 1;
+    __hip_atomic_store(&B.h_done[job], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  ICP_PH(st, 5);
+}
+
 #endif /* PPF_ICP_KERNELS_H */
