@@ -20,6 +20,9 @@ struct IcpScratch {
 
 constexpr int ICP_BATCH = 2;     /* iterations enqueued between two reads of the done flag (measured best of 1..6) */
 /* ICP_MAX_JOBS (ppf_icp_kernels.h): poses refined per batch of launches (legacy path: concurrently, one HIP stream each) */
+#ifndef PPF_ICP_NN_WAVES
+#define PPF_ICP_NN_WAVES 65536   /* batched path: waves of the neighbour search beyond which a wave takes several rows */
+#endif
 #ifndef PPF_ICP_BATCH2
 #define PPF_ICP_BATCH2 2         /* batched path: iterations (two launches each) enqueued between two reads of the done flags */
 #endif
@@ -261,13 +264,16 @@ struct IcpBatchScratch {
   DevBuf<int2> sel;
   DevBuf<double> parts, sum_src, sum_dst;
   DevBuf<float4> g_pts, g_box2;
-  DevBuf<uint32_t> g_start, g_cur, g_box1u;
+  DevBuf<uint32_t> g_start, g_cur, g_box1u, own_a;
+  DevBuf<float> bb_parts;
   DevBuf<IcpState2> state;
   int* h_done = nullptr;        /* pinned: one flag per job, written by the kernels */
-  IcpState2* h_state = nullptr; /* pinned: the jobs' final loop states */
+  IcpState2* h_state = nullptr; /* pinned: the jobs' loop states, written by the kernels when a level ends */
+  unsigned long long* h_ticks = nullptr; /* pinned: finished k_icp2_tail workgroups of the running call */
   ~IcpBatchScratch() {
     if (h_done) (void)hipHostFree(h_done);
     if (h_state) (void)hipHostFree(h_state);
+    if (h_ticks) (void)hipHostFree(h_ticks);
   }
 };
 
@@ -299,17 +305,23 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
   HIPCHK(sc.g_cur.reserve(J * ICP_LEAVES));
   HIPCHK(sc.g_box2.reserve(J * ICP_LEAVES * 2));
   HIPCHK(sc.g_box1u.reserve(J * 64 * 8));
+  HIPCHK(sc.own_a.reserve(J * nd_all));
+  HIPCHK(sc.bb_parts.reserve(J * B.p_sumd * 2));
   HIPCHK(sc.state.reserve(ICP_MAX_JOBS));
   if (!sc.h_done) HIPCHK(hipHostMalloc((void**)&sc.h_done, ICP_MAX_JOBS * sizeof(int), hipHostMallocDefault));
   if (!sc.h_state) HIPCHK(hipHostMalloc((void**)&sc.h_state, ICP_MAX_JOBS * sizeof(IcpState2), hipHostMallocDefault));
+  if (!sc.h_ticks) HIPCHK(hipHostMalloc((void**)&sc.h_ticks, 64, hipHostMallocDefault));
+  *sc.h_ticks = 0ull; /* no kernel of an earlier call is running: every call ends with all of its launches accounted for */
   B.src = d_src; B.dst = d_dst;
   B.n = n; B.sstride = sstride; B.snoff = snoff; B.nd_all = nd_all; B.dstride = dstride; B.dnoff = dnoff;
   B.src0 = sc.src0.p; B.dst0 = sc.dst0.p; B.src_pct = sc.src_pct.p;
   B.best = sc.best.p; B.owner = sc.owner.p; B.sel = sc.sel.p;
   B.parts = sc.parts.p; B.sum_src = sc.sum_src.p; B.sum_dst = sc.sum_dst.p;
-  B.g_pts = sc.g_pts.p; B.g_start = sc.g_start.p; B.g_cur = sc.g_cur.p; B.g_box2 = sc.g_box2.p; B.g_box1u = sc.g_box1u.p;
+  B.g_pts = sc.g_pts.p; B.g_start = sc.g_start.p; B.g_cur = sc.g_cur.p; B.g_box2 = sc.g_box2.p; B.g_box1u = sc.g_box1u.p; B.own_a = sc.own_a.p; B.bb_parts = sc.bb_parts.p;
   B.state = sc.state.p;
   B.h_done = sc.h_done;
+  B.h_ticks = sc.h_ticks;
+  B.h_state = sc.h_state;
   B.has_init = init_poses ? 1 : 0;
   for (int j = 0; j < jobs; j++)
     for (int k = 0; k < 16; k++) B.T0[j][k] = init_poses && init_poses[j] ? init_poses[j][k] : ((k % 5 == 0) ? 1.0 : 0.0);
@@ -322,17 +334,20 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
   const unsigned uj = (unsigned)jobs;
   /* the two clouds packed (the source moved by its job's initial pose), centred on the average of the two means, scaled to
    * unit average distance from the origin; the search grid over each job's scene */
-  k_icp2_reset<<<dim3(uj), dim3(256), 0, st>>>(B);
+  k_icp2_reset<<<dim3(uj, 32), dim3(256), 0, st>>>(B);
   k_icp2_pack_sums<<<dim3((unsigned)(chunks_src + chunks_dst), uj), dim3(64), 0, st>>>(B);
   k_icp2_mean<<<dim3(uj), dim3(256), 0, st>>>(B);
   k_icp2_dist_sums<<<dim3((unsigned)(chunks_src + chunks_dst), uj), dim3(64), 0, st>>>(B);
   k_icp2_scale<<<dim3(uj), dim3(256), 0, st>>>(B);
-  k_icp2_rows<<<dim3((unsigned)(((size_t)n + nd_all + 255) / 256), uj), dim3(256), 0, st>>>(B);
+  const unsigned nb_dst = (unsigned)((nd_all + ICP_ROWS_BLOCK - 1) / ICP_ROWS_BLOCK), nb_src = (unsigned)((n + ICP_ROWS_BLOCK - 1) / ICP_ROWS_BLOCK);
+  k_icp2_rows_count<<<dim3(nb_dst + nb_src, uj), dim3(1024), 0, st>>>(B);
   k_icp2_grid_scan<<<dim3(uj), dim3(1024), 0, st>>>(B);
-  k_icp2_grid_scatter<<<dim3((unsigned)((nd_all + 255) / 256), uj), dim3(256), 0, st>>>(B);
+  k_icp2_grid_scatter<<<dim3(nb_dst, uj), dim3(1024), 0, st>>>(B);
   k_icp2_grid_boxes<<<dim3(ICP_LEAVES / 4, uj), dim3(256), 0, st>>>(B);
   HIPCHK(hipGetLastError());
   const int robust = prm.rejection_scale > 0 ? 1 : 0;
+  unsigned long long tails_launched = 0;
+  bool last_level_waited = false;
   for (int level = prm.num_levels - 1; level >= 0; level--) {
     const double div = std::pow(2.0, (double)level);
     const int num_samples = (int)icp_round((double)n / div);
@@ -342,27 +357,50 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
     const int ns = (n + step - 1) / step, nd = (nd_all + step - 1) / step;
     int step_shift = -1;
     if ((step & (step - 1)) == 0) { step_shift = 0; while ((1 << step_shift) < step) step_shift++; }
-    k_icp2_level_begin<<<dim3((unsigned)((ns + 255) / 256), uj), dim3(256), 0, st>>>(B, step, ns, tol_p, max_iter, robust);
+    k_icp2_level_begin<<<dim3((unsigned)((ns + 255) / 256), uj), dim3(256), 0, st>>>(B, step, ns, tol_p, max_iter, robust, level == 0 ? 1 : 0);
     const int staged = ns <= 32768 ? 1 : 0; /* the level's distances fit LDS (4 bytes each): the selection passes read them there */
     const size_t tail_lds = std::max<size_t>(staged ? (size_t)ns * 4 : 0, (size_t)ICP_TAIL_VAL_BYTES);
-    const unsigned nn_blocks = (unsigned)((ns + 3) / 4);
+    /* rows per wave of the neighbour search: one, unless that makes more waves than the chip holds several times over */
+    const int nn_rows = (int)std::min<long long>(ICP_NN_ROWS, std::max<long long>(1, ((long long)ns * jobs) / PPF_ICP_NN_WAVES));
+    const unsigned nn_blocks = (unsigned)((ns + 4 * nn_rows - 1) / (4 * nn_rows));
     int launched = 0;
     while (true) {
       const int batch = std::min((int)PPF_ICP_BATCH2, max_iter - launched);
       for (int b = 0; b < batch; b++) {
-        k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift);
-        k_icp2_tail<<<dim3(uj), dim3(1024), tail_lds, st>>>(B, ns, nd, step, prm.rejection_scale, staged);
+        k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift, nn_rows);
+        k_icp2_tail<<<dim3(uj), dim3(1024), tail_lds, st>>>(B, ns, nd, step, prm.rejection_scale, staged, level == 0 ? 1 : 0);
       }
       launched += std::max(batch, 0);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(st));
+      if (batch <= 0) break;
+      /* wait for the batch: every k_icp2_tail workgroup, whatever it did, adds one to a counter in pinned memory as its last
+       * act (after its done flag and, at the end of a level, its state); polling that is a few microseconds quicker per
+       * batch than going through the stream (which is only asked when the counter has not moved for a long while) */
+      tails_launched += (unsigned long long)batch * (unsigned long long)jobs;
+      {
+        volatile unsigned long long* ticks = sc.h_ticks;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*ticks < tails_launched) {
+          __builtin_ia32_pause();
+          if ((++spins & 0xFFFFu) == 0) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > 0.05 && hipStreamQuery(st) != hipErrorNotReady) { /* the stream is idle (or broken): nothing more will come */
+              HIPCHK(hipStreamSynchronize(st));
+              if (*ticks < tails_launched) return fail(PPF_ERR_HIP, "ICP: %llu of %llu workgroups reported", (unsigned long long)*ticks, tails_launched);
+            }
+            if (waited > 30.0) return fail(PPF_ERR_HIP, "ICP: timed out waiting for the device");
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
       bool all = true;
-      for (int j = 0; j < jobs; j++) all &= sc.h_done[j] != 0;
+      for (int j = 0; j < jobs; j++) all &= reinterpret_cast<volatile int*>(sc.h_done)[j] != 0;
       if (all || launched >= max_iter) break;
     }
+    last_level_waited = launched > 0;
   }
-  HIPCHK(hipMemcpyAsync(sc.h_state, sc.state.p, J * sizeof(IcpState2), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if (!last_level_waited) HIPCHK(hipStreamSynchronize(st)); /* nothing was polled after the last state went out */
   for (int j = 0; j < jobs; j++) {
     /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
     const IcpState2& h = sc.h_state[j];

@@ -663,11 +663,15 @@ __global__ __launch_bounds__(1024) void k_icp_level_small(const float* __restric
  *                time.  A box is skipped only when its lower bound, shrunk by 1e-4, still exceeds the best distance found,
  *                so the result is the exhaustive search's (smallest float d2, then smallest scene index) -- the key
  *                (distance bits, index) is min-reduced whatever the visiting order.  Coarse levels (few scene rows) scan
- *                them all, 64 per step.  Also clears the ownership keys.
- *   k_icp2_tail  one workgroup per job: rejection threshold (radix select over LDS), picky ownership (atomicMin; a wave
- *                whose points all chose the same scene point -- a model thrown off the data -- sends one atomic, not
- *                64 to one address), ordered compaction, chunk sums, 6x6 solve, loop state; when the level ends it
- *                folds PoseX into the job's pose.  Same arithmetic and orders as the kernels above.
+ *                them all, 64 per step.  A wave takes eight rows in turn and then sends their picky-ownership keys:
+ *                atomicMin of (distance bits, model row) on the scene row each one chose, rows of the wave that chose the same
+ *                scene row combined first (a model thrown off the data sends ALL its rows to one scene row).  The rejection
+ *                threshold is not known yet and need not be: the smallest key of a scene row passes the threshold if
+ *                any key of that row does.
+ *   k_icp2_tail  one workgroup per job: rejection threshold (radix select over LDS), ordered compaction of the scene rows
+ *                whose owner passes it (clearing the keys as it goes), chunk sums, 6x6 solve (one column per lane), loop
+ *                state; when the level ends it folds PoseX into the job's pose.  Same arithmetic and orders as the
+ *                kernels above.
  * The host reads one flag per job (pinned memory, written by k_icp2_tail) after every batch of iterations.
  * ============================================================================================================ */
 constexpr int ICP_MAX_JOBS = 8;     /* poses refined per batch of launches */
@@ -684,7 +688,7 @@ struct IcpState2 {
   float thr;
   float org[3], inv_h; /* grid: cell = (int)((p - org) * inv_h) clamped to 0..15 */
   int n_sel, iter, max_iter, done, robust, total, pad0;
-  uint32_t raw_lo[3], raw_hi[3]; /* extent of the scene rows as given (ordered-uint coded floats; NaN left out) */
+  float raw_lo[3], raw_hi[3];    /* extent of the scene rows as given (NaN left out) */
 #ifdef PPF_ICP_CLOCKS
   unsigned long long ph[8];      /* diagnostic build: ticks of the 100 MHz clock k_icp2_tail's thread 0 spent per phase */
 #endif
@@ -710,6 +714,8 @@ struct IcpBatch {
   unsigned long long *best, *owner;   /* n, nd_all */
   int2* sel;                          /* min(n, nd_all) */
   double *parts, *sum_src, *sum_dst;  /* p_parts, p_sums, p_sumd */
+  float* bb_parts;                    /* 6 per chunk of scene rows: its extent (pitch p_sumd * 2) */
+  uint32_t* own_a;                    /* nd_all: model row of a scene row's owner, between two phases of k_icp2_tail */
   float4* g_pts;                      /* nd_all: x y z + original row index (bits) in leaf order */
   uint32_t* g_start;                  /* ICP_LEAVES + 1 (pitch ICP_LEAVES + 64) */
   uint32_t* g_cur;                    /* ICP_LEAVES: rows per leaf, then the scatter cursors */
@@ -717,10 +723,29 @@ struct IcpBatch {
   uint32_t* g_box1u;                  /* 8 per node: lo xyz -, hi xyz - as ordered-uint coded floats */
   IcpState2* state;
   int* h_done;                        /* pinned host memory: done flag per job */
+  unsigned long long* h_ticks;        /* pinned: k_icp2_tail workgroups that have finished since the call began (the host waits on it) */
+  IcpState2* h_state;                 /* pinned: a job's loop state, copied out by k_icp2_tail when a level ends */
   size_t p_sel, p_parts, p_sums, p_sumd;
   int has_init;
   double T0[ICP_MAX_JOBS][16];        /* initial poses */
 };
+
+static_assert(sizeof(IcpState2) % 8 == 0, "the state is copied to the host in 8-byte words");
+/* the job's loop state to pinned host memory (one thread) */
+__device__ __forceinline__ void icp_publish_state(const IcpBatch& B, int job) {
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(B.state + job);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(B.h_state + job);
+  for (size_t k = 0; k < sizeof(IcpState2) / 8; k++) dst[k] = src[k];
+}
+
+/* one more finished k_icp2_tail workgroup.  `wrote`: the calling thread has stored something the host will read once it sees
+ * the count (done flag, state): the count then goes out with release semantics at system scope, which orders it behind those
+ * stores (waiting for the stores' own completion is not enough: the count is an atomic and travels another way).  A release
+ * also writes the L2 back, so a workgroup that has nothing to show sends a plain one. */
+__device__ __forceinline__ void icp_tick(const IcpBatch& B, bool wrote) {
+  if (wrote) __hip_atomic_fetch_add(B.h_ticks, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_fetch_add(B.h_ticks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ float icp_wave_minf(float v) {
 #pragma unroll
@@ -782,14 +807,10 @@ __global__ __launch_bounds__(64) void k_icp2_pack_sums(IcpBatch B) {
 #pragma unroll
       for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], sh)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], sh)); }
     }
-    if (lane == 0) {
-      IcpState2* st = B.state + job;
+    if (lane == 0) { /* per chunk; k_icp2_mean joins them (a thousand co-resident blocks all found the accumulator "unset" and queued their atomics on six addresses) */
+      float* bb = B.bb_parts + ((size_t)job * B.p_sumd * 2 + (size_t)c * 6);
 #pragma unroll
-      for (int k = 0; k < 3; k++) { /* a thousand blocks per job: only those that move the extent send an atomic (a stale read only lets a redundant one through) */
-        const uint32_t l = icp_f2o(lo[k]), h = icp_f2o(hi[k]);
-        if (l < __hip_atomic_load(&st->raw_lo[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&st->raw_lo[k], l);
-        if (h > __hip_atomic_load(&st->raw_hi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->raw_hi[k], h);
-      }
+      for (int k = 0; k < 3; k++) { bb[k] = lo[k]; bb[3 + k] = hi[k]; }
     }
   }
 }
@@ -799,8 +820,10 @@ __global__ __launch_bounds__(256) void k_icp2_reset(IcpBatch B) {
   const int job = blockIdx.x, tid = threadIdx.x;
   uint32_t* cur = B.g_cur + (size_t)job * ICP_LEAVES;
   for (int k = tid; k < ICP_LEAVES; k += 256) cur[k] = 0u;
-  if (tid < 3) { B.state[job].raw_lo[tid] = 0xFFFFFFFFu; B.state[job].raw_hi[tid] = 0u; }
   for (int k = tid; k < 64 * 8; k += 256) B.g_box1u[(size_t)job * 64 * 8 + k] = (k & 4) ? icp_f2o(-__builtin_inff()) : icp_f2o(__builtin_inff());
+  /* the ownership keys: all "no owner" from here on (k_icp2_tail clears the ones an iteration set) */
+  unsigned long long* owner = B.owner + (size_t)job * B.nd_all;
+  for (int b = blockIdx.y * 256 + tid; b < B.nd_all; b += gridDim.y * 256) owner[b] = ICP_NONE;
 }
 
 /* sums of chunk partials (3 per chunk) in chunk order: thread c < 3 of the block returns the sum of component c.  The partials
@@ -828,12 +851,29 @@ __global__ __launch_bounds__(256) void k_icp2_mean(IcpBatch B) {
   const double a_src = icp_sum_staged(B.sum_src + (size_t)job * B.p_sums, (B.n + ICP_CHUNK - 1) / ICP_CHUNK, m_parts, tid, 256);
   const double a_dst = icp_sum_staged(B.sum_dst + (size_t)job * B.p_sumd, (B.nd_all + ICP_CHUNK - 1) / ICP_CHUNK, m_parts, tid, 256);
   if (tid < 3) { tot[tid] = a_src; tot[3 + tid] = a_dst; }
+  /* the scene's extent from its chunks' */
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  const int chunks_dst = (B.nd_all + ICP_CHUNK - 1) / ICP_CHUNK;
+  for (int c = tid; c < chunks_dst; c += 256) {
+    const float* bb = B.bb_parts + ((size_t)job * B.p_sumd * 2 + (size_t)c * 6);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], bb[k]); hi[k] = fmaxf(hi[k], bb[3 + k]); }
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], sh)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], sh)); }
+  }
+  __shared__ float ext[4][6];
+  if ((tid & 63) == 0) { for (int k = 0; k < 3; k++) { ext[tid >> 6][k] = lo[k]; ext[tid >> 6][3 + k] = hi[k]; } }
   __syncthreads();
   if (tid == 0) {
     IcpState2* st = B.state + job;
     for (int k = 0; k < 3; k++) {
       const double ms = tot[k] / (double)B.n, md = tot[3 + k] / (double)B.nd_all;
       st->mean_avg[k] = 0.5 * (ms + md);
+      st->raw_lo[k] = fminf(fminf(ext[0][k], ext[1][k]), fminf(ext[2][k], ext[3][k]));
+      st->raw_hi[k] = fmaxf(fmaxf(ext[0][3 + k], ext[1][3 + k]), fmaxf(ext[2][3 + k], ext[3][3 + k]));
     }
   }
 }
@@ -897,8 +937,8 @@ __global__ __launch_bounds__(256) void k_icp2_scale(IcpBatch B) {
   st->scale = scale;
   float lo[3], hi[3];
   for (int k = 0; k < 3; k++) {
-    lo[k] = (float)((double)(float)((double)icp_o2f(st->raw_lo[k]) - st->mean_avg[k]) * scale);
-    hi[k] = (float)((double)(float)((double)icp_o2f(st->raw_hi[k]) - st->mean_avg[k]) * scale);
+    lo[k] = (float)((double)(float)((double)st->raw_lo[k] - st->mean_avg[k]) * scale);
+    hi[k] = (float)((double)(float)((double)st->raw_hi[k] - st->mean_avg[k]) * scale);
   }
   const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
   const bool ok = ext > 0.f && ext < 1e30f; /* otherwise every row falls into cell 0 of each axis: still exact, just slow */
@@ -911,54 +951,52 @@ __global__ __launch_bounds__(256) void k_icp2_scale(IcpBatch B) {
   for (int k = 0; k < 8; k++) st->ph[k] = 0;
 #endif
   B.h_done[job] = 1;
+  icp_publish_state(B, job);
 }
 
-/* counter[leaf] += 1 for the active lanes (valid), returning each lane's slot: lanes that name the same leaf as the first
- * active one share an atomic (scene rows come in scan order: neighbours in memory are neighbours in space), two rounds of
- * that, the rest one atomic each */
-__device__ __forceinline__ uint32_t icp_leaf_take(uint32_t* __restrict__ counters, const int leaf, bool valid) {
-  uint32_t pos = 0;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int round = 0; round < 2; round++) {
-    const unsigned long long m = __ballot(valid);
-    if (!m) return pos;
-    const int first = __builtin_ctzll(m);
-    const int l0 = __shfl(leaf, first);
-    const unsigned long long same = __ballot(valid && leaf == l0);
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(&counters[l0], (uint32_t)__popcll(same));
-    base = (uint32_t)__shfl((int)base, first);
-    if (valid && leaf == l0) { pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); valid = false; }
-  }
-  if (valid) pos = atomicAdd(&counters[leaf], 1u);
-  return pos;
-}
-
-/* prologue 5: the final rows (centred, scaled) of both clouds, and the scene rows counted per leaf */
-__global__ __launch_bounds__(256) void k_icp2_rows(IcpBatch B) {
-  const int job = blockIdx.y;
+/* prologue 5: the final rows (centred, scaled) of both clouds; the scene rows counted per leaf.  A block takes 8,192 rows: the
+ * leaf counters are LDS counters first (a dense surface puts a thousand rows into one leaf: that many atomics on one address
+ * in memory take tens of microseconds), a block then adds its non-zero ones to the job's.  Blocks past the scene's take the
+ * model's rows. */
+constexpr int ICP_ROWS_BLOCK = 8192;
+__global__ __launch_bounds__(1024) void k_icp2_rows_count(IcpBatch B) {
+  __shared__ uint32_t hist[ICP_LEAVES];
+  const int job = blockIdx.y, tid = threadIdx.x;
   const IcpState2* st = B.state + job;
-  const int i = blockIdx.x * 256 + threadIdx.x;
   const double scale = st->scale;
-  int leaf = 0;
-  bool is_scene = false;
-  if (i < B.n) {
-    float* p = B.src0 + ((size_t)job * B.n + i) * 6;
-    float cf[3];
-    icp_centred(p, st->mean_avg, cf);
+  const int nb_dst = (B.nd_all + ICP_ROWS_BLOCK - 1) / ICP_ROWS_BLOCK;
+  if ((int)blockIdx.x >= nb_dst) {
+    const int r0 = ((int)blockIdx.x - nb_dst) * ICP_ROWS_BLOCK;
+    for (int u = 0; u < ICP_ROWS_BLOCK / 1024; u++) {
+      const int i = r0 + u * 1024 + tid;
+      if (i < B.n) {
+        float* p = B.src0 + ((size_t)job * B.n + i) * 6;
+        float cf[3];
+        icp_centred(p, st->mean_avg, cf);
 #pragma unroll
-    for (int k = 0; k < 3; k++) p[k] = (float)((double)cf[k] * scale);
-  } else if (i - B.n < B.nd_all) {
-    float* p = B.dst0 + ((size_t)job * B.nd_all + (i - B.n)) * 6;
-    float cf[3], v[3];
-    icp_centred(p, st->mean_avg, cf);
-#pragma unroll
-    for (int k = 0; k < 3; k++) { v[k] = (float)((double)cf[k] * scale); p[k] = v[k]; }
-    leaf = icp_leaf_id(icp_cell_of(v[0], st->org[0], st->inv_h), icp_cell_of(v[1], st->org[1], st->inv_h), icp_cell_of(v[2], st->org[2], st->inv_h));
-    is_scene = true;
+        for (int k = 0; k < 3; k++) p[k] = (float)((double)cf[k] * scale);
+      }
+    }
+    return;
   }
-  (void)icp_leaf_take(B.g_cur + (size_t)job * ICP_LEAVES, leaf, is_scene);
+  for (int k = tid; k < ICP_LEAVES; k += 1024) hist[k] = 0;
+  __syncthreads();
+  const int r0 = (int)blockIdx.x * ICP_ROWS_BLOCK;
+  const float ox = st->org[0], oy = st->org[1], oz = st->org[2], inv_h = st->inv_h;
+  for (int u = 0; u < ICP_ROWS_BLOCK / 1024; u++) {
+    const int i = r0 + u * 1024 + tid;
+    if (i < B.nd_all) {
+      float* p = B.dst0 + ((size_t)job * B.nd_all + i) * 6;
+      float cf[3], v[3];
+      icp_centred(p, st->mean_avg, cf);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { v[k] = (float)((double)cf[k] * scale); p[k] = v[k]; }
+      atomicAdd(&hist[icp_leaf_id(icp_cell_of(v[0], ox, inv_h), icp_cell_of(v[1], oy, inv_h), icp_cell_of(v[2], oz, inv_h))], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* cur = B.g_cur + (size_t)job * ICP_LEAVES;
+  for (int k = tid; k < ICP_LEAVES; k += 1024) { const uint32_t c = hist[k]; if (c) atomicAdd(&cur[k], c); }
 }
 
 /* prologue 6, one workgroup per job: where every leaf starts in the leaf-ordered row list */
@@ -986,17 +1024,40 @@ __global__ __launch_bounds__(1024) void k_icp2_grid_scan(IcpBatch B) {
   if (tid == 1023) g_start[ICP_LEAVES] = run;
 }
 
-/* prologue 7: the scene rows in leaf order (any order inside a leaf), each with its row index */
-__global__ __launch_bounds__(256) void k_icp2_grid_scatter(IcpBatch B) {
-  const int job = blockIdx.y;
+/* prologue 7: the scene rows in leaf order (any order inside a leaf), each with its row index.  Same blocks as the count: a row's
+ * rank among its block's rows of the same leaf comes from the LDS counter, the block's share of the leaf from one atomic on the
+ * leaf's cursor. */
+__global__ __launch_bounds__(1024) void k_icp2_grid_scatter(IcpBatch B) {
+  __shared__ uint32_t hist[ICP_LEAVES];
+  const int job = blockIdx.y, tid = threadIdx.x;
   const IcpState2* st = B.state + job;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = i < B.nd_all;
-  const float* p = B.dst0 + ((size_t)job * B.nd_all + (valid ? i : 0)) * 6;
-  const float x = p[0], y = p[1], z = p[2];
-  const int leaf = icp_leaf_id(icp_cell_of(x, st->org[0], st->inv_h), icp_cell_of(y, st->org[1], st->inv_h), icp_cell_of(z, st->org[2], st->inv_h));
-  const uint32_t pos = icp_leaf_take(B.g_cur + (size_t)job * ICP_LEAVES, leaf, valid);
-  if (valid) B.g_pts[(size_t)job * B.nd_all + pos] = make_float4(x, y, z, __int_as_float(i));
+  for (int k = tid; k < ICP_LEAVES; k += 1024) hist[k] = 0;
+  __syncthreads();
+  const int r0 = (int)blockIdx.x * ICP_ROWS_BLOCK;
+  const float ox = st->org[0], oy = st->org[1], oz = st->org[2], inv_h = st->inv_h;
+  constexpr int U = ICP_ROWS_BLOCK / 1024;
+  float x[U], y[U], z[U];
+  int leaf[U];
+  uint32_t rank[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int i = r0 + u * 1024 + tid;
+    leaf[u] = -1;
+    if (i < B.nd_all) {
+      const float* p = B.dst0 + ((size_t)job * B.nd_all + i) * 6;
+      x[u] = p[0]; y[u] = p[1]; z[u] = p[2];
+      leaf[u] = icp_leaf_id(icp_cell_of(x[u], ox, inv_h), icp_cell_of(y[u], oy, inv_h), icp_cell_of(z[u], oz, inv_h));
+      rank[u] = atomicAdd(&hist[leaf[u]], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* cur = B.g_cur + (size_t)job * ICP_LEAVES;
+  for (int k = tid; k < ICP_LEAVES; k += 1024) { const uint32_t c = hist[k]; hist[k] = c ? atomicAdd(&cur[k], c) : 0u; }
+  __syncthreads();
+  float4* g_pts = B.g_pts + (size_t)job * B.nd_all;
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (leaf[u] >= 0) g_pts[hist[leaf[u]] + rank[u]] = make_float4(x[u], y[u], z[u], __int_as_float(r0 + u * 1024 + tid));
 }
 
 /* prologue 8: the real extent of the rows of every leaf (one WAVE per leaf: a leaf on a dense surface holds a thousand rows)
@@ -1031,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_icp2_grid_boxes(IcpBatch B) {
 }
 
 /* a level starts: its source rows = pose * src0[a * step]; block 0 resets the level's loop state */
-__global__ __launch_bounds__(256) void k_icp2_level_begin(IcpBatch B, int step, int ns, double tol_p, int max_iter, int robust) {
+__global__ __launch_bounds__(256) void k_icp2_level_begin(IcpBatch B, int step, int ns, double tol_p, int max_iter, int robust, int last_level) {
   const int job = blockIdx.y;
   IcpState2* st = B.state + job;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1061,6 +1122,7 @@ __global__ __launch_bounds__(256) void k_icp2_level_begin(IcpBatch B, int step, 
     const int done = (!(fp < (1 + tol_p) && fp > (1 - tol_p)) && 0 < max_iter) ? 0 : 1;
     st->done = done;
     B.h_done[job] = done;
+    if (done && last_level) icp_publish_state(B, job); /* no pass of this level will run */
   }
 }
 
@@ -1070,103 +1132,164 @@ __device__ __forceinline__ float icp_box_lb2(const float4 lo, const float4 hi, f
   return (dx * dx + dy * dy) + dz * dz;
 }
 
-/* exact nearest neighbour of every source row of the level: one wave per row (see the header of this section) */
-__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int step, int step_shift) {
+/* exact nearest neighbour of every source row of the level and the picky-ownership keys (see the header of this section) */
+constexpr int ICP_NN_ROWS = 8; /* rows a wave takes in turn, at most */
+__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int step, int step_shift, int rows) {
   const int job = blockIdx.y;
   const IcpState2* st = B.state + job;
   if (st->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned long long* owner = B.owner + (size_t)job * B.nd_all;
-  for (int b = blockIdx.x * 256 + tid; b < nd; b += gridDim.x * 256) owner[b] = ICP_NONE;
-  const int a = blockIdx.x * 4 + wave;
-  if (a >= ns) return;
-  float qx, qy, qz;
-  {
-    const float* p = B.src_pct + ((size_t)job * B.n + a) * 6;
-    if (st->iter == 0) { /* the level's first pass searches from its rows as they are (`moved = srcPCT`) */
-      qx = p[0]; qy = p[1]; qz = p[2];
-    } else {             /* later passes from PoseX * row: the xyz of transformPCPose */
-      double v[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = st->PoseX[r * 4] * (double)p[0] + st->PoseX[r * 4 + 1] * (double)p[1] + st->PoseX[r * 4 + 2] * (double)p[2] + st->PoseX[r * 4 + 3];
-      if (ppf_fabs(v[3]) > PPF_EPS) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
-      qx = (float)v[0]; qy = (float)v[1]; qz = (float)v[2];
-    }
-  }
-  unsigned long long key = (unsigned long long)ICP_FLT_MAX_BITS << 32; /* nothing closer than FLT_MAX: index 0, as the sequential loop leaves it */
+  const int a0 = (blockIdx.x * 4 + wave) * rows;
+  if (a0 >= ns) return;
   const float* dst0 = B.dst0 + (size_t)job * B.nd_all * 6;
-  if (nd <= ICP_BRUTE_ND) {
-    for (int b = lane; b < nd; b += 64) {
-      const float* q = dst0 + (size_t)b * step * 6;
-      const float dx = qx - q[0], dy = qy - q[1], dz = qz - q[2];
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
-      key = k < key ? k : key;
+  const float4* __restrict__ pts = B.g_pts + (size_t)job * B.nd_all;
+  const uint32_t* __restrict__ g_start = B.g_start + (size_t)job * (ICP_LEAVES + 64);
+  const float4* __restrict__ box2 = B.g_box2 + (size_t)job * ICP_LEAVES * 2;
+  const uint32_t* __restrict__ box1u = B.g_box1u + ((size_t)job * 64 + lane) * 8;
+  const float4 n_lo = make_float4(icp_o2f(box1u[0]), icp_o2f(box1u[1]), icp_o2f(box1u[2]), 0.f);
+  const float4 n_hi = make_float4(icp_o2f(box1u[4]), icp_o2f(box1u[5]), icp_o2f(box1u[6]), 0.f);
+  const bool first_pass = st->iter == 0;
+  double X[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) X[k] = st->PoseX[k];
+  const double X3[4] = {st->PoseX[12], st->PoseX[13], st->PoseX[14], st->PoseX[15]};
+  const float ox = st->org[0], oy = st->org[1], oz = st->org[2], inv_h = st->inv_h;
+  unsigned long long mine = ICP_NONE; /* lane q keeps the key of the wave's q-th row */
+#pragma unroll 1
+  for (int q = 0; q < rows; q++) {
+    const int a = a0 + q;
+    if (a >= ns) break;
+    float qx, qy, qz;
+    {
+      const float* p = B.src_pct + ((size_t)job * B.n + a) * 6;
+      if (first_pass) { /* the level's first pass searches from its rows as they are (`moved = srcPCT`) */
+        qx = p[0]; qy = p[1]; qz = p[2];
+      } else {          /* later passes from PoseX * row: the xyz of transformPCPose */
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 3; r++) v[r] = X[r * 4] * (double)p[0] + X[r * 4 + 1] * (double)p[1] + X[r * 4 + 2] * (double)p[2] + X[r * 4 + 3];
+        v[3] = X3[0] * (double)p[0] + X3[1] * (double)p[1] + X3[2] * (double)p[2] + X3[3];
+        if (ppf_fabs(v[3]) > PPF_EPS) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
+        qx = (float)v[0]; qy = (float)v[1]; qz = (float)v[2];
+      }
     }
-    key = icp_wave_min64(key);
-  } else {
-    const float4* __restrict__ pts = B.g_pts + (size_t)job * B.nd_all;
-    const uint32_t* __restrict__ g_start = B.g_start + (size_t)job * (ICP_LEAVES + 64);
-    const float4* __restrict__ box2 = B.g_box2 + (size_t)job * ICP_LEAVES * 2;
-    const uint32_t* __restrict__ box1u = B.g_box1u + ((size_t)job * 64 + lane) * 8;
-    float ubest = 3.402823466e+38f; /* wave-uniform: smallest distance found so far */
-    auto scan_leaf = [&](const int leaf) {
-      const uint32_t s = g_start[leaf], e = g_start[leaf + 1];
-      for (uint32_t i = s + (uint32_t)lane; i < e; i += 64) {
-        const float4 q = pts[i];
-        const int idx = __float_as_int(q.w);
-        int b;
-        bool in;
-        if (step_shift >= 0) { b = idx >> step_shift; in = (idx & (step - 1)) == 0; }
-        else { b = idx / step; in = b * step == idx; }
-        const float dx = qx - q.x, dy = qy - q.y, dz = qz - q.z;
+    unsigned long long key = (unsigned long long)ICP_FLT_MAX_BITS << 32; /* nothing closer than FLT_MAX: index 0, as the sequential loop leaves it */
+    if (nd <= ICP_BRUTE_ND) {
+      for (int b = lane; b < nd; b += 64) {
+        const float* pq = dst0 + (size_t)b * step * 6;
+        const float dx = qx - pq[0], dy = qy - pq[1], dz = qz - pq[2];
         const float d2 = (dx * dx + dy * dy) + dz * dz;
         const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
-        if (in) key = k < key ? k : key;
+        key = k < key ? k : key;
       }
       key = icp_wave_min64(key);
-      ubest = __uint_as_float((uint32_t)(key >> 32));
-    };
-    const int own = icp_leaf_id(icp_cell_of(qx, st->org[0], st->inv_h), icp_cell_of(qy, st->org[1], st->inv_h), icp_cell_of(qz, st->org[2], st->inv_h));
-    scan_leaf(own);
-    /* nodes, then the children of an opened node, nearest first: the first one whose bound exceeds the best distance ends
-     * its list (a query far from the data would otherwise open box after box in index order, each a little closer) */
-    float lb1 = icp_box_lb2(make_float4(icp_o2f(box1u[0]), icp_o2f(box1u[1]), icp_o2f(box1u[2]), 0.f),
-                            make_float4(icp_o2f(box1u[4]), icp_o2f(box1u[5]), icp_o2f(box1u[6]), 0.f), qx, qy, qz);
-    lb1 = lb1 != lb1 ? 0.f : lb1; /* a NaN query: every box is opened */
-    while (true) {
-      const float m = icp_wave_minf(lb1);
-      if (m * ICP_LB_SHRINK > ubest) break;
-      const int k1 = __builtin_ctzll(__ballot(lb1 == m));
-      if (lane == k1) lb1 = __builtin_inff();
-      const int c0 = k1 * 64 + lane;
-      float lb2 = icp_box_lb2(box2[c0 * 2], box2[c0 * 2 + 1], qx, qy, qz);
-      lb2 = lb2 != lb2 ? 0.f : lb2;
-      if (c0 == own) lb2 = __builtin_inff(); /* already scanned */
+    } else {
+      float ubest = 3.402823466e+38f; /* wave-uniform: smallest distance found so far */
+      auto scan_leaf = [&](const int leaf) {
+        const uint32_t s = g_start[leaf], e = g_start[leaf + 1];
+        for (uint32_t i = s + (uint32_t)lane; i < e; i += 64) {
+          const float4 pq = pts[i];
+          const int idx = __float_as_int(pq.w);
+          int b;
+          bool in;
+          if (step_shift >= 0) { b = idx >> step_shift; in = (idx & (step - 1)) == 0; }
+          else { b = idx / step; in = b * step == idx; }
+          const float dx = qx - pq.x, dy = qy - pq.y, dz = qz - pq.z;
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
+          if (in) key = k < key ? k : key;
+        }
+        key = icp_wave_min64(key);
+        ubest = __uint_as_float((uint32_t)(key >> 32));
+      };
+      const int own = icp_leaf_id(icp_cell_of(qx, ox, inv_h), icp_cell_of(qy, oy, inv_h), icp_cell_of(qz, oz, inv_h));
+      scan_leaf(own);
+      /* nodes, then the children of an opened node, nearest first: the first one whose bound exceeds the best distance ends
+       * its list (a query far from the data would otherwise open box after box in index order, each a little closer) */
+      float lb1 = icp_box_lb2(n_lo, n_hi, qx, qy, qz);
+      lb1 = lb1 != lb1 ? 0.f : lb1; /* a NaN query: every box is opened */
       while (true) {
-        const float m2 = icp_wave_minf(lb2);
-        if (m2 * ICP_LB_SHRINK > ubest) break;
-        const int k2 = __builtin_ctzll(__ballot(lb2 == m2));
-        if (lane == k2) lb2 = __builtin_inff();
-        scan_leaf(k1 * 64 + k2);
+        const float m = icp_wave_minf(lb1);
+        if (m * ICP_LB_SHRINK > ubest) break;
+        const int k1 = __builtin_ctzll(__ballot(lb1 == m));
+        if (lane == k1) lb1 = __builtin_inff();
+        const int c0 = k1 * 64 + lane;
+        float lb2 = icp_box_lb2(box2[c0 * 2], box2[c0 * 2 + 1], qx, qy, qz);
+        lb2 = lb2 != lb2 ? 0.f : lb2;
+        if (c0 == own) lb2 = __builtin_inff(); /* already scanned */
+        while (true) {
+          const float m2 = icp_wave_minf(lb2);
+          if (m2 * ICP_LB_SHRINK > ubest) break;
+          const int k2 = __builtin_ctzll(__ballot(lb2 == m2));
+          if (lane == k2) lb2 = __builtin_inff();
+          scan_leaf(k1 * 64 + k2);
+        }
       }
     }
+    if (lane == 0) B.best[(size_t)job * B.n + a] = key;
+    if (lane == q) mine = key;
   }
-  if (lane == 0) B.best[(size_t)job * B.n + a] = key;
+  /* picky ownership: the scene row each of the wave's rows chose gets atomicMin(distance bits, model row); rows that chose the
+   * same scene row send one atomic with their smallest key */
+  {
+    const uint32_t b_mine = (uint32_t)mine;
+    const bool have = lane < rows && a0 + lane < ns;
+    unsigned long long k = have ? ((mine & 0xFFFFFFFF00000000ull) | (unsigned)(a0 + lane)) : ICP_NONE;
+    bool leader = have;
+#pragma unroll
+    for (int j = 0; j < ICP_NN_ROWS; j++) {
+      const uint32_t bj = (uint32_t)__shfl((int)b_mine, j);
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)k, j), hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), j);
+      const unsigned long long kj = ((unsigned long long)hi << 32) | lo; /* lane j's own key (it is never changed before step j) */
+      const bool valid_j = j < rows && a0 + j < ns;
+      if (have && valid_j && j != lane && bj == b_mine) {
+        if (j < lane) leader = false;      /* an earlier lane speaks for this scene row */
+        else k = kj < k ? kj : k;          /* this lane does: it takes the later lanes' keys in */
+      }
+    }
+    /* only a key that can lower the scene row's current one is sent (a stale read only lets a redundant atomic through): when a
+     * model has been thrown off the data, twenty thousand rows name the same scene row */
+    if (leader) {
+      unsigned long long* o = &B.owner[(size_t)job * B.nd_all + b_mine];
+      if (k < __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(o, k);
+    }
+  }
 }
 
 /* icp_block_select with the histogram updates of a wave combined for its most frequent digit: the distances of one level
  * share their leading byte (and, for a model thrown off the data, all their bits), and 64 lanes adding to one LDS counter
  * are 64 serial updates */
 template <class F>
-__device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* hist, uint32_t* sh) {
+__device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* hist, uint32_t* sh /* 4 words */) {
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t prefix = 0;
+  uint32_t cand = (uint32_t)n; /* values that still share the prefix */
   for (int shift = 24; shift >= 0; shift -= 8) {
+    const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    if (cand <= 256u) {
+      /* few candidates left (a coarse level: from the start): list them, and the one with `rank` smaller ones before it is the
+       * answer -- no further digit passes, each of which costs four barriers whatever it counts */
+      if (tid == 0) sh[3] = 0u;
+      __syncthreads();
+      for (int i = tid; i < n; i += blockDim.x) {
+        const uint32_t v = val(i);
+        if ((v & mask) == prefix) hist[atomicAdd(&sh[3], 1u)] = v;
+      }
+      __syncthreads();
+      if ((uint32_t)tid < cand) {
+        const uint32_t v = hist[tid];
+        uint32_t less = 0, leq = 0;
+        for (uint32_t j = 0; j < cand; j++) { const uint32_t w = hist[j]; less += w < v; leq += w <= v; }
+        if (less <= rank && rank < leq) sh[0] = v;
+      }
+      __syncthreads();
+      const uint32_t r = sh[0];
+      __syncthreads();
+      return r;
+    }
     for (int k = tid; k < 256; k += blockDim.x) hist[k] = 0;
     __syncthreads();
-    const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
     for (int i0 = 0; i0 < n; i0 += blockDim.x) {
       const int i = i0 + tid;
       const uint32_t v = i < n ? val(i) : 0u;
@@ -1198,11 +1321,13 @@ __device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* his
         for (; b < 3; b++) { if (rank < excl + c[b]) break; excl += c[b]; }
         sh[0] = prefix | ((uint32_t)(tid * 4 + b) << shift);
         sh[1] = rank - excl;
+        sh[2] = c[b];
       }
     }
     __syncthreads();
     prefix = sh[0];
     rank = sh[1];
+    cand = sh[2];
     __syncthreads();
   }
   return prefix;
@@ -1211,20 +1336,24 @@ __device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* his
 /* everything of an iteration after the neighbour search, one workgroup per job (see the header of this section).
  * Dynamic LDS: max(ns * 4 when staged, 16 waves x 64 x 9 doubles of chunk rows). */
 constexpr int ICP_TAIL_VAL_BYTES = 16 * ICP_CHUNK * 9 * 8;
-__global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, int step, float rej_scale, int staged) {
+__global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, int step, float rej_scale, int staged, int last_level) {
   extern __shared__ __align__(16) unsigned char t_dyn[];
-  __shared__ uint32_t hist[256], sh[2], wsum[16];
-  __shared__ double s_tot[ICP_ENTRIES], s_M[6][7];
+  __shared__ uint32_t hist[256], sh[4], wsum[16];
+  __shared__ double s_tot[ICP_ENTRIES];
   __shared__ float s_thr;
   __shared__ int s_done, s_nsel;
   const int job = blockIdx.x;
   IcpState2* st = B.state + job;
-  if (st->done) return;
+  if (st->done) { /* this job's level is over: only the host's count of finished workgroups moves */
+    if (threadIdx.x == 0) icp_tick(B, false);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int robust = st->robust;
   const unsigned long long* best = B.best + (size_t)job * B.n;
   unsigned long long* owner = B.owner + (size_t)job * B.nd_all;
   int2* sel = B.sel + (size_t)job * B.p_sel;
+  uint32_t* own_a = B.own_a + (size_t)job * B.nd_all;
   double* parts = B.parts + (size_t)job * B.p_parts;
   const float* src_pct = B.src_pct + (size_t)job * B.n * 6;
   const float* dst0 = B.dst0 + (size_t)job * B.nd_all * 6;
@@ -1233,7 +1362,14 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
   /* 1. rejection threshold */
   if (robust) {
     if (staged) {
-      for (int i = tid; i < ns; i += 1024) s_bits[i] = (uint32_t)(best[i] >> 32);
+      for (int i0 = 0; i0 < ns; i0 += 16 * 1024) { /* sixteen loads in flight per thread */
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = reinterpret_cast<const uint2*>(best)[min(i0 + u * 1024 + tid, ns - 1)].y;
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (i0 + u * 1024 + tid < ns) s_bits[i0 + u * 1024 + tid] = v[u];
+      }
       __syncthreads();
     }
     const uint32_t rank = (uint32_t)((ns - 1) / 2);
@@ -1249,33 +1385,8 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
     __syncthreads();
   }
   ICP_PH(st, 0);
-  /* 2. picky ownership: the closest model row per scene row (ties: smallest model row) */
+  /* 2. (the ownership keys were set by k_icp2_nn) */
   const float thr = robust ? s_thr : 0.f;
-  for (int a0 = 0; a0 < ns; a0 += 1024) {
-    const int a = a0 + tid;
-    const bool valid = a < ns;
-    const unsigned long long k0 = valid ? best[a] : 0ull;
-    const uint32_t dbits = (uint32_t)(k0 >> 32), b = (uint32_t)k0;
-    bool ok = valid && (!robust || __uint_as_float(dbits) < thr);
-    const unsigned long long k = ((unsigned long long)dbits << 32) | (unsigned)a;
-    /* lanes that chose the same scene row as the first pending lane send ONE atomic (their smallest key); four rounds of that,
-     * then one atomic per lane.  A model thrown off the data sends all its rows to a handful of scene rows: without this,
-     * twenty thousand atomics queue up on a few addresses. */
-#pragma unroll 1
-    for (int round = 0; round < 4; round++) {
-      const unsigned long long mask = __ballot(ok);
-      if (!mask) break;
-      const int first = __builtin_ctzll(mask);
-      const uint32_t b_first = (uint32_t)__shfl((int)b, first);
-      const bool mine = ok && b == b_first;
-      const unsigned long long grp = __ballot(mine);
-      if (__popcll(grp) == 1 && round > 0) break; /* the choices differ: no point in peeling them off one by one */
-      const unsigned long long kmin = icp_wave_min64(mine ? k : ICP_NONE);
-      if (lane == first) atomicMin(&owner[b_first], kmin);
-      ok = ok && !mine;
-    }
-    if (ok) atomicMin(&owner[b], k);
-  }
   __syncthreads();
   ICP_PH(st, 1);
   /* 3. ordered compaction by scene row.  The keys were produced by atomics: they are read at the coherence point, coalesced
@@ -1293,8 +1404,17 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
 #pragma unroll
         for (int u = 0; u < 16; u++) o[u] = icp_ld(&owner[r0 + min(b0 + u * 1024 + tid, rn - 1)]);
 #pragma unroll
-        for (int u = 0; u < 16; u++)
-          if (b0 + u * 1024 + tid < rn) s_flag[b0 + u * 1024 + tid] = o[u] != ICP_NONE ? 1 : 0;
+        for (int u = 0; u < 16; u++) { /* an owned row: is its owner within the threshold? which model row?  Its key is cleared for the next pass. */
+          const int bb = b0 + u * 1024 + tid;
+          if (bb < rn) {
+            const bool owned = o[u] != ICP_NONE;
+            s_flag[bb] = owned && (!robust || __uint_as_float((uint32_t)(o[u] >> 32)) < thr) ? 1 : 0;
+            if (owned) {
+              own_a[r0 + bb] = (uint32_t)o[u];
+              __hip_atomic_store(&owner[r0 + bb], ICP_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
       }
       __syncthreads();
       const int per = (rn + 1023) / 1024;
@@ -1316,7 +1436,7 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
       }
       uint32_t pos = done_rows + base + incl - cnt;
       for (int bb = b0; bb < b1; bb++)
-        if (s_flag[bb]) sel[pos++] = make_int2((int)(uint32_t)icp_ld(&owner[r0 + bb]), r0 + bb);
+        if (s_flag[bb]) sel[pos++] = make_int2((int)own_a[r0 + bb], r0 + bb);
       done_rows += total;
     }
     if (tid == 0) {
@@ -1375,66 +1495,102 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
     __syncthreads();
   }
   ICP_PH(st, 4);
-  if (tid != 0) return;
-  st->n_sel = n_sel;
+  if (wave != 0) return;
   int done = s_done;
   if (!done) {
-    int e = 0;
-    for (int i = 0; i < 6; i++)
-      for (int j = i; j < 6; j++) { s_M[i][j] = s_tot[e]; s_M[j][i] = s_tot[e]; e++; }
-    for (int i = 0; i < 6; i++) s_M[i][6] = s_tot[21 + i];
+    /* the damped 6x6 system, one COLUMN per lane (lanes 0..5: the matrix, lane 6: the right-hand side): the row operations
+     * of the elimination are the sequential solve's, element for element; the back substitution runs on lane 0 */
+    double col[6];
+    {
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) { if (lane == j) col[i] = s_tot[e]; if (lane == i) col[j] = s_tot[e]; e++; }
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (lane == 6) col[i] = s_tot[21 + i];
+      if (lane > 6) { for (int i = 0; i < 6; i++) col[i] = 0; }
+    }
     const double fsum = s_tot[27];
+    auto bcast = [&](double v, int src) {
+      const int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
     double trace = 0;
-    for (int i = 0; i < 6; i++) trace += s_M[i][i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) trace += bcast(col[i], i); /* M[i][i] in order */
     bool ok = trace > 0.0;
     if (ok) {
       const double lambda = 1e-10 * trace;
-      for (int i = 0; i < 6; i++) s_M[i][i] += lambda;
-      for (int c = 0; c < 6 && ok; c++) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (lane == i) col[i] += lambda;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        /* pivot: the first largest |M[r][c]|, r >= c (lane c holds column c) */
         int piv = c;
-        for (int r = c + 1; r < 6; r++) if (ppf_fabs(s_M[r][c]) > ppf_fabs(s_M[piv][c])) piv = r;
-        if (ppf_fabs(s_M[piv][c]) < 1e-300) { ok = false; break; }
-        if (piv != c) for (int k = 0; k < 7; k++) { const double tmp = s_M[c][k]; s_M[c][k] = s_M[piv][k]; s_M[piv][k] = tmp; }
+        double pv = ppf_fabs(col[c]);
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) { const double av = ppf_fabs(col[r]); if (av > pv) { pv = av; piv = r; } }
+        piv = __shfl(piv, c);
+        pv = bcast(pv, c);
+        if (pv < 1e-300) { ok = false; break; }
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) if (r == piv) { const double tmp = col[c]; col[c] = col[r]; col[r] = tmp; }
+        const double dcc = bcast(col[c], c);
+#pragma unroll
         for (int r = c + 1; r < 6; r++) {
-          const double f = s_M[r][c] / s_M[c][c];
-          for (int k = c; k < 7; k++) s_M[r][k] -= f * s_M[c][k];
+          const double f = bcast(col[r], c) / dcc;
+          if (lane >= c && lane < 7) col[r] -= f * col[c];
         }
       }
     }
-    if (ok) {
-      for (int c = 5; c >= 0; c--) {
-        double sacc = s_M[c][6];
-        for (int k = c + 1; k < 6; k++) sacc -= s_M[c][k] * s_M[k][6];
-        s_M[c][6] = sacc / s_M[c][c];
-      }
-      const double rpy[3] = {s_M[0][6], s_M[1][6], s_M[2][6]}, t[3] = {s_M[3][6], s_M[4][6], s_M[5][6]};
-      if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) ok = false;
+    double M[6][7];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 7; j++) M[i][j] = bcast(col[i], j);
+    if (lane == 0) {
       if (ok) {
-        double P[16];
-        icp_transform_from_euler(rpy, t, P);
-        for (int k = 0; k < 16; k++) st->PoseX[k] = P[k];
-        const double fval = ppf_sqrt(fsum) / (double)ns;
-        const double perc = fval / st->fval_old;
-        st->fval_perc = perc;
-        st->fval_old = fval;
-        if (fval < st->fval_min) st->fval_min = fval;
-        const int it = st->iter + 1;
-        st->iter = it;
-        const double tp = st->tol_p;
-        done = (!(perc < (1 + tp) && perc > (1 - tp)) && it < st->max_iter) ? 0 : 1;
+#pragma unroll
+        for (int c = 5; c >= 0; c--) {
+          double sacc = M[c][6];
+#pragma unroll
+          for (int k = c + 1; k < 6; k++) sacc -= M[c][k] * M[k][6];
+          M[c][6] = sacc / M[c][c];
+        }
+        const double rpy[3] = {M[0][6], M[1][6], M[2][6]}, t[3] = {M[3][6], M[4][6], M[5][6]};
+        if (rpy[0] != rpy[0] || rpy[1] != rpy[1] || rpy[2] != rpy[2] || t[0] != t[0] || t[1] != t[1] || t[2] != t[2]) ok = false;
+        if (ok) {
+          double P[16];
+          icp_transform_from_euler(rpy, t, P);
+          for (int k = 0; k < 16; k++) st->PoseX[k] = P[k];
+          const double fval = ppf_sqrt(fsum) / (double)ns;
+          const double perc = fval / st->fval_old;
+          st->fval_perc = perc;
+          st->fval_old = fval;
+          if (fval < st->fval_min) st->fval_min = fval;
+          const int it = st->iter + 1;
+          st->iter = it;
+          const double tp = st->tol_p;
+          done = (!(perc < (1 + tp) && perc > (1 - tp)) && it < st->max_iter) ? 0 : 1;
+        }
       }
+      if (!ok) done = 1;
     }
-    if (!ok) done = 1;
   }
+  if (lane != 0) return;
+  st->n_sel = n_sel;
   if (done) { /* the level is over: pose = PoseX * pose (what the host did between levels) */
     double tmp[16];
     ppf_mat44_mul(st->PoseX, st->pose, tmp);
     for (int k = 0; k < 16; k++) st->pose[k] = tmp[k];
     st->total += st->iter;
     st->done = 1;
+    if (last_level) icp_publish_state(B, job); /* what the host needs in the end: pose, residual, iterations, centring, scale */
     __hip_atomic_store(&B.h_done[job], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   ICP_PH(st, 5);
+  icp_tick(B, done != 0); /* after everything this thread wrote for the host */
 }
 
 #endif /* PPF_ICP_KERNELS_H */
