@@ -32,7 +32,10 @@ The ONE line printed by rank 0 carries
   issue_roofline / lds_roofline   what actually bounds k_vote: LDS wave-instructions and atomic lane-operations per second
   host_entry     (N = 1, c2) the call the reference really makes: ppf_match from HOST memory, upload and read-back
                  included (SURVEY section 8d's "poses/s per crop"), on a warm context
-  other_configs  (N = 1, c2) C4 and C5 measured in the same run, 2 steps each, with the same roofline fields
+  other_configs  (N = 1, c2) C4 and C5 measured in the same run, 2 steps each, with the same roofline fields, and c1_pipeline:
+                 the call the reference's main() makes on its own depth frame (crop -> voxel -> SOR -> normals -> edges ->
+                 match_S2B, not presampled -> ICP of the top 5): frame_to_pose_ms with prep_ms / match_ms / icp_ms, the CPU
+                 oracles' time for the same chain beside it
   pipelined      (N = 1, c2) throughput with two independent crops in flight (extra information, never `value`)
   cpu_baseline   the CPU oracle (kind "port", -O3 -march=native build made on this box) on a bounded sample of the
                  same workload: min and median of 5 repetitions on all usable cores plus a 1-thread figure; N = 1 only
@@ -171,6 +174,11 @@ def kernel_source_hash():
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
+    # ... and the flags they are compiled with, and whether another library than the in-tree build is loaded (PPF_HIP_LIB: a
+    # variant or diagnostic build carries its own -D switches): a counter pass is only this run's if all of that agrees
+    import __graft_entry__ as G
+    h.update(" ".join(G.HIP_FLAGS).encode())
+    h.update(("lib:" + os.path.basename(os.environ["PPF_HIP_LIB"])).encode() if os.environ.get("PPF_HIP_LIB") else b"lib:in-tree")
     return h.hexdigest()
 
 
@@ -348,6 +356,87 @@ def host_entry(det, scene, n_ref, resident_ms, reps=12, warm=3):
         "sample": f"median of {reps} calls after {1 + warm} warm-up calls on the same crop; first call of the detector "
                   f"(cold context: counting pass + scratch allocation) {first * 1e3:.2f} ms",
     }
+
+
+def c1_pipeline(bottle, reps=12, warm=3, with_cpu=True):
+    """The call the reference's main() really makes (src/YOLO_cropping_ppf_test.cpp:91-122), on its own depth frame
+    (tests/golden/c1_depth_window.npz) with its parameters: upload -> SceneCropping -> Subsampling -> OutlierProcessing ->
+    NormalEstimation -> EdgeExtraction -> PointCloudXYZNormalToMat x2 -> Matching_S2B = match_S2B(0.05, 0.05), not presampled,
+    + ICP(100, 0.005, 2.5, 8) on the top 5 (CloudProcessing.h:494-499 and :518-528 are the reference's own two timing
+    brackets).  Wall clock around the whole chain, clouds resident on the device between the stages; the CPU oracles' time for
+    the same chain beside it (one run; the table is trained once, outside both)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import prep_data as D
+    from yolo_ppf_pose_estimation_amd.cloud_processor import CloudProcessor
+    xyz, depth, box, intr = D.c1_frame()
+    K = np.array([[intr[0], 0, intr[2]], [0, intr[1], intr[3]], [0, 0, 1.0]])
+    leaf, sor = 0.003, 1.0
+    t0 = time.perf_counter()
+    trainer = CloudProcessor(None, None, [], [], [], 0.025, 0.05)
+    trainer.LoadSingleModel(bottle, "bottle")
+    trainer.TrainDetector(0.025, 0.05)  # the reference's parameters (CloudProcessing.h:64-65)
+    train_ms = (time.perf_counter() - t0) * 1e3
+    frames, parts, last = [], [], None
+    for it in range(warm + reps):
+        t0 = time.perf_counter()
+        cp = CloudProcessor(xyz, depth, [box], [39], [0], 0.025, 0.05)
+        cp.models, cp.detectors, cp.if_trained = trainer.models, trainer.detectors, trainer.if_trained
+        cp.label_to_id, cp.id_to_label, cp._model_clouds = trainer.label_to_id, trainer.id_to_label, trainer._model_clouds
+        cp.SceneCropping(K)
+        cp.Subsampling(leaf)
+        cp.OutlierProcessing(50, sor)
+        cp.NormalEstimation(30)
+        cp.EdgeExtraction(0.03)
+        obj = cp.PointCloudXYZNormalToMat(cp.objects_with_normals[0], resident=True)
+        edge = cp.PointCloudXYZNormalToMat(cp.objects_edges[0], resident=True)
+        t1 = time.perf_counter()
+        pose = cp.Matching_S2B("bottle", obj, edge)
+        t2 = time.perf_counter()
+        if it >= warm:
+            frames.append((t2 - t0) * 1e3)
+            parts.append(((t1 - t0) * 1e3, cp.timings["match"] * 1e3, cp.timings["icp"] * 1e3))
+        last = (pose, len(obj), len(edge))
+    pose, n_obj, n_edge = last
+    med = lambda v: float(np.median(np.asarray(v)))
+    out = {"workload": "C1: the reference's depth frame (166,718 valid pixels), its bbox, model trained at 0.025 / 0.05; crop -> voxel 3 mm -> "
+                       "SOR(50, 1.0) -> normals(30) -> edges(0.03) -> match_S2B(0.05, 0.05), not presampled -> ICP(100, 0.005, 2.5, 8) on the top 5",
+           "frame_points": int(xyz.shape[0]), "object_points": n_obj, "edge_points": n_edge,
+           "model_sampled_points": trainer.detectors[0].info()["n_ref"],
+           "frame_to_pose_ms": med(frames), "frame_to_pose_ms_min": float(min(frames)),
+           "prep_ms": med([p[0] for p in parts]), "match_ms": med([p[1] for p in parts]), "icp_ms": med([p[2] for p in parts]),
+           "train_ms_once": train_ms, "votes": int(pose.numVotes), "residual": float(pose.residual),
+           "sample": f"median of {reps} frames after {warm} warm-up frames; match_ms / icp_ms are the two brackets the reference prints"}
+    golden = os.path.join(ROOT, "tests", "golden", "c1_pipeline_golden.npz")
+    if os.path.exists(golden):
+        g = np.load(golden)
+        out["equals_oracle_golden"] = bool(int(g["top_votes"][0]) == int(pose.numVotes) and float(g["icp_residuals"][0]) == float(pose.residual)
+                                           and int(g["n_object"]) == n_obj and int(g["n_edge"]) == n_edge)
+    if with_cpu:
+        import oracle_lib as O
+        t0 = time.perf_counter()
+        keep, _ = O.prep_crop(xyz, box, depth, intr)
+        v = O.prep_voxel(xyz[keep], leaf)
+        k2, _, _ = O.prep_sor(v, 50, sor)
+        v = v[k2]
+        nrm, curv = O.prep_normals(v, 30)
+        o_obj = O.prep_to_mat(v, nrm)
+        o_edge = O.prep_to_mat(v[curv > 0.03], nrm[curv > 0.03])
+        t1 = time.perf_counter()
+        ora = O.OracleDetector(0.025, 0.05).train_model(bottle)
+        t2 = time.perf_counter()
+        threads = min(O.max_threads(), usable_cpus())
+        m = ora.match(o_obj, edge=o_edge, relative_scene_sample_step=0.05, relative_scene_distance=0.05, cluster=True, threads=threads)
+        t3 = time.perf_counter()
+        P, res, its = O.icp_refine(bottle, o_obj, [q["pose"] for q in m["poses"][:5]])
+        t4 = time.perf_counter()
+        out["cpu_oracles"] = {"frame_to_pose_ms": ((t1 - t0) + (t3 - t2) + (t4 - t3)) * 1e3, "prep_ms": (t1 - t0) * 1e3,
+                              "match_ms": (t3 - t2) * 1e3, "icp_ms": (t4 - t3) * 1e3, "train_ms_once": (t2 - t1) * 1e3,
+                              "threads": threads, "kind": "port", "runs": 1,
+                              "note": "match on `threads` threads over reference points (where upstream puts its omp parallel for); the stage and ICP oracles "
+                                      "use their own OpenMP loops (kNN, neighbour search)",
+                              "same_result": bool(m["poses"][0]["num_votes"] == pose.numVotes and float(res[0]) == float(pose.residual))}
+    return out
 
 
 def main(argv=None):
@@ -665,6 +754,9 @@ def main(argv=None):
                                    kernel_ms_note="sums over the 32 matches of one extra step run on a single lane (each kernel alone on the device); "
                                                   "lanes_overlapped = the same sums over the timed steps, whose lanes overlap and stretch every "
                                                   "kernel's event time")
+                del r5
+                torch.cuda.empty_cache()
+                other["c1_pipeline"] = c1_pipeline(bottle, with_cpu=not args.no_cpu_baseline)
                 line["other_configs"] = other
         print(json.dumps(line), flush=True)
     if world > 1:
