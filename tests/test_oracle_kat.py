@@ -304,3 +304,73 @@ def test_det_and_libm_modes_agree_on_votes(bottle):
     same = (a["triples"] == b["triples"]).all(axis=1).mean()
     assert same >= 0.98  # differences, if any, are single last-ulp bin flips
     assert abs(int(a["votes_per_ref"].sum()) - int(b["votes_per_ref"].sum())) <= 1e-4 * int(a["votes_per_ref"].sum())
+
+
+def test_tiny_case_accumulators_from_an_independent_numpy_voter():
+    """Second source for the 6-point model / 8-point scene of oracle_golden.npz: a voter written from SURVEY.md section 8a alone
+    (feature -> 4 ints -> MurmurHash3_x64_128 low word -> `hash % slots` bucket walk without key comparison -> alpha bin over
+    4 pi -> accumulator -> strict-> argmax), plain Python / numpy, nothing shared with oracle_lib or the C++ oracle.  It must
+    reproduce the oracle's FULL accumulator dump and vote triples.  (Says nothing about the reference -- parity stays
+    unpinned -- but a silent slip of the oracle can no longer redefine "green".)"""
+    import math
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
+    model, scene = g["tiny_model"].astype(np.float64), g["tiny_scene"].astype(np.float64)
+    A, M64 = 30, (1 << 64) - 1
+    astep = (360.0 / A) * math.pi / 180.0
+    ext = g["tiny_model"][:, :3].max(0) - g["tiny_model"][:, :3].min(0)
+    dstep = float(np.float32(math.sqrt(float((ext.astype(np.float64) ** 2).sum())) * 0.05))
+    slots = max(16, 1 << (len(model) ** 2 - 1).bit_length())
+    rotl = lambda x, r: ((x << r) | (x >> (64 - r))) & M64
+
+    def fmix(k):
+        k ^= k >> 33; k = k * 0xff51afd7ed558ccd & M64; k ^= k >> 33; k = k * 0xc4ceb9fe1a85ec53 & M64
+        return k ^ (k >> 33)
+
+    def murmur_low32(keys):  # MurmurHash3_x64_128 of four int32 (16 bytes, little endian), seed 42: low word of h1
+        c1, c2, h1, h2 = 0x87c37b91114253d5, 0x4cf5ad432745937f, 42, 42
+        w = [k & 0xFFFFFFFF for k in keys]
+        k1, k2 = w[0] | w[1] << 32, w[2] | w[3] << 32
+        k1 = rotl(k1 * c1 & M64, 31) * c2 & M64; h1 ^= k1; h1 = (rotl(h1, 27) + h2) & M64; h1 = (h1 * 5 + 0x52dce729) & M64
+        k2 = rotl(k2 * c2 & M64, 33) * c1 & M64; h2 ^= k2; h2 = (rotl(h2, 31) + h1) & M64; h2 = (h2 * 5 + 0x38495ab5) & M64
+        h1 ^= 16; h2 ^= 16; h1 = (h1 + h2) & M64; h2 = (h2 + h1) & M64
+        h1, h2 = fmix(h1), fmix(h2)
+        return ((h1 + h2) & M64) & 0xFFFFFFFF
+
+    def slot_of(p1, n1, p2, n2):
+        d = p2 - p1; f3 = math.sqrt(float(d @ d)); d = d / f3
+        f = [math.acos(float(n1 @ d)), math.acos(float(n2 @ d)), math.acos(float(n1 @ n2))]
+        return murmur_low32([int(v / astep) for v in f] + [int(f3 / dstep)]) % slots
+
+    def frame(p, n):  # rotation taking n onto +x (Rodrigues about (0, n.z, -n.y)), t = -R p
+        ang, ax = math.acos(n[0]), np.array([0.0, n[2], -n[1]])
+        ax = ax / np.linalg.norm(ax) if (n[1] != 0 or n[2] != 0) else np.array([0.0, 1.0, 0.0])
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = math.cos(ang) * np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * np.outer(ax, ax)
+        return R, -R @ p
+
+    def alpha(R, t, p2):
+        q = t + R @ p2
+        a = math.atan2(-q[2], q[1])
+        return -(-a if math.sin(a) * q[2] < 0 else a)
+
+    table = {}
+    for i in range(len(model)):
+        R, t = frame(model[i, :3], model[i, 3:])
+        for j in range(len(model)):
+            if j != i:
+                table.setdefault(slot_of(model[i, :3], model[i, 3:], model[j, :3], model[j, 3:]), []).append(
+                    (i, float(np.float32(alpha(R, t, model[j, :3])))))
+    acc = np.zeros((len(scene), len(model) * A), dtype=np.uint32)
+    for i in range(len(scene)):
+        R, t = frame(scene[i, :3], scene[i, 3:])
+        for j in range(len(scene)):
+            if j != i:
+                a_s = alpha(R, t, scene[j, :3])
+                for im, am in table.get(slot_of(scene[i, :3], scene[i, 3:], scene[j, :3], scene[j, 3:]), []):
+                    flat = im * A + int(A * (am - a_s + 2 * math.pi) / (4 * math.pi))
+                    if flat < acc.shape[1]:
+                        acc[i, flat] += 1
+    np.testing.assert_array_equal(acc.reshape(len(scene), len(model), A), g["tiny_acc"])
+    flat = acc.argmax(1)  # numpy's argmax returns the first maximum: model row ascending, bin ascending, strict >
+    np.testing.assert_array_equal(np.stack([flat // A, flat % A, acc.max(1)], 1).astype(np.uint32), g["tiny_triples"])
+    assert int(g["tiny_info"][0]) == slots and int(g["tiny_info"][1]) == A
