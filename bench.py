@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--shard", default="crops", choices=["crops", "refs"],
                     help="c4 at N > 1: 'refs' strides the reference points of the one scene over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU baseline: seconds per repetition")
-    ap.add_argument("--cells", choices=["auto", "32"], default="auto",
+    ap.add_argument("--cells", choices=["auto", "32", "16", "limit"], default="auto",
                     help="accumulator cells of the vote kernel: auto = 16-bit, 32-bit for what overflows (the library's default); "
                          "32 = 32-bit from the first call (profiling a workload that always overflows, e.g. c4)")
     ap.add_argument("--pipeline-depth", type=int, default=1,
@@ -498,6 +498,24 @@ def main(argv=None):
 
     assert torch.cuda.current_device() == device_index, "the rank's current device is not its own"
     bottle = W.bottle()
+    if world > 1:
+        # one line per rank on stderr before the first step: a wrong placement on an 8-GPU box shows in the run's tail
+        def pci_bus_id(dev):
+            try:
+                import ctypes as C
+                buf = C.create_string_buffer(64)
+                hip = C.CDLL("libamdhip64.so")  # the runtime _capi.lib() made the process-wide one
+                return buf.value.decode() if hip.hipDeviceGetPCIBusId(buf, 64, int(dev)) == 0 and buf.value else "?"
+            except Exception:  # noqa: BLE001
+                p = torch.cuda.get_device_properties(dev)
+                return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+        _capi.lib()
+        probe = PPF3DDetector(0.2, 0.05).trainModel(bottle[::50])  # a throw-away table: where does THIS rank's engine put its memory?
+        sys.stderr.write(f"bench.py rank {rank}/{world}: local_rank {local_rank} torch.cuda.current_device {torch.cuda.current_device()} "
+                         f"ppf_model_get_device {probe.device()} pci {pci_bus_id(torch.cuda.current_device())} backend {backend} "
+                         f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}\n")
+        sys.stderr.flush()
+        del probe
     step_stride = int(1.0 / W.SCENE_STEP)
     src_hash = kernel_source_hash()
 
@@ -525,9 +543,9 @@ def main(argv=None):
         # wherever the sequence starts.
         streams = [torch.cuda.Stream() for _ in range(1 if depth == 1 else 4)]
         wss = [Workspace(timing=True) for _ in range(depth)]
-        if cells == "32":
+        if cells != "auto":  # 32: 32-bit cells for everything; 16: 16-bit cells first, always; limit: a learned per-item vote limit
             for w_ in wss:
-                w_.set_option(_capi.PPF_OPT_ACC32, 1)
+                w_.set_option(_capi.PPF_OPT_ACC32, {"32": 1, "16": 2, "limit": 3}[cells])
         n_ref_total = (n_scene + step_stride - 1) // step_stride
         ref_kw = {"ref_offset": rank, "ref_stride": world, "skip_clustering": True} if shard else {}
         n_ref_max = (n_ref_total + world - 1) // world

@@ -177,7 +177,7 @@ typedef struct ppf_match_stats {
   int32_t n_batches;       /* batches of reference points the call was cut into */
   int32_t n_retries;       /* repeats because the hit pools (sized from earlier calls) were too small */
   uint64_t n_acc32_items;  /* (reference point, accumulator tile)s voted with 32-bit cells: those whose 16-bit cells overflowed, or all
-                              of them once a workspace has seen a tenth of a call's votes cast in such ones (or with PPF_OPT_ACC32) */
+                              of them once a workspace has seen a twentieth of a call's votes cast twice (or with PPF_OPT_ACC32 = 1) */
   uint64_t n_tables;       /* count tables built for the runs of many hits (one per 191 hits of such a run) */
   uint64_t phase_clocks[8]; /* zero, except in a diagnostic build of the library (-DPPF_PHASE_CLOCKS): shader clocks the voting kernel's waves spent per phase */
 } ppf_match_stats;
@@ -228,6 +228,12 @@ ppf_status ppf_model_release(ppf_model* m);
 ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info);
 /* HIP device the model's table lives on (the current device of the thread that trained or loaded it) */
 ppf_status ppf_model_get_device(const ppf_model* m, int* device);
+/* The host-buffer entries (ppf_match, ppf_raw_votes, ppf_match_clouds) keep warm contexts with the model -- one per call that
+ * has been in flight at once (at least 2, at most 16), each holding a stream, pinned staging and the scratch of its last call
+ * (0.45 GB for a 50,000-point crop).  This releases the idle ones beyond `keep` (0: all) and returns how many went; calls in
+ * flight are not touched, the next call on a model without an idle context simply starts cold.  The reference has no
+ * counterpart: its detector frees nothing until it is destroyed (/root/reference/include/CloudProcessing.h:79-83). */
+ppf_status ppf_model_trim_contexts(const ppf_model* m, int keep, int* released);
 /* sampled model cloud (n_ref x 6 floats) */
 ppf_status ppf_model_get_sampled(const ppf_model* m, float* out, int cap_rows);
 /* CSR dump for inspection/tests: any pointer may be NULL. bucket_off has n_tiles*(n_buckets+1) u32,
@@ -287,8 +293,11 @@ ppf_status ppf_workspace_destroy(ppf_workspace* ws);
 #define PPF_OPT_HIT_FRACTION 1
 #define PPF_OPT_GROUP_ROUND_BUCKETS 2
 #define PPF_OPT_CLUSTER_SERIAL 3 /* != 0: the serial greedy cluster assignment (the path for > 11,520 poses) for any size */
-#define PPF_OPT_ACC32 4          /* != 0: 32-bit accumulator cells for every (reference point, tile) (otherwise 16-bit cells first, and 32-bit
-                                   cells only for those the vote kernel saw overflow) */
+#define PPF_OPT_ACC32 4          /* 0 (default): 16-bit accumulator cells first, 32-bit cells for the (reference point, tile)s whose cells overflow;
+                                   a workspace that sees a twentieth of a call's votes cast twice that way goes to 32-bit cells for
+                                   everything; 1: 32-bit cells for everything from the first call; 2: 16-bit cells first, always;
+                                   3: the (reference point, tile)s that will cast more votes than a limit learned from the previous
+                                   call go straight to 32-bit cells (measured slower than 0 on BASELINE's C4: kept for the comparison) */
 #define PPF_OPT_TABLE_FRACTION 5 /* expected count tables per hit (sizes the table pool of the next call; learned from then on) */
 #define PPF_OPT_BATCH_REFS 6     /* > 0: at most this many reference points per batch of a call (default: what 4 GB of hit scratch hold); a test knob */
 ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);

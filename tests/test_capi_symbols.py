@@ -98,7 +98,7 @@ def _write_model_file(path, n_ref=2, junk=b""):
     info.n_entries, info.n_tiles, info.tile_refs = n_ref * (n_ref - 1), 1, n_ref
     info.angle_step, info.distance_step, info.diameter = 2 * np.pi / 30, 0.01, 0.2
     with open(path, "wb") as f:
-        f.write(b"PPFHIP04" + bytes(tp) + bytes(info) + struct.pack("<Q", 1) + junk)
+        f.write(b"PPFHIP05" + struct.pack("<II", 64, 0) + bytes(tp) + bytes(info) + struct.pack("<Q", 1) + junk)
 
 
 def test_model_file_validation_is_host_side_and_loud(tmp_path):

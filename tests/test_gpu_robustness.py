@@ -281,7 +281,7 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     np.testing.assert_array_equal(back.raw_votes(crop, 1.0 / 10.0, 0.05, presampled=True)["triples"], oracle_crop["triples"])
     raw = bytearray(good.read_bytes())
     info = det.info()
-    header = 8 + C.sizeof(_capi.TrainParams) + C.sizeof(_capi.ModelInfo) + 8
+    header = 8 + 8 + C.sizeof(_capi.TrainParams) + C.sizeof(_capi.ModelInfo) + 8  # magic, build word {count-table cells, 0}, params, info, n_records
     sampled = info["n_ref"] * 24
     slotmap = ((info["slots"] + 63) // 64) * 16
     boff = info["n_tiles"] * (info["n_buckets"] + 1) * 4
@@ -339,8 +339,13 @@ def test_corrupt_model_files_are_rejected_not_run(det, crop, oracle_crop, tmp_pa
     assert load(bytes(bad)) == _capi.PPF_ERR_IO and "halves" in _capi.last_error()
     bad = bytearray(raw); bad[rec0 + 3] |= 0x3F                            # cell >= 126: beyond the count table's cells
     assert load(bytes(bad)) == _capi.PPF_ERR_IO and "cell" in _capi.last_error()
-    bad = bytearray(raw); bad[8 + C.sizeof(_capi.TrainParams)] ^= 0x40     # n_ref in the header
+    bad = bytearray(raw); bad[16 + C.sizeof(_capi.TrainParams)] ^= 0x40    # n_ref in the header
     assert load(bytes(bad)) == _capi.PPF_ERR_IO
+    # a file of a build with another count-table cell count (-DPPF_AGG_Q=48: the cell bits of every row code mean something
+    # else there) must not be voted through this build's cells
+    assert int.from_bytes(raw[8:12], "little") == 64
+    bad = bytearray(raw); bad[8:12] = (48).to_bytes(4, "little")
+    assert load(bytes(bad)) == _capi.PPF_ERR_IO and "cell count" in _capi.last_error()
 
 
 def test_fine_alpha_resolution_votes_directly(bottle):
@@ -390,3 +395,35 @@ def test_a_model_on_another_device_is_refused(det, crop):
     """check_match_args: the model's device must be the calling thread's current device (one GPU here: the positive case)."""
     assert lib().ppf_device_count() >= 1
     assert _device_run(det, crop, skip_clustering=True)["n_ref"] == 1200
+
+
+def test_idle_contexts_follow_the_calls_in_flight_and_can_be_trimmed(det, crop):
+    """the host-buffer entry keeps one warm context per call that was in flight at once (three threads: three), the trim
+    releases them, and a match after the trim (cold again) returns what it returned before"""
+    import threading
+    want = det.match(crop, 1.0 / 10.0, 0.05, presampled=True)
+    det.trim_contexts(0)
+    got, errs = {}, []
+    gate = threading.Barrier(3)
+
+    def work(k):
+        try:
+            gate.wait()
+            for _ in range(4):
+                got[k] = det.match(crop, 1.0 / 10.0, 0.05, presampled=True)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for k in range(3):
+        assert [p.numVotes for p in got[k]] == [p.numVotes for p in want]
+    released = det.trim_contexts(0)
+    assert 1 <= released <= 3          # as many as ran at once (the threads may not have overlapped fully)
+    assert det.trim_contexts(0) == 0   # nothing idle is left
+    again = det.match(crop, 1.0 / 10.0, 0.05, presampled=True)
+    assert [p.numVotes for p in again] == [p.numVotes for p in want]
+    np.testing.assert_array_equal(again[0].pose, want[0].pose)
+    assert det.trim_contexts(5) == 0 and det.trim_contexts(0) == 1

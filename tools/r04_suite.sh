@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04_suite; mkdir -p $OUT
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $OUT/pytest.log

@@ -196,6 +196,7 @@ struct ppf_model {
    * stream, pinned staging.  The table itself stays immutable; this list is the only state calls share, under its mutex. */
   mutable std::mutex ctx_mu;
   mutable std::vector<HostCtx*> ctx_idle;
+  mutable size_t ctx_out = 0, ctx_peak = 0; /* calls in flight on this model now / at most so far (since the last trim) */
   ~ppf_model();
 };
 
@@ -243,6 +244,7 @@ struct ppf_workspace {
   int n_batches = 0;
   bool pending = false;
   bool checked = false;                  /* the overflow flag of the pending call has been read */
+  bool pools_failed = false;             /* a call ran out of hit pools at their worst-case size: the context is dropped, not kept warm */
   bool has_edge = false;
   double hit_frac = 0.25;                /* expected hits per scene pair: sizes the hit pools, learned from every call */
   bool frac_known = false;               /* false: the next call first COUNTS its hits (one extra pair pass and one wait) */
@@ -252,8 +254,12 @@ struct ppf_workspace {
   std::vector<Learned> frac_by_model;    /* the three fractions remembered per model, at most 16 (batches alternate models): workspace_learned() */
   int batch_refs_cap = 0;                /* 0 = what the scratch budget holds; tests lower it to force several batches per call */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
-  bool acc32 = false;                    /* a 16-bit accumulator cell overflowed with this model: 32-bit cells until the model changes */
-  bool force_acc32 = false;              /* PPF_OPT_ACC32 */
+  bool acc32 = false;                    /* a call on this model cast more than PPF_ACC32_SWITCH of its votes twice (16-bit cells overflowed): 32-bit cells until the model changes */
+  bool force_acc32 = false;              /* PPF_OPT_ACC32 = 1: 32-bit cells for every (reference point, tile) */
+  int acc32_policy = 0;                  /* PPF_OPT_ACC32: 0 the switch above, 2 never switch (16-bit cells first, always), 3 a per-item limit (heavy_votes) */
+  unsigned long long heavy_votes = ~0ull; /* policy 3: a (reference point, tile) that will cast at least this many votes goes straight to 32-bit cells:
+                                            learned per model from what the previous call's items of each size needed (workspace_finish) */
+  DevBuf<unsigned long long> item_votes, need_hist;
   bool cluster_serial = false;           /* force the serial greedy assignment (otherwise only used above 11,520 poses) */
   int device = -1;
   uint32_t* acc_dump = nullptr; /* set by ppf_debug_accumulators for one call */

@@ -35,7 +35,11 @@ ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value)
       ws->cluster_serial = value != 0;
       return PPF_OK;
     case PPF_OPT_ACC32:
-      ws->force_acc32 = value != 0;
+      if (!(value == 0 || value == 1 || value == 2 || value == 3)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: PPF_OPT_ACC32 takes 0 .. 3");
+      ws->force_acc32 = value == 1;
+      ws->acc32_policy = value == 1 ? 0 : (int)value;
+      ws->heavy_votes = ~0ull;
+      if (value != 0) ws->acc32 = false;
       return PPF_OK;
     case PPF_OPT_BATCH_REFS:
       if (!(value >= 0 && value <= 1e9)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: bad batch size");
@@ -165,6 +169,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   if (ws->model != m) { /* another model: its own hit density (remembered if it has been here before) */
     workspace_remember_frac(ws);
     ws->acc32 = false;
+    ws->heavy_votes = ~0ull; /* another table: its own limit, learned from its first call on */
     if (const ppf_workspace::Learned* fm = workspace_learned(ws, m, false)) {
       ws->hit_frac = fm->hit; ws->run_frac = fm->run; ws->tbl_frac = fm->tbl;
       ws->frac_known = true;
@@ -200,6 +205,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   HIPCHK(ws->partial.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->half_edge.reserve((size_t)n_ref * T * 2));
   HIPCHK(ws->ovf_items.reserve((size_t)n_ref * T));
+  if (ws->acc32_policy == 3) {
+    HIPCHK(ws->item_votes.reserve((size_t)n_ref * T));
+    HIPCHK(ws->need_hist.reserve(2 * ACC_HIST));
+  }
   const size_t n_cnt = (size_t)n_ref * T + n_ref + 16; /* cellsum | pairs | totals[2] | tally[14]: LDS operations, hits, runs, 32-bit items, votes cast twice, count tables, 8 phase clocks (diagnostic build) */
   HIPCHK(ws->counters.reserve(n_cnt));
   HIPCHK(ws->votes.reserve(n_ref));
@@ -207,6 +216,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   if (ws->timing) HIPCHK(hipEventRecord(ws->ev[0], st));
   HIPCHK(hipMemsetAsync(ws->counters.p, 0, n_cnt * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync(ws->ovf_items.p, 0, (size_t)n_ref * T * sizeof(uint32_t), st));
+  if (ws->acc32_policy == 3) {
+    HIPCHK(hipMemsetAsync(ws->need_hist.p, 0, 2 * ACC_HIST * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(ws->item_votes.p, 0, (size_t)n_ref * T * sizeof(unsigned long long), st));
+  }
 
   MatchArgs va;
   memset(&va, 0, sizeof(va));
@@ -230,7 +243,14 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.bucket_total = m->bucket_total.p;
   va.bucket_mid = m->bucket_mid.p;
   va.key_exact = m->params.key_equality == PPF_KEY_EXACT;
-  const bool acc32_all = ws->acc32 || ws->force_acc32; /* otherwise: 16-bit cells, then 32-bit cells for the (reference point, tile)s that overflowed */
+  /* 16-bit cells first, 32-bit cells for the (reference point, tile)s whose cells overflow -- until a call casts more than
+   * PPF_ACC32_SWITCH of its votes twice that way: from then on 32-bit cells for everything (what they cost extra is less than
+   * what the repeats cost: profiles/r04_c4_acc32_policies.md).  PPF_OPT_ACC32 = 3 instead sends the items that will cast at
+   * least ws->heavy_votes votes straight to the 32-bit launch, decided on the device, per item, for THIS scene, before a vote
+   * is cast (measured on C4: slower than either, the vote count of an item says little about its fullest cell). */
+  const bool acc32_all = ws->force_acc32 || (ws->acc32 && ws->acc32_policy == 0);
+  va.item_votes = (!acc32_all && ws->acc32_policy == 3) ? ws->item_votes.p : nullptr;
+  va.heavy_votes = ws->heavy_votes;
   const bool darboux = m->params.feature == PPF_FEATURE_DARBOUX;
   va.pair_radius = params->pair_radius;
   va.agg_min_hits = (params->vote_mode == PPF_VOTE_DIRECT || params->alpha_range_2pi || m->info.num_angles > AGG_MAX_ANGLES) ? 0 : PPF_AGG_MIN_HITS;
@@ -391,6 +411,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   fa.partial = ws->partial.p; fa.cellsum = va.cellsum; fa.pairs = va.pairs;
   fa.votes = ws->votes.p; fa.poses = ws->raw_poses.p;
   fa.totals = ws->counters.p + (size_t)n_ref * T + n_ref;
+  fa.item_votes = va.item_votes; fa.need_hist = va.item_votes ? ws->need_hist.p : nullptr;
   k_finalize<<<dim3((n_ref + 63) / 64), dim3(64), 0, st>>>(fa);
   HIPCHK(hipGetLastError());
   if (!params->skip_clustering) {
@@ -426,9 +447,35 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->stats.n_lds_atomics = tot[2];
       ws->stats.n_hits = tot[3];
       ws->stats.n_acc32_items = tot[5];
-      /* The 16-bit launch is about 12 % cheaper than the 32-bit one, and what it flags is voted twice: a scene that casts more
-       * than a tenth of its votes in (reference point, tile)s that overflow goes straight to 32-bit cells from now on. */
-      if (!ws->acc32 && (double)tot[6] > 0.10 * (double)tot[0]) ws->acc32 = true;
+      /* The limit of the next call: k_finalize filed the votes of every (reference point, tile) under its size class, as
+       * "needed 32-bit cells" (a cell beyond 65,535) or "did not".  An item sent to 32-bit cells costs about PPF_ACC32_COST of
+       * what 16-bit cells cost it; one that overflows 16-bit cells costs 1 + PPF_ACC32_COST.  The class boundary that makes
+       * the sum smallest becomes the limit (none above every class: the scene needs no 32-bit cells). */
+      if (!ws->acc32 && ws->acc32_policy == 0 && (double)tot[6] > PPF_ACC32_SWITCH * (double)tot[0]) ws->acc32 = true;
+      if (!ws->force_acc32 && ws->acc32_policy == 3) {
+        unsigned long long hist[2 * ACC_HIST];
+        HIPCHK(hipMemcpy(hist, ws->need_hist.p, sizeof(hist), hipMemcpyDeviceToHost));
+        double best = -1;
+        int best_k = ACC_HIST;
+        double above = 0, below = 0; /* cost of the classes >= k (sent to 32-bit cells) / < k (tried with 16-bit cells) */
+        for (int b = 0; b < ACC_HIST; b++) below += (double)hist[ACC_HIST + b] + (1.0 + PPF_ACC32_COST) * (double)hist[b];
+        for (int k = ACC_HIST; k >= 0; k--) {
+          if (k < ACC_HIST) {
+            const double need = (double)hist[k], rest = (double)hist[ACC_HIST + k];
+            above += PPF_ACC32_COST * (need + rest);
+            below -= rest + (1.0 + PPF_ACC32_COST) * need;
+          }
+          const double cost = above + below;
+          if (best < 0 || cost < best) { best = cost; best_k = k; }
+        }
+        ws->heavy_votes = best_k >= ACC_HIST ? ~0ull : acc_hist_lower(best_k);
+        if (getenv("PPF_DEBUG_ACC32")) {
+          for (int b = 0; b < ACC_HIST; b++)
+            if (hist[b] || hist[ACC_HIST + b])
+              fprintf(stderr, "acc32 class %3d (>= %llu votes): needed %llu  not needed %llu\n", b, acc_hist_lower(b), hist[b], hist[ACC_HIST + b]);
+          fprintf(stderr, "acc32 limit -> class %d (%llu votes)\n", best_k, ws->heavy_votes);
+        }
+      }
       if (tot[1]) ws->hit_frac = std::min(1.0, std::max(1e-3, 1.06 * (double)tot[3] / (double)tot[1]));
       if (tot[3]) ws->run_frac = std::min(1.0, std::max(0.02, 1.10 * (double)tot[4] / (double)tot[3]));
       if (tot[3]) ws->tbl_frac = std::min(TBL_FRAC_MAX, std::max(1e-4, 1.15 * (double)tot[7] / (double)tot[3]));
@@ -456,7 +503,10 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->checked = true;
       return PPF_OK;
     }
-    if (ws->hit_frac >= 1.0) return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
+    if (ws->hit_frac >= 1.0) {
+      ws->pools_failed = true; /* not the caller's output buffer: a context in this state is not kept (HostLoan) */
+      return fail(PPF_ERR_CAPACITY, "match: hit pools overflowed at worst-case size (flags %u)", ovf);
+    }
     if (ovf & 3u) ws->hit_frac = std::min(1.0, ws->hit_frac * 2.0); /* raw or sorted hit pool */
     if (ovf & 4u) ws->run_frac = std::min(1.0, ws->run_frac * 2.0); /* run table */
     if (ovf & 8u) { /* count-table pool */
@@ -682,8 +732,11 @@ ppf_status ppf_cluster_poses(const ppf_model* m, const ppf_pose* in, int n, int 
  * borrows a WARM context from its model: a workspace that has already sized its hit pools and learned this scene
  * family's hit density (no counting pass, no scratch allocation), a non-blocking stream, pinned staging for the upload.
  * Contexts are handed out under the model's mutex, one per call in flight, so concurrent calls on one model from several
- * host threads stay independent; up to HOST_CTX_KEEP idle ones are kept, the rest are destroyed on return. */
+ * host threads stay independent.  A model keeps as many idle ones as it has had calls in flight at once (at least
+ * HOST_CTX_KEEP, at most HOST_CTX_MAX): N threads matching on one detector all stay warm; ppf_model_trim_contexts releases
+ * them (each holds the scratch of its last call: 0.45 GB for a C2-sized crop). */
 constexpr size_t HOST_CTX_KEEP = 2;
+constexpr size_t HOST_CTX_MAX = 16;
 
 struct HostCtx {
   ppf_workspace ws;
@@ -693,7 +746,9 @@ struct HostCtx {
   DevBuf<float> d_rows[2];
   int device = -1;
   ~HostCtx() {
-    sync_device(device);
+    /* everything this context ever enqueued went to its own stream: wait for that, not for the whole device (other threads'
+     * calls on other contexts keep running) */
+    if (stream) (void)hipStreamSynchronize(stream); else sync_device(device);
     for (float* p : pinned)
       if (p) (void)hipHostFree(p);
     if (stream) (void)hipStreamDestroy(stream);
@@ -704,6 +759,19 @@ ppf_model::~ppf_model() {
   for (HostCtx* c : ctx_idle) delete c;
 }
 
+extern "C" ppf_status ppf_model_trim_contexts(const ppf_model* m, int keep, int* released) {
+  if (!m || keep < 0) return fail(PPF_ERR_INVALID, "ppf_model_trim_contexts: bad argument");
+  std::vector<HostCtx*> drop;
+  {
+    std::lock_guard<std::mutex> g(m->ctx_mu);
+    while (m->ctx_idle.size() > (size_t)keep) { drop.push_back(m->ctx_idle.back()); m->ctx_idle.pop_back(); }
+    m->ctx_peak = m->ctx_out; /* the high-water mark starts again: later calls keep what THEY need */
+  }
+  for (HostCtx* c : drop) delete c; /* waits for the context's stream, returns its scratch to the block cache */
+  if (released) *released = (int)drop.size();
+  return PPF_OK;
+}
+
 namespace {
 
 /* RAII loan of a context: returned to the model's idle list when the call succeeded, destroyed otherwise (a failed call
@@ -712,11 +780,15 @@ struct HostLoan {
   const ppf_model* m;
   HostCtx* c = nullptr;
   bool ok = false;
+  bool counted = false;
   explicit HostLoan(const ppf_model* model) : m(model) {}
   ppf_status open() {
     {
       std::lock_guard<std::mutex> g(m->ctx_mu);
       if (!m->ctx_idle.empty()) { c = m->ctx_idle.back(); m->ctx_idle.pop_back(); }
+      m->ctx_out++;
+      m->ctx_peak = std::max(m->ctx_peak, m->ctx_out);
+      counted = true;
     }
     if (c) return PPF_OK;
     std::unique_ptr<HostCtx> n(new (std::nothrow) HostCtx());
@@ -728,12 +800,15 @@ struct HostLoan {
     return PPF_OK;
   }
   ~HostLoan() {
-    if (!c) return;
-    if (ok) {
+    {
       std::lock_guard<std::mutex> g(m->ctx_mu);
-      if (m->ctx_idle.size() < HOST_CTX_KEEP) { m->ctx_idle.push_back(c); c = nullptr; }
+      if (counted) m->ctx_out--;
+      if (c && ok && !c->ws.pools_failed && m->ctx_idle.size() < std::min(HOST_CTX_MAX, std::max(HOST_CTX_KEEP, m->ctx_peak))) {
+        m->ctx_idle.push_back(c);
+        c = nullptr;
+      }
     }
-    delete c;
+    delete c; /* outside the lock: it waits for its stream */
   }
   /* host rows -> pinned staging -> device, all on the context's stream */
   ppf_status upload(int which, const float* rows, int n, int stride, const float** d_out) {

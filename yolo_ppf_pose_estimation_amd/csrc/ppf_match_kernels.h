@@ -123,6 +123,13 @@
 #ifndef PPF_COST_ITEM
 #define PPF_COST_ITEM 512     /* ... and a run's fixed cost (claim, look-up, first loads), in record-hits */
 #endif
+#ifndef PPF_ACC32_COST
+#define PPF_ACC32_COST 1.02 /* what voting a (reference point, tile) with 32-bit cells (two passes, one per half of its rows) costs, relative to 16-bit cells
+                               (C4, round 4: 342 ms with 32-bit cells for everything against 380 ms when the tenth of the votes that overflows is cast twice) */
+#endif
+#ifndef PPF_ACC32_SWITCH
+#define PPF_ACC32_SWITCH 0.05 /* share of a call's votes cast twice (16-bit cells overflowed) beyond which a workspace goes to 32-bit cells for everything */
+#endif
 #ifndef PPF_TWO_QUEUES
 #define PPF_TWO_QUEUES 0 /* 1: k_vote claims count-table items and direct items from two queues, half of the waves preferring each (measured: +2 %, profiles/r03_vote_variants.md) */
 #endif
@@ -323,7 +330,10 @@ struct MatchArgs {
   double pair_radius;           /* > 0: pairs farther apart than this are skipped (not counted) */
   int acc32;                    /* k_vote<.., true> (32-bit cells, one workgroup per half of a tile's rows): 1 = every (reference point, tile),
                                    2 = only those the 16-bit launch flagged in ovf_items */
-  uint32_t* ovf_items;          /* [n_ref_all * n_tiles] != 0: a 16-bit cell of this (reference point, tile) overflowed */
+  uint32_t* ovf_items;          /* [n_ref_all * n_tiles] != 0: voted with 32-bit cells -- 1: a 16-bit cell of this (reference point, tile) overflowed;
+                                   2: sent there without a 16-bit attempt (it will cast at least heavy_votes votes) */
+  unsigned long long* item_votes; /* [n_ref_all * n_tiles] votes the (reference point, tile) will cast (NULL: not wanted), written by the 16-bit launch */
+  unsigned long long heavy_votes; /* a (reference point, tile) that will cast at least this many goes straight to 32-bit cells (~0: none does) */
   uint32_t* ovf_list;           /* [n_ref * n_tiles] the same for this batch as a list: local reference point | tile << 16 (cursors[CUR_OVFCOUNT] entries) */
   int count_only;               /* k_pairs only counts its hits (cold workspace: sizes the pools of the real pass) */
   /* results, indexed by global r */
@@ -1388,6 +1398,40 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   if (tid == 0) { red[50] = red[51] = red[52] = red[53] = red[58] = red[59] = 0u; } /* votes issued / found / counted (64-bit each), see the overflow check */
 
   const uint32_t* __restrict__ boff = a.bucket_off + (size_t)tile * (a.n_buckets + 1);
+  if (!ACC32 && a.item_votes) {
+    /* How many votes will this (reference point, tile) cast?  hits x entries of its runs, known before a single vote: one pass
+     * over the run table.  The host learns from it (k_finalize files every item's count under "needed 32-bit cells" or "did
+     * not"); and an item at or above the learned limit is not tried with 16-bit cells at all -- it joins the list of the
+     * 32-bit launch right away (an overflow that is found by voting costs the item twice). */
+    unsigned long long v = 0;
+    for (int blk = 0; blk < a.n_rounds; blk++) {
+      const uint2 rb = a.run_blocks[(size_t)r * a.n_rounds + blk];
+      for (uint32_t i = (uint32_t)tid; i < rb.y; i += VOTE_BLOCK) {
+        const uint4 run = a.runs[rb.x + i];
+        v += (unsigned long long)run.z * (unsigned long long)(boff[run.x + 1] - boff[run.x]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    unsigned long long* red64 = reinterpret_cast<unsigned long long*>(red + 16); /* 16 x 8 bytes of the header, free until the staging */
+    __syncthreads();
+    if (lane == 0) red64[wave] = v;
+    __syncthreads();
+    unsigned long long V = 0;
+#pragma unroll
+    for (int k = 0; k < VOTE_WAVES; k++) V += red64[k];
+    V *= 2ull; /* two entries per pair record */
+    const size_t item = (size_t)rg * a.n_tiles + tile;
+    if (tid == 0) a.item_votes[item] = V;
+    if (V >= a.heavy_votes) {
+      if (tid == 0) {
+        a.ovf_items[item] = 2u;
+        a.ovf_list[atomicAdd(&a.cursors[CUR_OVFCOUNT], 1u)] = (uint32_t)r | ((uint32_t)tile << 16);
+      }
+      return;
+    }
+    __syncthreads(); /* red64 is staging scratch again */
+  }
   const uint4* __restrict__ records = a.records;
   const double s64 = WRAP ? (double)A / (2 * PPF_PI) : (double)A / (4 * PPF_PI);
   const float S = (float)s64;

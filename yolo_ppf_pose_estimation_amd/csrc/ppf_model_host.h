@@ -401,7 +401,10 @@ ppf_status ppf_model_get_table(const ppf_model* m, uint32_t* bucket_slot, uint32
 
 /* ---- model (de)serialisation: versioned binary CSR (the reference's XML format is defined by a
  * private OpenCV patch and unknown) ------------------------------------------------- */
-static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '4'}; /* 02: pair-record table; 03: ppf_train_params.feature; 04: 64 count-table cells (7-bit cell field), cell-grouped dealing */
+static const char PPF_MAGIC[8] = {'P', 'P', 'F', 'H', 'I', 'P', '0', '5'}; /* 02: pair-record table; 03: ppf_train_params.feature; 04: 64 count-table cells (7-bit cell field), cell-grouped dealing; 05: the build's count-table cell count in the header */
+/* what the records' count-table bits were computed with: a file written by a build with another PPF_AGG_Q carries cells of
+ * another width in its row codes and would be voted through the wrong cells; it is refused */
+struct ModelBuildWord { uint32_t agg_q, reserved; };
 
 /* the model as a byte stream (what a model file holds), written to an open FILE */
 static ppf_status model_write(const ppf_model* m, FILE* f, const char* path) {
@@ -414,6 +417,8 @@ static ppf_status model_write(const ppf_model* m, FILE* f, const char* path) {
   if (nb) HIPCHK(hipMemcpy(bslot.data(), m->bucket_slot.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (ne) HIPCHK(hipMemcpy(ent.data(), m->records.p, ne * sizeof(uint4), hipMemcpyDeviceToHost));
   bool ok = fwrite(PPF_MAGIC, 1, 8, f) == 8;
+  const ModelBuildWord bw = {(uint32_t)AGG_Q, 0u};
+  ok = ok && fwrite(&bw, sizeof(bw), 1, f) == 1;
   ok = ok && fwrite(&m->params, sizeof(m->params), 1, f) == 1;
   ok = ok && fwrite(&m->info, sizeof(m->info), 1, f) == 1;
   ok = ok && fwrite(&m->n_records, sizeof(m->n_records), 1, f) == 1;
@@ -474,6 +479,9 @@ static ppf_status model_load_stream(FILE* f, const char* path, ppf_model** out, 
   std::unique_ptr<ppf_model> owner(new ppf_model()); /* released on every early return */
   ppf_model* m = owner.get();
   if (fread(magic, 1, 8, f) != 8 || memcmp(magic, PPF_MAGIC, 8) != 0) return bad("magic");
+  ModelBuildWord bw;
+  if (fread(&bw, sizeof(bw), 1, f) != 1) return bad("header");
+  if (bw.agg_q != (uint32_t)AGG_Q || bw.reserved != 0u) return bad("written by a build with another count-table cell count");
   if (fread(&m->params, sizeof(m->params), 1, f) != 1 || fread(&m->info, sizeof(m->info), 1, f) != 1 ||
       fread(&m->n_records, sizeof(m->n_records), 1, f) != 1)
     return bad("header");
@@ -496,7 +504,7 @@ static ppf_status model_load_stream(FILE* f, const char* path, ppf_model** out, 
   const uint64_t nb = I.n_buckets, ne = m->n_records, T = (uint64_t)I.n_tiles;
   if (ne > I.n_entries / 2 + 32ull * T * nb + 64 || ne >= 0xFFFFFFFFull) return bad("n_records");
   const uint64_t words = ((uint64_t)I.slots + 63) / 64;
-  const uint64_t expect = 8 + sizeof(m->params) + sizeof(m->info) + sizeof(m->n_records) + N * 6 * sizeof(float) +
+  const uint64_t expect = 8 + sizeof(ModelBuildWord) + sizeof(m->params) + sizeof(m->info) + sizeof(m->n_records) + N * 6 * sizeof(float) +
                           words * sizeof(SlotWord) + T * (nb + 1) * sizeof(uint32_t) + nb * sizeof(uint32_t) + ne * sizeof(uint4);
   if ((uint64_t)fsize != expect) return bad("file size does not match its header");
   std::vector<SlotWord> slotmap(words);

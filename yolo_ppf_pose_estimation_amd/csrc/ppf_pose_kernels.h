@@ -36,7 +36,23 @@ struct FinalArgs {
   ppf_vote* votes;
   ppf_pose* poses;
   unsigned long long* totals; /* [0] votes, [1] pairs */
+  const unsigned long long* item_votes; /* votes per (reference point, tile), or NULL */
+  unsigned long long* need_hist;        /* [2][ACC_HIST]: votes of the items that needed 32-bit cells / that did not, by size class of the item */
 };
+
+/* size classes of a (reference point, tile) by the votes it casts: four per octave */
+constexpr int ACC_HIST = 256;
+__host__ __device__ inline int acc_hist_class(unsigned long long v) {
+  if (v < 4ull) return (int)v;
+  int lg = 63;
+  while (!((v >> lg) & 1ull)) lg--;
+  return lg * 4 + (int)((v >> (lg - 2)) & 3ull);
+}
+__host__ __device__ inline unsigned long long acc_hist_lower(int cls) { /* smallest count of a class */
+  if (cls < 8) return cls < 4 ? (unsigned long long)cls : 4ull; /* classes 4..7 are empty (lg = 1 gives 4 + ...: never reached below lg 2) */
+  const int lg = cls / 4, fr = cls % 4;
+  return (unsigned long long)(4 + fr) << (lg - 2);
+}
 
 __global__ void k_finalize(FinalArgs a) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,7 +64,15 @@ __global__ void k_finalize(FinalArgs a) {
     const uint2 p = a.partial[slot];
     nv += a.cellsum[(size_t)r * a.n_tiles + t];
     if (p.x > maxVotes) { maxVotes = p.x; flat = (uint32_t)(t * a.tile_refs * a.num_angles) + p.y; }
-    if (a.acc32 || a.ovf_items[(size_t)r * a.n_tiles + t]) { /* the high-half rows come after the low-half rows; bin 0 of their first row still lacks the spill
+    uint32_t cell_max = p.x;
+    const bool wide = a.acc32 || a.ovf_items[(size_t)r * a.n_tiles + t];
+    if (wide) cell_max = max(cell_max, a.partial[slot + 1].x);
+    if (a.item_votes && a.need_hist) { /* what the host learns the 32-bit limit from: did an item of this size need 32-bit cells? */
+      const unsigned long long V = a.item_votes[(size_t)r * a.n_tiles + t];
+      const bool needed = wide && cell_max > 65535u;
+      if (V) atomicAdd(&a.need_hist[(needed ? 0 : ACC_HIST) + acc_hist_class(V)], V);
+    }
+    if (wide) { /* the high-half rows come after the low-half rows; bin 0 of their first row still lacks the spill
                       cell of the row before it, which the low halves' workgroup counted */
       uint2 q = a.partial[slot + 1];
       const uint32_t carry = a.edge[slot];

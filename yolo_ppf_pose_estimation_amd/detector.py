@@ -161,6 +161,14 @@ class PPF3DDetector:
         check(lib().ppf_model_get_device(self._model.ptr, C.byref(d)))
         return d.value
 
+    def trim_contexts(self, keep: int = 0) -> int:
+        """Release the idle warm contexts of the host-buffer entries beyond ``keep`` (each holds the scratch of its last
+        call); returns how many were released."""
+        self._require_trained()
+        n = C.c_int(0)
+        check(lib().ppf_model_trim_contexts(self._model.ptr, int(keep), C.byref(n)))
+        return n.value
+
     def info(self) -> dict:
         self._require_trained()
         mi = ModelInfo()
