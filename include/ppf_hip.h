@@ -228,6 +228,12 @@ ppf_status ppf_model_release(ppf_model* m);
 ppf_status ppf_model_get_info(const ppf_model* m, ppf_model_info* info);
 /* HIP device the model's table lives on (the current device of the thread that trained or loaded it) */
 ppf_status ppf_model_get_device(const ppf_model* m, int* device);
+/* pcl::PPFHashMapSearch::nearestNeighborSearch(f1, f2, f3, f4, indices) (north_star's PCL names; the reference never calls it):
+ * the pairs (i, j) of the trained model's sampled points whose quantised feature equals the quantised f4[0..3] -- what a hash
+ * map keyed on the quantised feature holds under that key -- ascending by (i, j), as pairs_ij[2q], pairs_ij[2q + 1].  The
+ * feature kind and the steps are the model's (ppf_train_params.feature, ppf_model_info.angle_step / distance_step).
+ * cap_pairs = 0 only counts (*n_out). */
+ppf_status ppf_model_nearest_pairs(const ppf_model* m, const float* f4, uint32_t* pairs_ij, int cap_pairs, int* n_out);
 /* The host-buffer entries (ppf_match, ppf_raw_votes, ppf_match_clouds) keep warm contexts with the model -- one per call that
  * has been in flight at once (at least 2, at most 16), each holding a stream, pinned staging and the scratch of its last call
  * (0.45 GB for a 50,000-point crop).  This releases the idle ones beyond `keep` (0: all) and returns how many went; calls in

@@ -35,7 +35,9 @@
 #include <array>
 #include <cmath>
 #include <cstddef>
+#include <functional>
 #include <memory>
+#include <utility>
 #include <type_traits>
 #include <vector>
 
@@ -70,44 +72,59 @@ struct PointCloud {
 namespace detail {
 template <class C> auto pts(const C& c) -> decltype(c.points) const& { return c.points; }
 template <class P> const std::vector<P>& pts(const std::vector<P>& v) { return v; }
+template <class C> auto pts_mut(C& c) -> decltype(c.points)& { return c.points; }
+template <class P> std::vector<P>& pts_mut(std::vector<P>& v) { return v; }
 
 /* A cloud of PointNormal-like points as the C-ABI's (pointer, rows, stride, normal_offset): the caller's storage itself
  * when the point type keeps x y z and normal_x normal_y normal_z as two runs of three consecutive floats (pcl::PointNormal
  * does: stride 12, normal offset 4), so nothing is repacked on the host -- unlike the reference's
  * PointCloudXYZNormalToMat (CloudProcessing.h:163-190), which copies every point into an N x 6 Mat first.  Any other
- * point type is copied into N x 6 rows once.  `keep` holds the caller's cloud (or the copy) alive. */
+ * point type is copied into N x 6 rows.  A view holds the caller's smart pointer, not an address: `refresh()` takes pointer
+ * and row count from the cloud AS IT IS THEN, so points that were resized or reallocated between setInputCloud() and
+ * compute() / align() -- legal in PCL, which reads through the cloud pointer at compute time -- are read where they are now. */
 struct RowsView {
   const float* p = nullptr;
   int n = 0, stride = 6, noff = PPF_NOFF_MAT;
-  std::shared_ptr<void> keep;
+  std::shared_ptr<void> keep;             /* the caller's cloud pointer, or the copied rows */
+  std::function<void(RowsView&)> resolve; /* fills p / n / stride / noff from the cloud */
+  void refresh() { if (resolve) resolve(*this); }
 };
 
 template <class CloudPtr>
 RowsView view_of(const CloudPtr& cloud) {
   RowsView v;
-  const auto& p = pts(*cloud);
-  typedef typename std::decay<decltype(p[0])>::type PointT;
-  v.n = (int)p.size();
-  if (p.empty()) return v;
-  const float* base = &p[0].x;
-  const std::ptrdiff_t oy = &p[0].y - base, oz = &p[0].z - base, nx = &p[0].normal_x - base, ny = &p[0].normal_y - base,
-                       nz = &p[0].normal_z - base;
-  if (sizeof(PointT) % sizeof(float) == 0 && oy == 1 && oz == 2 && nx >= 3 && ny == nx + 1 && nz == nx + 2 &&
-      (std::size_t)(nz + 1) * sizeof(float) <= sizeof(PointT)) {
-    v.p = base;
-    v.stride = (int)(sizeof(PointT) / sizeof(float));
-    v.noff = (int)nx;
-    v.keep = std::make_shared<CloudPtr>(cloud); /* a copy of the caller's smart pointer: the points stay where they are */
-    return v;
-  }
-  auto rows = std::make_shared<std::vector<float>>(p.size() * 6);
-  for (std::size_t i = 0; i < p.size(); i++) {
-    float* d = &(*rows)[i * 6];
-    d[0] = p[i].x; d[1] = p[i].y; d[2] = p[i].z;
-    d[3] = p[i].normal_x; d[4] = p[i].normal_y; d[5] = p[i].normal_z;
-  }
-  v.p = rows->data();
-  v.keep = rows;
+  v.resolve = [cloud](RowsView& r) {
+    const auto& p = pts(*cloud);
+    typedef typename std::decay<decltype(p[0])>::type PointT;
+    r.n = (int)p.size();
+    r.p = nullptr;
+    if (p.empty()) return;
+    /* member offsets in bytes from the point's first byte (no pointer arithmetic across members) */
+    const char* b0 = reinterpret_cast<const char*>(&p[0]);
+    const std::ptrdiff_t ox = reinterpret_cast<const char*>(&p[0].x) - b0, oy = reinterpret_cast<const char*>(&p[0].y) - b0,
+                         oz = reinterpret_cast<const char*>(&p[0].z) - b0, nx = reinterpret_cast<const char*>(&p[0].normal_x) - b0,
+                         ny = reinterpret_cast<const char*>(&p[0].normal_y) - b0, nz = reinterpret_cast<const char*>(&p[0].normal_z) - b0;
+    const std::ptrdiff_t F = (std::ptrdiff_t)sizeof(float);
+    if (sizeof(PointT) % sizeof(float) == 0 && oy == ox + F && oz == ox + 2 * F && nx >= ox + 3 * F && (nx - ox) % F == 0 && ny == nx + F &&
+        nz == nx + 2 * F && (std::size_t)(nz + F) <= sizeof(PointT)) {
+      r.p = reinterpret_cast<const float*>(b0 + ox);
+      r.stride = (int)(sizeof(PointT) / sizeof(float));
+      r.noff = (int)((nx - ox) / F);
+      r.keep = std::make_shared<CloudPtr>(cloud); /* a copy of the caller's smart pointer: the points stay where they are */
+      return;
+    }
+    auto rows = std::make_shared<std::vector<float>>(p.size() * 6);
+    for (std::size_t i = 0; i < p.size(); i++) {
+      float* d = &(*rows)[i * 6];
+      d[0] = p[i].x; d[1] = p[i].y; d[2] = p[i].z;
+      d[3] = p[i].normal_x; d[4] = p[i].normal_y; d[5] = p[i].normal_z;
+    }
+    r.p = rows->data();
+    r.stride = 6;
+    r.noff = PPF_NOFF_MAT;
+    r.keep = rows;
+  };
+  v.refresh();
   return v;
 }
 }  // namespace detail
@@ -128,6 +145,7 @@ class PPFEstimation {
   template <class CloudPtr> void setInputCloud(const CloudPtr& cloud) { model_ = detail::view_of(cloud); }
   template <class CloudPtr> void setInputNormals(const CloudPtr&) {} /* normals travel with the points */
   void compute(PPFFeatureCloud& out) {
+    model_.refresh(); /* the cloud as it is now */
     out.model = model_;
     const std::size_t n = (std::size_t)model_.n;
     out.points.assign(n * n, PPFSignature());
@@ -152,6 +170,7 @@ class PPFHashMapSearch {
   /* trains the device table: the model rows are used as they are (PCL does not resample the model), the distance
    * step is PCL's absolute step expressed relative to the model's bbox diagonal */
   void setInputFeatureCloud(const PPFFeatureCloud::Ptr& features) {
+    features->model.refresh();
     const detail::RowsView& mv = features->model;
     if (!mv.p || mv.n < 2) throw ppf_match_3d::Error(PPF_ERR_INVALID, "PPFHashMapSearch: empty feature cloud");
     const float* r = mv.p;
@@ -174,6 +193,18 @@ class PPFHashMapSearch {
     ppf_model* m = nullptr;
     ppf_match_3d::check(ppf_model_train(r, n, mv.stride, mv.noff, &tp, &m)); /* pcl::PointNormal storage as it is: stride 12, normals at 4 */
     model_.reset(m, [](ppf_model* p) { ppf_model_release(p); });
+  }
+  /* the model pairs (i, j) filed under the quantised (f1, f2, f3, f4): PCL's hash-map lookup with key equality */
+  void nearestNeighborSearch(float& f1, float& f2, float& f3, float& f4, std::vector<std::pair<std::size_t, std::size_t>>& indices) {
+    if (!model_) throw ppf_match_3d::Error(PPF_ERR_NOT_TRAINED, "PPFHashMapSearch: no feature cloud set");
+    const float f[4] = {f1, f2, f3, f4};
+    int n = 0;
+    ppf_match_3d::check(ppf_model_nearest_pairs(model_.get(), f, nullptr, 0, &n));
+    std::vector<uint32_t> ij((std::size_t)std::max(n, 1) * 2);
+    ppf_match_3d::check(ppf_model_nearest_pairs(model_.get(), f, ij.data(), std::max(n, 1), &n));
+    indices.clear();
+    indices.reserve((std::size_t)n);
+    for (int q = 0; q < n; q++) indices.push_back(std::make_pair((std::size_t)ij[2 * q], (std::size_t)ij[2 * q + 1]));
   }
   float getAngleDiscretizationStep() const { return angle_step_; }
   float getDistanceDiscretizationStep() const { return dist_step_; }
@@ -198,7 +229,7 @@ class PPFRegistration {
   void setSceneReferencePointSamplingRate(unsigned rate) { rate_ = rate ? rate : 1; }
   void setPositionClusteringThreshold(float t) { pos_thr_ = t; }
   void setRotationClusteringThreshold(float t) { rot_thr_ = t; }
-  template <class CloudPtr> void setInputSource(const CloudPtr&) {} /* the model lives in the search method */
+  template <class CloudPtr> void setInputSource(const CloudPtr& model) { source_ = detail::view_of(model); } /* voted from the search method's table; align() moves THIS cloud */
   template <class CloudPtr> void setInputTarget(const CloudPtr& scene) { scene_ = detail::view_of(scene); }
 
   /* computeTransformation(): votes, clusters; keeps every clustered pose, best first */
@@ -213,6 +244,7 @@ class PPFRegistration {
     mp.pair_radius = 0.5 * (double)search_->getModelDiameter(); /* the radius search of computeTransformation() */
     mp.rot_metric_relative = 1;                                 /* posesWithinErrorBounds(): angle of the relative rotation */
     mp.alpha_range_2pi = 1;                                     /* alpha wrapped into [-pi, pi], bins of the angle discretisation step */
+    scene_.refresh(); /* the target as it is now */
     const int n = scene_.n;
     if (!scene_.p || n <= 0) throw ppf_match_3d::Error(PPF_ERR_INVALID, "PPFRegistration: no target cloud");
     std::vector<ppf_pose> out((size_t)n / rate_ + 8);
@@ -227,7 +259,20 @@ class PPFRegistration {
       results_.push_back(p);
     }
     converged_ = n_out > 0;
-    (void)output; /* PCL fills `output` with the transformed source; left to the caller (ppf_transform_pc_pose) */
+    /* PCL: `output` = the input source transformed by the final transformation (the source itself when nothing was found) */
+    source_.refresh();
+    auto& op = detail::pts_mut(output);
+    op.resize((std::size_t)std::max(source_.n, 0));
+    if (source_.p && source_.n > 0) {
+      const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      std::vector<float> rows((std::size_t)source_.n * 6);
+      ppf_match_3d::check(ppf_transform_pc_pose(source_.p, source_.n, source_.stride, source_.noff, n_out > 0 ? out[0].pose : ident, rows.data()));
+      for (int i = 0; i < source_.n; i++) {
+        const float* r = &rows[(std::size_t)i * 6];
+        op[(std::size_t)i].x = r[0]; op[(std::size_t)i].y = r[1]; op[(std::size_t)i].z = r[2];
+        op[(std::size_t)i].normal_x = r[3]; op[(std::size_t)i].normal_y = r[4]; op[(std::size_t)i].normal_z = r[5];
+      }
+    }
   }
   bool hasConverged() const { return converged_; }
   Matrix4f getFinalTransformation() const {
@@ -240,7 +285,7 @@ class PPFRegistration {
   PPFHashMapSearch::Ptr search_;
   unsigned rate_ = 5;
   float pos_thr_ = -1.f, rot_thr_ = -1.f;
-  detail::RowsView scene_;
+  detail::RowsView scene_, source_;
   std::vector<PoseWithVotes> results_;
   bool converged_ = false;
 };

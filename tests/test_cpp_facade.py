@@ -148,6 +148,9 @@ def test_pcl_shaped_facade_runs(tmp_path, bottle):
     r = subprocess.run([exe, m, s], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "converged=1" in r.stdout
+    search = dict(kv.split("=") for kv in r.stdout.split("SEARCH ")[1].splitlines()[0].split())
+    assert int(search["pairs"]) >= 1 and search["has01"] == "1" and search["sorted"] == "1"
+    outp = dict(kv.split("=") for kv in r.stdout.split("OUTPUT ")[1].splitlines()[0].split())
     votes = int(r.stdout.split("votes=")[1].split()[0])
     model, scene = ply.load_ply_simple(m), ply.load_ply_simple(s)
     diameter = float(np.linalg.norm((model[:, :3].max(0) - model[:, :3].min(0)).astype(np.float32)))
@@ -159,6 +162,25 @@ def test_pcl_shaped_facade_runs(tmp_path, bottle):
     det.setPolicy(pair_radius=0.5 * float(np.float32(diameter)), rot_metric_relative=True, alpha_range_2pi=True)
     poses = det.match(scene, 1.0 / 20.0, 0.05, presampled=True)
     assert votes == poses[0].numVotes
+    assert int(outp["rows"]) == model.shape[0] and outp["moved_ok"] == "1"   # align(output): the source under the final transformation
+    # nearestNeighborSearch against the oracle's per-pair keys: every model pair with the key of pair (0, 1), nothing else
+    import oracle_lib as O
+    astep, dstep = det.info()["angle_step"], det.info()["distance_step"]
+    f01, key01, _ = O.pair_feature_darboux(model[0, :3], model[0, 3:], model[1, :3], model[1, 3:], astep, dstep)
+    got = det.nearest_pairs(f01.astype(np.float32))
+    assert int(search["pairs"]) == len(got)
+    rng = np.random.default_rng(0)
+    gs = {(int(i), int(j)) for i, j in got}
+    assert (0, 1) in gs
+    for i, j in list(gs)[:40]:                               # what it returns has the key
+        r_ = O.pair_feature_darboux(model[i, :3], model[i, 3:], model[j, :3], model[j, 3:], astep, dstep)
+        assert r_ is not None and list(r_[1]) == list(key01)
+    for _ in range(300):                                     # a sample of what it does not return has another key
+        i, j = (int(v) for v in rng.integers(0, model.shape[0], size=2))
+        if i == j or (i, j) in gs:
+            continue
+        r_ = O.pair_feature_darboux(model[i, :3], model[i, 3:], model[j, :3], model[j, 3:], astep, dstep)
+        assert r_ is None or list(r_[1]) != list(key01)
 
 
 def test_stage_wrapper_compiles_and_fails_loudly_without_gpu(tmp_path, bottle):

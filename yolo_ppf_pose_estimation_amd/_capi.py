@@ -103,6 +103,7 @@ _SIGNATURES = {
     "ppf_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
     "ppf_model_get_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ppf_model_trim_contexts": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "ppf_model_nearest_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
     "ppf_model_get_sampled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ppf_model_get_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppf_model_save": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -333,6 +333,37 @@ ppf_status ppf_pair_features(const float* xyzn, int n, int stride, int noff, int
   return PPF_OK;
 }
 
+ppf_status ppf_model_nearest_pairs(const ppf_model* m, const float* f4, uint32_t* pairs_ij, int cap_pairs, int* n_out) {
+  if (!m || !f4 || !n_out || cap_pairs < 0 || (cap_pairs > 0 && !pairs_ij)) return fail(PPF_ERR_INVALID, "ppf_model_nearest_pairs: bad argument");
+  if (!have_device()) return fail(PPF_ERR_HIP, "ppf_model_nearest_pairs: no HIP device (this engine has no CPU fallback)");
+  const bool darboux = m->params.feature == PPF_FEATURE_DARBOUX;
+  const double as = m->info.angle_step, ds = m->info.distance_step;
+  int32_t k[4];
+  for (int c = 0; c < 4; c++) { /* the key of the query: the quantisation the table's pairs went through */
+    const double q = (double)f4[c] / (c < 3 ? as : ds);
+    k[c] = darboux ? ppf_floor_key(q) : ppf_d2i(q);
+  }
+  const int n = m->info.n_ref;
+  DevBuf<uint2> d_out;
+  DevBuf<uint32_t> d_cur;
+  const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)n * (uint64_t)n, 1u << 26); /* 512 MB at most */
+  HIPCHK(d_out.reserve(std::max<uint32_t>(cap, 1u)));
+  HIPCHK(d_cur.reserve(1));
+  HIPCHK(hipMemset(d_cur.p, 0, sizeof(uint32_t)));
+  k_key_pairs<<<dim3((unsigned)n), dim3(256)>>>(m->cloud.view(), darboux ? 1 : 0, as, ds, k[0], k[1], k[2], k[3], d_out.p, cap, d_cur.p);
+  HIPCHK(hipGetLastError());
+  uint32_t found = 0;
+  HIPCHK(hipMemcpy(&found, d_cur.p, sizeof(found), hipMemcpyDeviceToHost));
+  if (found > cap) return fail(PPF_ERR_CAPACITY, "ppf_model_nearest_pairs: %u pairs share this key, more than one call returns", found);
+  *n_out = (int)found;
+  if ((int)found > cap_pairs) return cap_pairs == 0 ? PPF_OK : fail(PPF_ERR_CAPACITY, "ppf_model_nearest_pairs: need room for %u pairs", found);
+  std::vector<uint2> h(found);
+  if (found) HIPCHK(hipMemcpy(h.data(), d_out.p, (size_t)found * sizeof(uint2), hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end(), [](const uint2& a, const uint2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+  for (uint32_t q = 0; q < found; q++) { pairs_ij[2 * q] = h[q].x; pairs_ij[2 * q + 1] = h[q].y; }
+  return PPF_OK;
+}
+
 ppf_status ppf_model_retain(ppf_model* m) {
   if (!m) return fail(PPF_ERR_INVALID, "ppf_model_retain: NULL");
   m->refcount.fetch_add(1);

@@ -129,6 +129,33 @@ __global__ __launch_bounds__(256) void k_pair_features(CloudSoA m, int darboux, 
   }
 }
 
+/* pcl::PPFHashMapSearch::nearestNeighborSearch: the model pairs (i, j) whose quantised feature IS the key -- what a hash map
+ * keyed on the quantised feature holds under that key (the voting table itself does not keep j: a vote does not need it).
+ * One workgroup per first point; the pairs found are appended through one cursor (any order: the host sorts them). */
+__global__ __launch_bounds__(256) void k_key_pairs(CloudSoA m, int darboux, double angle_step, double dist_step, int k0, int k1, int k2, int k3,
+                                                   uint2* __restrict__ out, uint32_t cap, uint32_t* __restrict__ cursor) {
+  const int i = blockIdx.x;
+  const ppf_vec3 p1 = ld3(m.x, m.y, m.z, i), n1 = ld3(m.nx, m.ny, m.nz, i);
+  for (int j = threadIdx.x; j < m.n; j += blockDim.x) {
+    if (j == i) continue;
+    const ppf_vec3 p2 = ld3(m.x, m.y, m.z, j), n2 = ld3(m.nx, m.ny, m.nz, j);
+    double f[4] = {0, 0, 0, 0};
+    int32_t k[4];
+    if (darboux) {
+      if (!ppf_pair_feature_darboux(p1, n1, p2, n2, f)) continue;
+      k[0] = ppf_floor_key(f[0] / angle_step); k[1] = ppf_floor_key(f[1] / angle_step); k[2] = ppf_floor_key(f[2] / angle_step);
+      k[3] = ppf_floor_key(f[3] / dist_step);
+    } else {
+      ppf_pair_feature(p1, n1, p2, n2, f);
+      k[0] = ppf_d2i(f[0] / angle_step); k[1] = ppf_d2i(f[1] / angle_step); k[2] = ppf_d2i(f[2] / angle_step); k[3] = ppf_d2i(f[3] / dist_step);
+    }
+    if (k[0] == k0 && k[1] == k1 && k[2] == k2 && k[3] == k3) {
+      const uint32_t pos = atomicAdd(cursor, 1u);
+      if (pos < cap) out[pos] = make_uint2((uint32_t)i, (uint32_t)j);
+    }
+  }
+}
+
 __global__ void k_bucket_total(const uint32_t* __restrict__ bucket_off, int n_buckets, int n_tiles, uint32_t* __restrict__ total) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_buckets) return;

@@ -161,6 +161,17 @@ class PPF3DDetector:
         check(lib().ppf_model_get_device(self._model.ptr, C.byref(d)))
         return d.value
 
+    def nearest_pairs(self, f4) -> np.ndarray:
+        """pcl::PPFHashMapSearch::nearestNeighborSearch: the (i, j) pairs of the sampled model whose quantised feature equals
+        the quantised ``f4`` (four floats, the model's feature kind), ascending, as an (n, 2) uint32 array."""
+        self._require_trained()
+        f = (C.c_float * 4)(*[float(v) for v in f4])
+        n = C.c_int(0)
+        check(lib().ppf_model_nearest_pairs(self._model.ptr, f, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 2), dtype=np.uint32)
+        check(lib().ppf_model_nearest_pairs(self._model.ptr, f, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.shape[0], C.byref(n)))
+        return out[:n.value]
+
     def trim_contexts(self, keep: int = 0) -> int:
         """Release the idle warm contexts of the host-buffer entries beyond ``keep`` (each holds the scratch of its last
         call); returns how many were released."""
