@@ -92,7 +92,15 @@
 #ifndef PPF_ABL_DIRECT_BIG
 #define PPF_ABL_DIRECT_BIG 1   /* direct items on more than 32 records: 0 = neither loads nor votes, 2 = the record loads without the votes */
 #endif
-#define PPF_ABL_ANY (PPF_ABL_COUNTED != 1 || PPF_ABL_OWNCELL != 1 || PPF_ABL_DIRECT_SMALL != 1 || PPF_ABL_DIRECT_BIG != 1)
+/* PPF_MOCK_PAIRBINS (never the product; wrong votes, timing only): what an accumulator with two adjacent alpha bins per 32-bit word
+ * would cost -- a count-table entry casts 9 counted atomics instead of 17 (one v_perm each), a one-by-one vote forms its word
+ * address from bin / 2 and its increment from bin % 2 (two or three more VALU instructions than now). */
+#ifndef PPF_MOCK_PAIRBINS
+#define PPF_MOCK_PAIRBINS 0
+#endif
+#define PPF_ABL_ANY (PPF_ABL_COUNTED != 1 || PPF_ABL_OWNCELL != 1 || PPF_ABL_DIRECT_SMALL != 1 || PPF_ABL_DIRECT_BIG != 1 || PPF_MOCK_PAIRBINS)
+/* one vote for bin k of the row at LDS address p */
+__device__ __forceinline__ void vote_one(const uint32_t p, const int k, const uint32_t inc);
 
 /* Diagnostic build (-DPPF_PHASE_CLOCKS, never the product): every k_vote wave sums the shader clocks (s_memtime) it spends in
  * each phase; ppf_match_stats.phase_clocks = the sums over all waves of the call (tools/vote_phases.py prints them).
@@ -779,6 +787,16 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ void lds_add(const uint32_t addr, const uint32_t v) {
   (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void vote_one(const uint32_t p, const int k, const uint32_t inc) {
+#if PPF_MOCK_PAIRBINS == 1 /* 2: only the counted atomics change (what halving THEIR number is worth on its own) */
+  (void)inc;
+  const uint32_t word = p + (((uint32_t)k & ~1u) << 1);                /* v_and + v_lshl_add */
+  const uint32_t add = __builtin_amdgcn_ubfe((uint32_t)k, 0u, 1u) * 0xFFFFu + 1u; /* v_bfe / v_and + v_mad: 1 or 0x10000 */
+  lds_add(word, add);
+#else
+  lds_add(p + ((uint32_t)k << 2), inc);
+#endif
+}
 __device__ __forceinline__ uint32_t lds_add_rtn(const uint32_t addr, const uint32_t v) {
   return __hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -878,8 +896,8 @@ __device__ __forceinline__ void vote_issue(const uint32_t (&pa)[U], const uint32
 #pragma unroll
   for (int u = 0; u < U; u++) {
     if (u < n_valid) {
-      lds_add(pa[u] + ((uint32_t)ka[u] << 2), ia[u]);
-      lds_add(pb[u] + ((uint32_t)kb[u] << 2), ib[u]);
+      vote_one(pa[u], ka[u], ia[u]);
+      vote_one(pb[u], kb[u], ib[u]);
     }
   }
 }
@@ -962,9 +980,14 @@ __device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const 
   asm volatile("" : "+v"(pr), "+v"(inc));
   const float am = __uint_as_float(alpha_bits);
   uint32_t adr_prev = 0;
+  int k_prev = 0;
   for (int hh = 0; hh < nh; hh++) {
     const float Ohg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ohg_v), hh));
+#if PPF_MOCK_PAIRBINS == 1
+    if (hh) vote_one(pr, k_prev, inc);
+#else
     if (hh) lds_add(adr_prev, inc);
+#endif
     const float q = __builtin_fmaf(am, S, Ohg);
     int k = vote_wrap<WRAP>((int)q, A);
     if (__builtin_expect(__any(__builtin_amdgcn_fractf(q) < G2), 0)) {
@@ -975,8 +998,14 @@ __device__ __forceinline__ void vote_hits_single(const uint32_t acc_base, const 
       if (__builtin_amdgcn_fractf(__builtin_fmaf(az, S, Ohg)) < G2) k = vote_bin_exact<WRAP>(az, as, A);
     }
     adr_prev = pr + ((uint32_t)k << 2);
+    k_prev = k;
+    (void)k_prev;
   }
+#if PPF_MOCK_PAIRBINS == 1
+  if (nh > 0) vote_one(pr, k_prev, inc);
+#else
   if (nh > 0) lds_add(adr_prev, inc);
+#endif
 }
 
 /* ---- aggregated votes ------------------------------------------------------------------------------------------- */
@@ -1173,8 +1202,8 @@ __device__ __forceinline__ void agg_own_vote(const AggConsts& k, const uint32_t 
     if (fa < k.G2) ba = vote_bin_exact_4pi(__uint_as_float(za), g_a64[tbl[TBL_OFF_IDX + ha]], k.A);
     if (fb < k.G2) bb = vote_bin_exact_4pi(__uint_as_float(zb), g_a64[tbl[TBL_OFF_IDX + hb]], k.A);
   }
-  if (da) lds_add(pa + ((uint32_t)ba << 2), inc_a);
-  if (db) lds_add(pb + ((uint32_t)bb << 2), inc_b);
+  if (da) vote_one(pa, ba, inc_a);
+  if (db) vote_one(pb, bb, inc_b);
 }
 
 /* Own-cell state of the two entries of one pair record: the ranges of their cells in the table's cell-sorted hit list (an
@@ -1229,11 +1258,32 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
     for (int jj = 0; jj < 4; jj++) { sa[jj] = sa0 + (uint32_t)jj * sta; sb[jj] = sb0 + (uint32_t)jj * stb; }
   }
 #if PPF_ABL_COUNTED
+#if PPF_MOCK_PAIRBINS == 3 /* nine 64-bit atomics (two adjacent words each), one v_perm per count as now: timing of the ds_add_u64 form */
+  {
+    const uint32_t va8 = va & ~7u, vb8 = vb & ~7u;
+#pragma unroll
+    for (int j = 0; j <= AGG_NY; j += 2) {
+      const int j1 = j + 1 > AGG_NY ? j : j + 1;
+      const unsigned long long da = ((unsigned long long)__builtin_amdgcn_perm(0u, wa[j1 >> 2], sa[j1 & 3]) << 32) | __builtin_amdgcn_perm(0u, wa[j >> 2], sa[j & 3]);
+      const unsigned long long db = ((unsigned long long)__builtin_amdgcn_perm(0u, wb[j1 >> 2], sb[j1 & 3]) << 32) | __builtin_amdgcn_perm(0u, wb[j >> 2], sb[j & 3]);
+      typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+      (void)__hip_atomic_fetch_add((lds_u64*)(uintptr_t)(va8 + (uint32_t)((AGG_NY - j) * 4)), da, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add((lds_u64*)(uintptr_t)(vb8 + (uint32_t)((AGG_NY - j) * 4)), db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+#elif PPF_MOCK_PAIRBINS
+#pragma unroll
+  for (int j = 0; j <= AGG_NY; j += 2) { /* 9 atomics, one two-source v_perm each */
+    lds_add(va + (uint32_t)((AGG_NY - j) * 2), __builtin_amdgcn_perm(wa[(j + 1 > AGG_NY ? j : j + 1) >> 2], wa[j >> 2], sa[(j >> 1) & 3]));
+    lds_add(vb + (uint32_t)((AGG_NY - j) * 2), __builtin_amdgcn_perm(wb[(j + 1 > AGG_NY ? j : j + 1) >> 2], wb[j >> 2], sb[(j >> 1) & 3]));
+  }
+#else
 #pragma unroll
   for (int j = 0; j <= AGG_NY; j++) {
     lds_add(va + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wa[j >> 2], sa[j & 3]));
     lds_add(vb + (uint32_t)((AGG_NY - j) * 4), __builtin_amdgcn_perm(0u, wb[j >> 2], sb[j & 3]));
   }
+#endif
 #endif
   const uint32_t na = ca.y - ca.x, nb = cb.y - cb.x;
   votes += na + nb;
