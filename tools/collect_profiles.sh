@@ -28,7 +28,16 @@ if [ "$WHAT" = lines ] || [ "$WHAT" = benchlines ]; then
     rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c4" -o c4 -- python3 "$ROOT/bench.py" --config c4 --cells 32 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c4.log" 2>&1
     rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace_c5" -o c5 -- python3 "$ROOT/bench.py" --config c5 --steps 3 --warmup 1 > "$ROOT/$OUT/trace_c5.log" 2>&1 )
   echo "traces done"
-  tools/vote_variants.sh "$OUT/classes" product a_counted0 a_owncell0 a_dsmall0 a_dbig0 a_dbig2 a_aggonly a_directonly a_none
+  # the reference's real call and its ICP: timings and the ICP kernels' trace
+  python tools/pipeline_timing.py > "$OUT/pipeline_timing.json" 2> "$OUT/pipeline_timing.err"
+  python tools/icp_timing.py --repeat 5 > "$OUT/icp_timing.json" 2> "$OUT/icp_timing.err"
+  python tools/icp_timing.py --repeat 5 --legacy > "$OUT/icp_timing_legacy.json" 2>> "$OUT/icp_timing.err"
+  ( cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace_icp" -o icp -- python3 "$ROOT/tools/icp_timing.py" --repeat 3 > "$ROOT/$OUT/trace_icp.log" 2>&1 )
+  echo "pipeline and ICP done"
+  if [ -f build_var/a_none.so ]; then
+    tools/vote_variants.sh "$OUT/classes" product a_counted0 a_owncell0 a_dsmall0 a_dbig0 a_dbig2 a_aggonly a_directonly a_none
+  fi
 else
   tools/pmc_vote.sh "$OUT/pmc_c2"
   echo "pmc c2 done"

@@ -57,6 +57,17 @@ def main():
             open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{w}.json"), "w").write(summary)
             s = json.loads(summary)
             print(w, "k_vote fabric GB/s %.0f" % s["hbm_gbs_k_vote"], {k: round(v, 3) for k, v in s["k_vote_issue"].items() if isinstance(v, float) and v < 10})
+    # the reference's real call (frame -> pose) and its ICP step
+    for n in ("pipeline_timing", "icp_timing", "icp_timing_legacy"):
+        q = os.path.join(src, n + ".json")
+        if os.path.exists(q):
+            open(os.path.join(ROOT, "profiles", f"{tag}_{n}.json"), "w").write(last_line(q) + "\n")
+            d = json.loads(last_line(q))
+            print(n, d.get("frame_to_pose_ms") or d.get("gpu_seconds"), d.get("of_which_ms", ""))
+    icp_csv = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(src, "trace_icp")) for f in fs if f.endswith("kernel_stats.csv")]
+    if icp_csv:
+        rows = [ln for ln in open(icp_csv[0]).read().splitlines() if ln.startswith('"Name"') or "icp" in ln]
+        open(os.path.join(ROOT, "profiles", f"{tag}_icp_kernel_stats.csv"), "w").write("\n".join(rows) + "\n")
     cdir = os.path.join(src, "classes")
     if os.path.isdir(cdir):
         md = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vote_classes_summary.py"), cdir, "product", tag], check=True,
