@@ -142,3 +142,61 @@ def test_icp_argument_errors(bottle):
         ICP().registerModelToScene(bottle[:0], bottle)
     with pytest.raises(PPFError):
         ICP(iterations=-1).registerModelToScene(bottle[:100], bottle[:100])
+
+
+def test_icp_concurrent_calls_from_two_threads(bottle):
+    """two host threads refining at the same time: one works on the process-wide scratch of the batched schedule, the other on
+    a private one (its own pinned counters and states); both get what a single call gets, bit for bit"""
+    import threading
+    T = synth.rigid_pose(5, 0.1)
+    model, scene = bottle[::8].copy(), synth.apply_pose(bottle[3::5], T)
+    mats = [_perturb(T, 4.0, [0.004, -0.003, 0.002]), _perturb(T, -3.0, [0.0, 0.002, 0.001], axis=0), T]
+    ref = ICP(100, 0.005, 2.5, 8)
+    want = ref.registerModelToScene(model, scene, _poses(mats))
+    out, errs = {}, []
+    gate = threading.Barrier(2)
+
+    def work(k):
+        try:
+            gate.wait()
+            for _ in range(6):
+                icp = ICP(100, 0.005, 2.5, 8)
+                out[k] = (icp.registerModelToScene(model, scene, _poses(mats)), icp.last_iterations)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for k in range(2):
+        got, its = out[k]
+        assert its == ref.last_iterations
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g.pose, w.pose)
+            assert g.residual == w.residual
+
+
+def test_icp_grid_search_on_every_level_ties_and_many_poses(bottle):
+    """the grid neighbour search forced onto every level (steps that are no powers of two: 1,733 model rows; scene rows
+    that exist twice: equal distances must go to the smaller index; a scene of one dense spot plus far outliers: nearly all
+    rows in one leaf), and more poses than one batch of launches carries (11 > 8): the oracle's poses, residuals and
+    iteration counts bit for bit"""
+    from yolo_ppf_pose_estimation_amd import _capi
+    scene, Ts = synth.make_scene(bottle, n_points=3001, seed=77)
+    T = Ts[0]
+    model = bottle[::11][:1733].copy()
+    twice = np.vstack([scene, scene[::-1]]).astype(np.float32)          # every row twice, the copies in reverse order
+    rng = np.random.default_rng(5)
+    far = np.hstack([rng.uniform(-30, 30, size=(40, 3)), np.tile([0, 0, 1.0], (40, 1))]).astype(np.float32)
+    spotty = np.vstack([scene, far]).astype(np.float32)
+    mats = [_perturb(T, 3.0 - 0.5 * k, [0.003, 0.0005 * k, -0.002]) for k in range(11)]
+    for sc, ms in ((twice, mats[:2]), (spotty, mats[:2]), (scene, mats)):
+        want_P, want_r, want_i = O.icp_refine(model, sc, ms)
+        for flags in (_capi.PPF_ICP_GRID_ALWAYS, 0):
+            icp = ICP(100, 0.005, 2.5, 8, flags=flags)
+            got = icp.registerModelToScene(model, sc, _poses(ms))
+            assert icp.last_iterations == list(want_i)
+            for g, P, r in zip(got, want_P, want_r):
+                np.testing.assert_array_equal(g.pose, P)
+                assert g.residual == r

@@ -367,7 +367,7 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
     while (true) {
       const int batch = std::min((int)PPF_ICP_BATCH2, max_iter - launched);
       for (int b = 0; b < batch; b++) {
-        k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift, nn_rows);
+        k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift, nn_rows, (prm.flags & PPF_ICP_GRID_ALWAYS) ? 0 : ICP_BRUTE_ND);
         k_icp2_tail<<<dim3(uj), dim3(1024), tail_lds, st>>>(B, ns, nd, step, prm.rejection_scale, staged, level == 0 ? 1 : 0);
       }
       launched += std::max(batch, 0);

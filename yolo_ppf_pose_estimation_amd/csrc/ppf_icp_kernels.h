@@ -1134,7 +1134,7 @@ __device__ __forceinline__ float icp_box_lb2(const float4 lo, const float4 hi, f
 
 /* exact nearest neighbour of every source row of the level and the picky-ownership keys (see the header of this section) */
 constexpr int ICP_NN_ROWS = 8; /* rows a wave takes in turn, at most */
-__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int step, int step_shift, int rows) {
+__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int step, int step_shift, int rows, int brute_nd) {
   const int job = blockIdx.y;
   const IcpState2* st = B.state + job;
   if (st->done) return;
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int
       }
     }
     unsigned long long key = (unsigned long long)ICP_FLT_MAX_BITS << 32; /* nothing closer than FLT_MAX: index 0, as the sequential loop leaves it */
-    if (nd <= ICP_BRUTE_ND) {
+    if (nd <= brute_nd) {
       for (int b = lane; b < nd; b += 64) {
         const float* pq = dst0 + (size_t)b * step * 6;
         const float dx = qx - pq[0], dy = qy - pq[1], dz = qz - pq[2];
