@@ -374,3 +374,72 @@ def test_tiny_case_accumulators_from_an_independent_numpy_voter():
     flat = acc.argmax(1)  # numpy's argmax returns the first maximum: model row ascending, bin ascending, strict >
     np.testing.assert_array_equal(np.stack([flat // A, flat % A, acc.max(1)], 1).astype(np.uint32), g["tiny_triples"])
     assert int(g["tiny_info"][0]) == slots and int(g["tiny_info"][1]) == A
+
+
+def test_tiny_case_raw_poses_from_an_independent_composition():
+    """Second source for the pose assembly: pose = T_sg^-1 * Rx(alpha_idx * 4 pi / A - 2 pi) * T_mg
+    composed in numpy from the golden vote triples, against the oracle's per-reference-point poses (which the GPU path must equal
+    bit for bit).  numpy's libm and the oracle's deterministic math differ in the last units: 1e-12."""
+    import math
+    import oracle_lib as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
+    model, scene, A = g["tiny_model"], g["tiny_scene"], 30
+
+    def frame(p, n):
+        p, n = p.astype(np.float64), n.astype(np.float64)
+        ang, ax = math.acos(n[0]), np.array([0.0, n[2], -n[1]])
+        ax = ax / np.linalg.norm(ax) if (n[1] != 0 or n[2] != 0) else np.array([0.0, 1.0, 0.0])
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        T = np.eye(4)
+        T[:3, :3] = math.cos(ang) * np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * np.outer(ax, ax)
+        T[:3, 3] = -T[:3, :3] @ p
+        return T
+
+    det = O.OracleDetector(0.05, 0.05).train_model(model, presampled=True)
+    r = det.match(scene, relative_scene_sample_step=1.0, presampled=True, cluster=False)
+    np.testing.assert_array_equal(r["triples"], g["tiny_triples"])
+    for i, (ref, idx, votes) in enumerate(g["tiny_triples"]):
+        a = float(idx) * (4 * math.pi / A) - 2 * math.pi
+        Rx = np.eye(4)
+        Rx[1:3, 1:3] = [[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]]
+        want = np.linalg.inv(frame(scene[i, :3], scene[i, 3:])) @ Rx @ frame(model[ref, :3], model[ref, 3:])
+        got = np.asarray(r["raw_poses"][i]["pose"], dtype=np.float64).reshape(4, 4)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+        assert r["raw_poses"][i]["num_votes"] == int(votes)
+
+
+def test_pose_clustering_from_an_independent_greedy_clusterer():
+    """Second source for clusterPoses on the golden bottle case (150 voted poses): poses by votes
+    descending (ties: input order), each joins the FIRST cluster whose first pose lies within the position threshold (the
+    relative sampling step used as metres) and whose rotation angle differs by less than the (ineffective, ~30 rad) rotation
+    threshold, else opens one; a cluster's votes are its members' sum, its translation their plain mean, clusters by votes
+    descending.  Membership, vote sums, cluster count and translations against the oracle's clustered result (the rotation
+    average goes through upstream's quaternion conventions and is left to the oracle)."""
+    import oracle_lib as O
+    from yolo_ppf_pose_estimation_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
+    bottle = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bottle_model_xyzn.npy"))
+    scene, _ = synth.make_scene(bottle, n_points=int(g["b07_scene_seed"][1]), seed=int(g["b07_scene_seed"][0]))
+    det = O.OracleDetector(0.07, 0.05).train_model(bottle)
+    r = det.match(scene, relative_scene_sample_step=1.0 / 10.0, presampled=True)
+    raw = r["raw_poses"]
+    n_poses = len(r["sampled_scene"]) // 10 if len(r["sampled_scene"]) else len(raw)  # rows / step, integer division
+    order = sorted(range(len(raw)), key=lambda i: -raw[i]["num_votes"])  # stable: ties keep input order
+    pos_thr, rot_thr = 0.07, (360.0 / (2 * np.pi / 30)) / 180.0 * np.pi
+    clusters = []
+    for i in order[:min(n_poses, len(order))]:
+        for c in clusters:
+            head = raw[c[0]]
+            if np.linalg.norm(head["t"] - raw[i]["t"]) < pos_thr and abs(raw[i]["angle"] - head["angle"]) < rot_thr:
+                c.append(i)
+                break
+        else:
+            clusters.append([i])
+    votes = [sum(raw[i]["num_votes"] for i in c) for c in clusters]
+    corder = sorted(range(len(clusters)), key=lambda k: -votes[k])
+    assert len(clusters) == r["n_final"] == int(g["b07_n_final"][0])
+    for rank, k in enumerate(corder[:5]):
+        assert votes[k] == r["poses"][rank]["num_votes"] == int(g["b07_top_votes"][rank])
+        t_mean = np.sum([raw[i]["t"] for i in clusters[k]], axis=0) * (1.0 / len(clusters[k]))
+        np.testing.assert_allclose(r["poses"][rank]["t"], t_mean, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(g["b07_top_poses"][rank][:3, 3], t_mean, rtol=0, atol=1e-15)
