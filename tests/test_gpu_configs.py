@@ -144,6 +144,14 @@ def test_c2_crop_seen_twice_overflows_some_16_bit_cells(bottle, det_c2):
     assert n_over > 0 and res["stats"]["n_acc32_items"] >= n_over and res["stats"]["n_retries"] == 0
     # PPF_OPT_ACC32 = 3: the per-item vote limit (learned by the first call, applied by the second, which sends the heavy
     # (reference point, tile)s to 32-bit cells without a 16-bit attempt): the same triples and totals both times
+    ws2 = Workspace()
+    ws2.set_option(_capi.PPF_OPT_ACC32, 2)  # 16-bit cells first, always: the second call must not have switched to 32-bit cells
+    for call in range(2):
+        ws2.match_device(det_c2, d.data_ptr(), scene.shape[0], 6, STEP, W.REL_DISTANCE, presampled=True, ref_offset=0, ref_stride=stride,
+                         skip_clustering=True)
+        r2 = ws2.results(scene.shape[0])
+        np.testing.assert_array_equal(r2["triples"], want["triples"])
+        assert n_over <= r2["stats"]["n_acc32_items"] < res["n_ref"]
     ws3 = Workspace()
     ws3.set_option(_capi.PPF_OPT_ACC32, 3)
     for call in range(2):
