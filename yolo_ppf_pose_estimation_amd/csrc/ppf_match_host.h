@@ -216,6 +216,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   if (ws->timing) HIPCHK(hipEventRecord(ws->ev[0], st));
   HIPCHK(hipMemsetAsync(ws->counters.p, 0, n_cnt * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync(ws->ovf_items.p, 0, (size_t)n_ref * T * sizeof(uint32_t), st));
+  if (ws->acc_dump) /* debug dump of the full accumulators: a repeat of the call starts from zeros again (one of its cells is accumulated, not assigned) */
+    HIPCHK(hipMemsetAsync(ws->acc_dump, 0, (size_t)n_ref * (size_t)m->info.n_ref * (size_t)m->info.num_angles * sizeof(uint32_t), st));
   if (ws->acc32_policy == 3) {
     HIPCHK(hipMemsetAsync(ws->need_hist.p, 0, 2 * ACC_HIST * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(ws->item_votes.p, 0, (size_t)n_ref * T * sizeof(unsigned long long), st));
@@ -596,6 +598,12 @@ ppf_status ppf_debug_accumulators(const ppf_model* m, const float* scene, int ns
   p.skip_clustering = 1;
   ppf_status s = run_host(m, scene, ns, sstride, snoff, edge, ne, estride, enoff, &p, &ws);
   if (s != PPF_OK) return s;
+  /* a cold workspace sizes its pools from estimates: when one ran out, runs were left out of the vote and the dump is incomplete.
+   * workspace_finish reads the flag and repeats the call with bigger pools (match_prepared clears the dump first) -- without it
+   * this entry returned a partial accumulator whenever the table pool's first guess was too small, depending on which
+   * reference points reached the pool first */
+  if ((s = workspace_finish(&ws)) != PPF_OK) return s;
+  HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipMemcpy(acc, dump.p, per_ref * nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (n_ref) *n_ref = nr;
   return PPF_OK;

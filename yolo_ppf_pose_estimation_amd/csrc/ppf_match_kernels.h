@@ -1543,6 +1543,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           mm = run.z;
           tb0 = run.w;
           heavy_run = run.z >= agg_min;
+          (void)heavy_run; /* only the two-queue variant (PPF_TWO_QUEUES) counts them */
           if (cnt) {
             if (run.z >= agg_min && cnt >= PPF_AGG_MIN_RECORDS) {
               items = ((run.z + AGG_SUB - 1) / AGG_SUB) * ((cnt + AGG_CHUNK - 1) / AGG_CHUNK);
