@@ -211,7 +211,7 @@ typedef struct ppf_icp_params {
 #define PPF_ICP_NO_SMALL_LEVELS 1
 #define PPF_ICP_ONE_STREAM 2
 #define PPF_ICP_LEGACY 4
-#define PPF_ICP_GRID_ALWAYS 8 /* test knob: the grid neighbour search on every level (by default levels of at most 4,096 scene rows scan them all) */
+#define PPF_ICP_GRID_ALWAYS 8 /* test knob: the grid neighbour search on every level (by default levels of at most 1,024 scene rows scan them all) */
 
 void ppf_default_train_params(ppf_train_params* p);
 void ppf_default_match_params(ppf_match_params* p);

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(1024) void k_icp_level_small(const float* __restric
  * ============================================================================================================ */
 constexpr int ICP_MAX_JOBS = 8;     /* poses refined per batch of launches */
 constexpr int ICP_LEAVES = 4096;    /* 16 x 16 x 16 cells, grouped 4 x 4 x 4 under 64 nodes */
-constexpr int ICP_BRUTE_ND = 4096;  /* levels with at most this many scene rows scan them all */
+constexpr int ICP_BRUTE_ND = 1024;  /* levels with at most this many scene rows scan them all (16 steps of a wave; C1 level 2, 2,599 rows: 58 us scanning them all, 25 us through the grid) */
 constexpr float ICP_LB_SHRINK = 0.9999f;
 
 struct IcpState2 {
@@ -747,19 +747,30 @@ __device__ __forceinline__ void icp_tick(const IcpBatch& B, bool wrote) {
   else __hip_atomic_fetch_add(B.h_ticks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__device__ __forceinline__ float icp_wave_minf(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
+/* Smallest value over the wave, in every lane.  Through DPP (data-parallel primitives of the VALU: a lane reads its neighbour's
+ * register inside the instruction), not through __shfl: the shuffles of this compiler are ds_bpermute_b32, LDS instructions with
+ * a hundred cycles of latency each, and the neighbour search makes a dozen reductions per query (88 ds_bpermute in its ISA).
+ * Prefix-min inside the rows of 16 (row_shr 1, 2, 4, 8: a lane without a source keeps the identity), row 0's and row 2's last
+ * lane into rows 1 and 3 (row_bcast15), row 1's into rows 2 and 3 (row_bcast31): lane 63 has it. */
+__device__ __forceinline__ uint32_t icp_wave_min_u32(uint32_t v) {
+#define ICP_DPP_MIN(ctrl, rows) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, ctrl, rows, 0xf, false))
+  ICP_DPP_MIN(0x111, 0xf);
+  ICP_DPP_MIN(0x112, 0xf);
+  ICP_DPP_MIN(0x114, 0xf);
+  ICP_DPP_MIN(0x118, 0xf);
+  ICP_DPP_MIN(0x142, 0xa);
+  ICP_DPP_MIN(0x143, 0xc);
+#undef ICP_DPP_MIN
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+/* ... of floats that are >= +0 or +inf (their bit patterns order like they do) */
+__device__ __forceinline__ float icp_wave_minf(float v) { return __uint_as_float(icp_wave_min_u32(__float_as_uint(v))); }
+/* ... of 64-bit keys (distance bits, index): the smallest high word, then the smallest low word among the lanes that have it */
 __device__ __forceinline__ unsigned long long icp_wave_min64(unsigned long long k) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)k, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), o);
-    const unsigned long long y = ((unsigned long long)hi << 32) | lo;
-    k = y < k ? y : k;
-  }
-  return k;
+  const uint32_t hi = (uint32_t)(k >> 32);
+  const uint32_t hmin = icp_wave_min_u32(hi);
+  const uint32_t lmin = icp_wave_min_u32(hi == hmin ? (uint32_t)k : 0xFFFFFFFFu);
+  return ((unsigned long long)hmin << 32) | lmin;
 }
 
 /* prologue 1: src0 = T0 * src (or a copy), dst0 = a copy, and the per-chunk coordinate sums (rows of a chunk in order) */
@@ -1082,8 +1093,8 @@ __global__ __launch_bounds__(256) void k_icp2_grid_boxes(IcpBatch B) {
   }
   if (lane != 0) return;
   float4* box2 = B.g_box2 + (size_t)job * ICP_LEAVES * 2;
-  box2[leaf * 2] = make_float4(l[0], l[1], l[2], 0.f);
-  box2[leaf * 2 + 1] = make_float4(h[0], h[1], h[2], 0.f);
+  box2[leaf * 2] = make_float4(l[0], l[1], l[2], __uint_as_float(s));         /* .w: where the leaf's rows start ... */
+  box2[leaf * 2 + 1] = make_float4(h[0], h[1], h[2], __uint_as_float(e - s)); /* ... and how many: the search reads no second table */
   if (e > s) {
     uint32_t* nb = B.g_box1u + ((size_t)job * 64 + (leaf >> 6)) * 8;
 #pragma unroll
@@ -1144,7 +1155,6 @@ __global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int
   if (a0 >= ns) return;
   const float* dst0 = B.dst0 + (size_t)job * B.nd_all * 6;
   const float4* __restrict__ pts = B.g_pts + (size_t)job * B.nd_all;
-  const uint32_t* __restrict__ g_start = B.g_start + (size_t)job * (ICP_LEAVES + 64);
   const float4* __restrict__ box2 = B.g_box2 + (size_t)job * ICP_LEAVES * 2;
   const uint32_t* __restrict__ box1u = B.g_box1u + ((size_t)job * 64 + lane) * 8;
   const float4 n_lo = make_float4(icp_o2f(box1u[0]), icp_o2f(box1u[1]), icp_o2f(box1u[2]), 0.f);
@@ -1186,45 +1196,85 @@ __global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int
       key = icp_wave_min64(key);
     } else {
       float ubest = 3.402823466e+38f; /* wave-uniform: smallest distance found so far */
-      auto scan_leaf = [&](const int leaf) {
-        const uint32_t s = g_start[leaf], e = g_start[leaf + 1];
-        for (uint32_t i = s + (uint32_t)lane; i < e; i += 64) {
-          const float4 pq = pts[i];
-          const int idx = __float_as_int(pq.w);
-          int b;
-          bool in;
-          if (step_shift >= 0) { b = idx >> step_shift; in = (idx & (step - 1)) == 0; }
-          else { b = idx / step; in = b * step == idx; }
-          const float dx = qx - pq.x, dy = qy - pq.y, dz = qz - pq.z;
-          const float d2 = (dx * dx + dy * dy) + dz * dz;
-          const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
-          if (in) key = k < key ? k : key;
+      /* one row of the leaf-ordered list against the query */
+      auto take = [&](const float4 pq, const bool valid) {
+        const int idx = __float_as_int(pq.w);
+        int b;
+        bool in;
+        if (step_shift >= 0) { b = idx >> step_shift; in = (idx & (step - 1)) == 0; }
+        else { b = idx / step; in = b * step == idx; }
+        const float dx = qx - pq.x, dy = qy - pq.y, dz = qz - pq.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)b;
+        if (valid && in) key = k < key ? k : key;
+      };
+      /* the rows [s0, s0 + n0) and [s1, s1 + n1) against the query: TWO leaves per memory round trip, and four steps' loads of
+       * each at once (a leaf on a dense surface holds hundreds of rows) */
+      auto scan_two = [&](const uint32_t s0, const uint32_t n0, const uint32_t s1, const uint32_t n1) {
+        const uint32_t nmax = n0 > n1 ? n0 : n1;
+        for (uint32_t i0 = 0; i0 < nmax; i0 += 256) {
+          float4 pa[4], pb[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
+            pa[u] = pts[s0 + (i < n0 ? i : 0u)]; /* a leaf with rows starts inside the list; an empty one reads row s0 (clamped into the list by the caller) */
+            pb[u] = pts[s1 + (i < n1 ? i : 0u)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
+            take(pa[u], i < n0);
+            take(pb[u], i < n1);
+          }
         }
         key = icp_wave_min64(key);
         ubest = __uint_as_float((uint32_t)(key >> 32));
       };
+      const uint32_t last_row = (uint32_t)B.nd_all - 1u;
+      /* one node: lane l tests child l (its box arrives with the child's row range: no second table to read); `first` (>= 0) is
+       * scanned whatever its bound -- the query's own leaf, which gives the search a distance to prune with --, then the
+       * children nearest first, two at a time: the first one whose bound exceeds the best distance ends the list (the second of
+       * a pair is scanned on the bound as it stood before the first: scanning a leaf too many costs nothing but its rows) */
+      auto visit_node = [&](const int k1, const int first) {
+        const int c0 = k1 * 64 + lane;
+        const float4 c_lo = box2[c0 * 2], c_hi = box2[c0 * 2 + 1];
+        float lb2 = icp_box_lb2(c_lo, c_hi, qx, qy, qz);
+        lb2 = lb2 != lb2 ? 0.f : lb2; /* a NaN query: every box is opened */
+        const int c_start = (int)min((uint32_t)__float_as_int(c_lo.w), last_row), c_count = __float_as_int(c_hi.w);
+        int ka = first;
+        if (first >= 0 && lane == first) lb2 = __builtin_inff();
+        while (true) {
+          if (ka < 0) {
+            const float m2 = icp_wave_minf(lb2);
+            if (m2 * ICP_LB_SHRINK > ubest) break;
+            ka = __builtin_ctzll(__ballot(lb2 == m2));
+            if (lane == ka) lb2 = __builtin_inff();
+          }
+          int kb = -1;
+          {
+            const float m2 = icp_wave_minf(lb2);
+            if (!(m2 * ICP_LB_SHRINK > ubest)) {
+              kb = __builtin_ctzll(__ballot(lb2 == m2));
+              if (lane == kb) lb2 = __builtin_inff();
+            }
+          }
+          scan_two((uint32_t)__builtin_amdgcn_readlane(c_start, ka), (uint32_t)__builtin_amdgcn_readlane(c_count, ka),
+                   kb >= 0 ? (uint32_t)__builtin_amdgcn_readlane(c_start, kb) : 0u, kb >= 0 ? (uint32_t)__builtin_amdgcn_readlane(c_count, kb) : 0u);
+          ka = -1;
+          if (kb < 0) break;
+        }
+      };
       const int own = icp_leaf_id(icp_cell_of(qx, ox, inv_h), icp_cell_of(qy, oy, inv_h), icp_cell_of(qz, oz, inv_h));
-      scan_leaf(own);
-      /* nodes, then the children of an opened node, nearest first: the first one whose bound exceeds the best distance ends
-       * its list (a query far from the data would otherwise open box after box in index order, each a little closer) */
       float lb1 = icp_box_lb2(n_lo, n_hi, qx, qy, qz);
-      lb1 = lb1 != lb1 ? 0.f : lb1; /* a NaN query: every box is opened */
-      while (true) {
+      lb1 = lb1 != lb1 ? 0.f : lb1;
+      visit_node(own >> 6, own & 63);
+      if (lane == (own >> 6)) lb1 = __builtin_inff();
+      while (true) { /* the other nodes, nearest first */
         const float m = icp_wave_minf(lb1);
         if (m * ICP_LB_SHRINK > ubest) break;
         const int k1 = __builtin_ctzll(__ballot(lb1 == m));
         if (lane == k1) lb1 = __builtin_inff();
-        const int c0 = k1 * 64 + lane;
-        float lb2 = icp_box_lb2(box2[c0 * 2], box2[c0 * 2 + 1], qx, qy, qz);
-        lb2 = lb2 != lb2 ? 0.f : lb2;
-        if (c0 == own) lb2 = __builtin_inff(); /* already scanned */
-        while (true) {
-          const float m2 = icp_wave_minf(lb2);
-          if (m2 * ICP_LB_SHRINK > ubest) break;
-          const int k2 = __builtin_ctzll(__ballot(lb2 == m2));
-          if (lane == k2) lb2 = __builtin_inff();
-          scan_leaf(k1 * 64 + k2);
-        }
+        visit_node(k1, -1);
       }
     }
     if (lane == 0) B.best[(size_t)job * B.n + a] = key;
