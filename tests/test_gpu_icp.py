@@ -2,6 +2,8 @@
 (oracle/ppf_icp_oracle.cpp).  The device kernels follow the oracle's arithmetic and summation orders, so poses,
 residuals and iteration counts must be IDENTICAL, not just close.  Reference call site:
 /root/reference/include/CloudProcessing.h:465-470, :518-523 (ICP icp(100, 0.005f, 2.5f, 8))."""
+import os
+
 import numpy as np
 import pytest
 
@@ -200,3 +202,45 @@ def test_icp_grid_search_on_every_level_ties_and_many_poses(bottle):
             for g, P, r in zip(got, want_P, want_r):
                 np.testing.assert_array_equal(g.pose, P)
                 assert g.residual == r
+
+
+def _icp_draw(seed):
+    rng = np.random.default_rng(7000 + seed)
+    return dict(kind=["bottle", "box", "cylinder", "torus"][int(rng.integers(0, 4))],
+                model_step=int(rng.integers(3, 14)), model_rows=int(rng.integers(300, 4000)),
+                n_scene=int(rng.integers(700, 9000)), scene_seed=int(rng.integers(0, 10 ** 6)),
+                clutter=bool(rng.integers(0, 3)), n_poses=int(rng.integers(1, 10)),
+                max_deg=float(rng.choice([1.0, 4.0, 12.0, 40.0])), max_shift=float(rng.choice([0.001, 0.005, 0.03])),
+                iterations=int(rng.choice([3, 20, 100])), tolerance=float(rng.choice([0.0, 0.005, 0.05])),
+                rejection_scale=float(rng.choice([0.0, 1.0, 2.5, 4.0])), num_levels=int(rng.choice([1, 2, 3, 5, 8])),
+                grid_always=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(6 + int(os.environ.get("PPF_SOAK_ICP", "0"))))
+def test_icp_random_draw(bottle, seed):
+    """seeded draws over model shape and size, scene size and clutter, number of poses, how far off they start (up to poses
+    thrown off the object: the <= 6 correspondences break path), every ICP parameter and the neighbour-search schedule:
+    poses, residuals and iteration counts equal the oracle's bit for bit (PPF_SOAK_ICP=N adds N draws, tools/soak.sh)"""
+    from yolo_ppf_pose_estimation_amd import _capi
+    cfg = _icp_draw(seed)
+    rng = np.random.default_rng(seed)
+    full = bottle if cfg["kind"] == "bottle" else synth.make_solid(cfg["kind"], 12000, seed=seed + 3)
+    model = full[::cfg["model_step"]][:cfg["model_rows"]].copy()
+    if cfg["clutter"]:
+        scene, Ts = synth.make_scene(full, n_points=cfg["n_scene"], seed=cfg["scene_seed"])
+        T = Ts[0]
+    else:
+        T = synth.rigid_pose(cfg["scene_seed"] % 1000, 0.2)
+        pick = rng.permutation(full.shape[0])[:cfg["n_scene"]]
+        scene = synth.apply_pose(full[np.sort(pick)], T)
+    mats = [_perturb(T, float(rng.uniform(-1, 1)) * cfg["max_deg"], rng.uniform(-1, 1, 3) * cfg["max_shift"], axis=int(rng.integers(0, 3)))
+            for _ in range(cfg["n_poses"])]
+    kw = dict(iterations=cfg["iterations"], tolerance=cfg["tolerance"], rejection_scale=cfg["rejection_scale"], num_levels=cfg["num_levels"])
+    want_P, want_r, want_i = O.icp_refine(model, scene, mats, **kw)
+    icp = ICP(kw["iterations"], kw["tolerance"], kw["rejection_scale"], kw["num_levels"],
+              flags=_capi.PPF_ICP_GRID_ALWAYS if cfg["grid_always"] else 0)
+    got = icp.registerModelToScene(model, scene, _poses(mats))
+    assert icp.last_iterations == list(want_i), cfg
+    for g, P, r in zip(got, want_P, want_r):
+        np.testing.assert_array_equal(g.pose, P, err_msg=str(cfg))
+        assert g.residual == r, cfg

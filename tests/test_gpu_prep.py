@@ -2,6 +2,8 @@
 (oracle/ppf_prep_oracle.cpp), bit for bit, on the reference's own depth frame and on synthetic clouds; then the
 reference's whole sequence crop -> subsample -> outlier removal -> normals -> edges -> Matching_S2B (+ICP) through the
 CloudProcessor mirror (/root/reference/src/YOLO_cropping_ppf_test.cpp:84-123)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -184,3 +186,46 @@ def test_reference_sequence_on_a_synthetic_frame(bottle):
     assert (pose_dev.numVotes, pose_dev.residual) == (pose.numVotes, pose.residual)
     # plain surface matching votes for the wall that fills the crop (planes beat the bottle); it still returns a pose
     assert cp.Matching("bottle", obj_mat, 0.05, 0.05) is not None
+
+
+@pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PPF_SOAK_PREP", "0"))))
+def test_stages_random_draw(frame, seed):
+    """seeded draws over the stages' parameters and inputs (a random window of the reference's frame or a synthetic plane +
+    sphere cloud with noise, duplicated rows and a few non-finite ones): voxel grid, neighbour lists, outlier removal, normals
+    and edges equal the oracle bit for bit (PPF_SOAK_PREP=N adds N draws, tools/soak.sh)"""
+    rng = np.random.default_rng(9000 + seed)
+    if rng.integers(0, 2):
+        xyz = frame[0]
+        lo = int(rng.integers(0, xyz.shape[0] - 30000))
+        cloud = xyz[lo:lo + int(rng.integers(2000, 30000)):int(rng.integers(1, 4))].copy()
+        cloud = cloud[np.isfinite(cloud).all(axis=1) & (cloud[:, 2] > 0)]
+    else:
+        a, _ = D.plane_cloud(int(rng.integers(200, 3000)), seed=seed, noise=float(rng.choice([0.0, 0.0005, 0.003])))
+        b, _ = D.sphere_cloud(int(rng.integers(200, 4000)), seed=seed + 1)
+        cloud = np.concatenate([a, b]).astype(np.float32)
+        cloud = np.concatenate([cloud, cloud[rng.integers(0, cloud.shape[0], 50)]])   # rows that exist twice: distance ties
+    if cloud.shape[0] < 80:
+        pytest.skip("an empty window of the frame")
+    leaf = float(rng.choice([0.002, 0.003, 0.005, 0.011]))
+    dirty = cloud.copy()
+    dirty[int(rng.integers(0, dirty.shape[0]))] = [np.nan, 0.0, 1.0]
+    np.testing.assert_array_equal(DeviceCloud.upload(dirty).voxel_grid(leaf).xyz(), O.prep_voxel(dirty, leaf))
+    sub = O.prep_voxel(cloud, leaf)
+    dc = DeviceCloud.upload(sub)
+    k = int(rng.integers(2, 65))
+    if sub.shape[0] > k:
+        idx, d2 = dc.knn(k)
+        widx, wd2 = O.prep_knn(sub, k)
+        np.testing.assert_array_equal(idx, widx)
+        np.testing.assert_array_equal(d2, wd2)
+    mean_k, mul = int(rng.integers(2, 64)), float(rng.choice([0.5, 1.0, 2.0]))
+    keep, _, _ = O.prep_sor(sub, mean_k, mul)
+    filt = dc.outlier_removal(mean_k, mul)
+    np.testing.assert_array_equal(filt.xyz(), sub[keep])
+    kn = int(rng.integers(3, 65))
+    n, c = O.prep_normals(sub[keep], kn)
+    rows, curv = filt.normals(kn).download()
+    np.testing.assert_array_equal(rows[:, 3:], n)
+    np.testing.assert_array_equal(curv, c)
+    thr = float(rng.choice([0.01, 0.03, 0.08]))
+    np.testing.assert_array_equal(filt.normals(kn).edges(thr).rows(), rows[c > thr])

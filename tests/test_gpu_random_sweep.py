@@ -1,9 +1,12 @@
-"""Seeded random sweep of the hot path against the oracle: 24 configurations drawn over model shape and sampling
+"""Seeded random sweep of the hot path against the oracle: 24 configurations (PPF_SOAK_MATCH=N adds N more draws: the
+soak runs of tools/soak.sh, results under profiles/) drawn over model shape and sampling
 step, alpha resolution, distance-step rule, scene size / sampling / reference stride, presampled or not, surface or
 surface-to-boundary matching, clustering thresholds, forced accumulator tiling, and for every third draw the vote kernel's
 32-bit-cell instantiation as well.  Every one must give bit-exact vote
 triples, vote and pair totals, bit-identical raw poses and the oracle's clustered poses (the bar of
 tests/test_gpu_parity.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,7 +38,7 @@ def _draw(seed):
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + int(os.environ.get("PPF_SOAK_MATCH", "0"))))
 def test_random_configuration(bottle, seed):
     cfg = _draw(seed)
     model = bottle if cfg["kind"] == "bottle" else synth.make_solid(cfg["kind"], 6000, seed=seed + 1)
@@ -81,5 +84,51 @@ def test_random_configuration(bottle, seed):
     poses = det.match(scene, cfg["ref_step"], cfg["scene_dist"], presampled=cfg["presampled"], edge=edge)
     assert len(poses) == want["n_final"], cfg
     for g, w in zip(poses, want["poses"]):
+        assert g.numVotes == w["num_votes"], cfg
+        np.testing.assert_allclose(g.pose, w["pose"], rtol=0, atol=1e-9, err_msg=str(cfg))
+
+
+def _draw_policy(seed):
+    rng = np.random.default_rng(5000 + seed)
+    return dict(kind=KINDS[int(rng.integers(0, 4))],
+                train_step=float(rng.choice([0.05, 0.0625, 0.08])), num_angles=int(rng.choice([15, 30, 31, 40])),
+                n_scene=int(rng.integers(800, 5000)), scene_seed=int(rng.integers(0, 10 ** 6)),
+                ref_step=float(rng.choice([1.0 / 5.0, 1.0 / 10.0, 1.0 / 25.0])),
+                key_exact=bool(rng.integers(0, 2)), darboux=bool(rng.integers(0, 2)), radius=float(rng.choice([0.0, 0.3, 0.5, 0.9])),
+                rot_relative=bool(rng.integers(0, 2)), alpha_2pi=bool(rng.integers(0, 2)),
+                pos_thr=float(rng.choice([-1.0, 0.03])), rot_thr=float(rng.choice([-1.0, 0.35])),
+                max_tile_refs=int(rng.choice([0, 0, 90, 300])), acc32=int(rng.choice([0, 0, 1])))
+
+
+@pytest.mark.parametrize("seed", range(12 + int(os.environ.get("PPF_SOAK_POLICY", "0"))))
+def test_random_policy_configuration(bottle, seed):
+    """the same bar under drawn combinations of the PCL-semantics switches (exact keys, Darboux feature, pair radius, relative
+    rotation metric, 2 pi alpha range: tests/test_gpu_policy.py has each alone), with forced tiling and 32-bit cells mixed in"""
+    import torch
+    from yolo_ppf_pose_estimation_amd import _capi
+    from yolo_ppf_pose_estimation_amd.device import Workspace
+    cfg = _draw_policy(seed)
+    model = bottle if cfg["kind"] == "bottle" else synth.make_solid(cfg["kind"], 6000, seed=seed + 11)
+    det = PPF3DDetector(cfg["train_step"], 0.05, cfg["num_angles"], max_tile_refs=cfg["max_tile_refs"],
+                        key_equality=int(cfg["key_exact"]), feature=int(cfg["darboux"])).trainModel(model)
+    radius = cfg["radius"] * det.info()["diameter"]
+    det.setPolicy(pair_radius=radius, rot_metric_relative=cfg["rot_relative"], alpha_range_2pi=cfg["alpha_2pi"])
+    det.setSearchParams(cfg["pos_thr"], cfg["rot_thr"])
+    ora = O.OracleDetector(cfg["train_step"], 0.05, cfg["num_angles"]).train_model(model, darboux=cfg["darboux"])
+    ora.set_policy(key_exact=cfg["key_exact"], pair_radius=radius, rot_relative=cfg["rot_relative"], alpha_2pi=cfg["alpha_2pi"])
+    ora.set_search_params(cfg["pos_thr"], cfg["rot_thr"])
+    scene, _ = synth.make_scene(model, n_points=cfg["n_scene"], seed=cfg["scene_seed"])
+    want = ora.match(scene, relative_scene_sample_step=cfg["ref_step"], presampled=True)
+    ws = Workspace()
+    ws.set_option(_capi.PPF_OPT_ACC32, cfg["acc32"])
+    d = torch.from_numpy(np.ascontiguousarray(scene, dtype=np.float32)).cuda()
+    ws.match_device(det, d.data_ptr(), scene.shape[0], 6, cfg["ref_step"], 0.05, presampled=True, skip_clustering=True)
+    res = ws.results(scene.shape[0])
+    np.testing.assert_array_equal(res["triples"], want["triples"], err_msg=str(cfg))
+    assert res["stats"]["n_votes"] == int(want["votes_per_ref"].sum()), cfg
+    assert res["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum()), cfg
+    poses = det.match(scene, cfg["ref_step"], 0.05, presampled=True)
+    assert len(poses) == want["n_final"], cfg
+    for g, w in zip(poses[:10], want["poses"][:10]):
         assert g.numVotes == w["num_votes"], cfg
         np.testing.assert_allclose(g.pose, w["pose"], rtol=0, atol=1e-9, err_msg=str(cfg))

@@ -120,6 +120,19 @@ PPF_HD bool key_index(const KeyDims& d, const int32_t k0, const int32_t k1, cons
   return true;
 }
 PPF_HD size_t key_table_size(const KeyDims& d) { return (size_t)d.n0 * d.n1 * d.n2 * d.nd; }
+/* PPF_KEY_EXACT with the reference's feature: an acos of a dot product a rounding above 1 (parallel normals on a flat face) is
+ * NaN and its bin INT_MIN (ppf_d2i).  The reference's table hashes such a key like any other, and so does the hash path
+ * here; under exact keys they are keys like any other too -- a model pair and a scene pair with NaN in the same places and
+ * equal bins elsewhere match -- and take the last bin of their dimension, which no angle reaches (bins run to
+ * floor(pi / angle_step), the dimension one further).  Off the fast path: only keys key_index() turned down come here. */
+PPF_HD bool key_index_nan(const KeyDims& d, int32_t k0, int32_t k1, int32_t k2, const int32_t k3, size_t* idx) {
+  if ((d.o0 | d.o1 | d.o2) != 0) return false; /* the Darboux feature has no NaN keys (degenerate pairs are left out) */
+  const int32_t nan_bin = (int32_t)0x80000000;
+  if (k0 == nan_bin) k0 = d.n0 - 1;
+  if (k1 == nan_bin) k1 = d.n1 - 1;
+  if (k2 == nan_bin) k2 = d.n2 - 1;
+  return key_index(d, k0, k1, k2, k3, idx);
+}
 
 /* A pair record names a model row by a code: bits 0..17 the byte offset of the row's bin 0 in the LDS accumulator (a multiple
  * of 4) with the half of the word its 16-bit cells live in as bit 0; bits 18..22 and 23..29 the entry's X and cell q of the

@@ -334,7 +334,7 @@ struct MatchArgs {
   uint32_t* perm;               /* [n_ref] reference points ordered by work, heaviest first (k_rank) */
   const uint32_t* perm_group;   /* [n_ref] reference points ordered by hit count, for k_group */
   int agg_min_hits;             /* 0: every run votes directly */
-  int key_exact;                /* PPF_KEY_EXACT table: keys outside the key table match nothing */
+  int key_exact;                /* PPF_KEY_EXACT table: keys outside the key table (but for NaN angle bins, key_index_nan) match nothing */
   double pair_radius;           /* > 0: pairs farther apart than this are skipped (not counted) */
   int acc32;                    /* k_vote<.., true> (32-bit cells, one workgroup per half of a tile's rows): 1 = every (reference point, tile),
                                    2 = only those the 16-bit launch flagged in ovf_items */
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
           size_t ki;
           if (key_index(a.kd, key[0], key[1], key[2], key[3], &ki)) {
             b = a.key_lut[ki];
-          } else if (a.key_exact) { /* no model pair has a key outside the table */
-            b = -1;
+          } else if (a.key_exact) { /* NaN angles have bins of their own (key_index_nan); no model pair has any other key outside the table */
+            b = key_index_nan(a.kd, key[0], key[1], key[2], key[3], &ki) ? a.key_lut[ki] : -1;
           } else { /* NaN features (INT_MIN bins) or pairs farther apart than the table covers */
             b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
           }

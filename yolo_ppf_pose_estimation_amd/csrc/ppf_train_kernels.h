@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void k_train_pairs(CloudSoA m, double angle_st
     uint32_t slot;
     if (key_exact) { /* PPF_KEY_EXACT: the "slot" is the quantised key itself (its index in the key table) */
       size_t ki;
-      if (!key_index(kd, k0, k1, k2, k3, &ki)) { pair_slot[idx] = 0xFFFFFFFFu; pair_alpha[idx] = 0.f; continue; } /* cannot happen: ppf_model_train checks the range */
+      if (!key_index(kd, k0, k1, k2, k3, &ki) && !key_index_nan(kd, k0, k1, k2, k3, &ki)) { /* cannot happen: ppf_model_train checks the range */
+        pair_slot[idx] = 0xFFFFFFFFu; pair_alpha[idx] = 0.f; continue;
+      }
       slot = (uint32_t)ki;
     } else {
       slot = ppf_murmur_key16(k0, k1, k2, k3) & slot_mask; /* hash % slots, slots a power of two */
