@@ -132,3 +132,69 @@ def test_random_policy_configuration(bottle, seed):
     for g, w in zip(poses[:10], want["poses"][:10]):
         assert g.numVotes == w["num_votes"], cfg
         np.testing.assert_allclose(g.pose, w["pose"], rtol=0, atol=1e-9, err_msg=str(cfg))
+
+
+def _draw_degenerate(seed):
+    rng = np.random.default_rng(3000 + seed)
+    return dict(kind=["bottle", "box", "cylinder", "plane"][int(rng.integers(0, 4))],
+                model_rows=int(rng.choice([12, 60, 300, 1500])), num_angles=int(rng.choice([5, 7, 16, 30, 31, 32, 33, 64])),
+                dist_step=float(rng.choice([0.02, 0.05, 0.3])), n_scene=int(rng.choice([1, 2, 7, 64, 65, 700, 2500])),
+                scene_seed=int(rng.integers(0, 10 ** 6)), ref_step=float(rng.choice([1.0, 1.0 / 3.0, 1.0 / 10.0])),
+                duplicates=bool(rng.integers(0, 2)), zero_normals=bool(rng.integers(0, 3) == 0), long_normals=bool(rng.integers(0, 3) == 0),
+                non_finite=bool(rng.integers(0, 3) == 0), s2b=bool(rng.integers(0, 3) == 0), key_exact=bool(rng.integers(0, 4) == 0),
+                max_tile_refs=int(rng.choice([0, 0, 5, 64])))
+
+
+def _bounded(cfg):
+    """a flat model sends every pair into a handful of buckets: the oracle then casts model rows^2 votes per scene pair"""
+    if cfg["kind"] in ("plane", "box") and cfg["model_rows"] > 300:
+        cfg["n_scene"] = min(cfg["n_scene"], 700)
+    if cfg["kind"] == "plane" and cfg["model_rows"] > 300:
+        cfg["model_rows"] = 300
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(10 + int(os.environ.get("PPF_SOAK_DEGENERATE", "0"))))
+def test_random_degenerate_inputs(bottle, seed):
+    """inputs a real crop can hold and a test cloud rarely does, drawn together: models of a dozen rows, flat models (every
+    pair of a face has parallel normals: acos arguments a rounding above 1, NaN angle bins), scenes of one or two rows, rows
+    that exist twice, zero and over-long normals, a few non-finite coordinates or normals (such a pair's alpha is NaN and the
+    reference's loop skips it), odd alpha resolutions around the count tables' limit (31 / 32), coarse and fine distance
+    steps: vote triples, vote and pair totals and the raw poses equal the oracle's."""
+    cfg = _bounded(_draw_degenerate(seed))
+    rng = np.random.default_rng(seed)
+    if cfg["kind"] == "plane":
+        uv = rng.uniform(-0.1, 0.1, size=(4000, 2))
+        full = np.zeros((4000, 6), np.float32)
+        full[:, :2] = uv
+        full[:, 2] = 0.5
+        full[:, 5] = 1.0
+    else:
+        full = bottle if cfg["kind"] == "bottle" else synth.make_solid(cfg["kind"], 6000, seed=seed + 5)
+    model = full[rng.permutation(full.shape[0])[:cfg["model_rows"]]].copy()
+    det = PPF3DDetector(0.05, cfg["dist_step"], cfg["num_angles"], max_tile_refs=cfg["max_tile_refs"], key_equality=int(cfg["key_exact"]))
+    det.trainModel(model, presampled=True)
+    ora = O.OracleDetector(0.05, cfg["dist_step"], cfg["num_angles"]).train_model(model, presampled=True).set_policy(key_exact=cfg["key_exact"])
+    T = synth.rigid_pose(cfg["scene_seed"] % 997, 0.2)
+    scene = synth.apply_pose(full[rng.permutation(full.shape[0])[:cfg["n_scene"]]], T).astype(np.float32)
+    n = scene.shape[0]
+    if cfg["duplicates"] and n > 1:
+        scene[rng.integers(0, n, max(1, n // 10))] = scene[rng.integers(0, n, max(1, n // 10))]
+    if cfg["zero_normals"]:
+        scene[rng.integers(0, n, max(1, n // 20)), 3:] = 0.0
+    if cfg["long_normals"]:
+        scene[rng.integers(0, n, max(1, n // 20)), 3:] *= 3.0
+    if cfg["non_finite"]:
+        for r in rng.integers(0, n, max(1, n // 50)):
+            scene[r, int(rng.integers(0, 6))] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
+    edge = scene[rng.random(n) < 0.5] if cfg["s2b"] else None
+    if edge is not None and edge.shape[0] == 0:
+        edge = scene[:1]
+    got = det.raw_votes(scene, cfg["ref_step"], 0.05, presampled=True, edge=edge)
+    want = ora.match(scene, edge=edge, relative_scene_sample_step=cfg["ref_step"], presampled=True, cluster=False)
+    assert got["n_ref"] == want["n_ref"], cfg
+    np.testing.assert_array_equal(got["triples"], want["triples"], err_msg=str(cfg))
+    assert got["stats"]["n_votes"] == int(want["votes_per_ref"].sum()), cfg
+    assert got["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum()), cfg
+    for g, w in zip(got["raw_poses"], want["raw_poses"]):
+        assert np.array_equal(g.pose, w["pose"], equal_nan=True), cfg

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void k_frames(MatchArgs a) {
    * k_group's counting pass need not look at the points at all. */
   bool odd = false;
   for (int j = r; j < a.paired.n; j += gridDim.x * blockDim.x) {
-    const float m = fmaxf(fmaxf(fabsf(a.paired.x[j]), fabsf(a.paired.y[j])), fabsf(a.paired.z[j]));
+    const float m = (fabsf(a.paired.x[j]) + fabsf(a.paired.y[j])) + fabsf(a.paired.z[j]); /* a sum, not fmaxf: that one drops a NaN operand */
     odd |= !(m < 1e30f); /* NaN, infinite or beyond anything a transformed coordinate could keep finite */
   }
   if (r < a.n_ref) {
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   fk.rdstep = 1.0 / a.dist_step;
   unsigned long long my_pairs = 0;
   uint32_t hit_mask = 0;
+  const bool odd_values = !a.count_only && a.cursors[CUR_ODDVALUES] != 0u; /* set by k_frames, which ran before this launch (the counting pass of a cold workspace has no frames yet, and keeps its totals in the cursors) */
   const int j0 = blockIdx.x * (PAIR_BLOCK * PAIRS_PER_THREAD) + tid;
   const int n = a.paired.n;
   /* the point of the next iteration is fetched while the current pair is hashed */
@@ -448,9 +449,16 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
           } else { /* NaN features (INT_MIN bins) or pairs farther apart than the table covers */
             b = slot_to_bucket(a.slotmap, ppf_murmur_key16(key[0], key[1], key[2], key[3]) & a.slot_mask);
           }
-          /* The reference skips a pair whose alpha_s is NaN; for finite clouds it never is.  alpha_s itself is
-           * computed later (k_group), only for the pairs that found a bucket. */
-          my_pairs += 1u;
+          /* The reference skips a pair whose alpha_s is NaN BEFORE it counts it; for finite clouds it never is.  alpha_s
+           * itself is computed later (k_group), only for the pairs that found a bucket (and a hit without one is retired there). */
+          if (__builtin_expect(odd_values, 0)) { /* k_frames saw a frame or a point that is no ordinary number: count as the reference does */
+            const double* f = a.frames + (size_t)r * 12;
+            const double qy = f[10] + (f[3] * p2.x + f[4] * p2.y + f[5] * p2.z);
+            const double qz = f[11] + (f[6] * p2.x + f[7] * p2.y + f[8] * p2.z);
+            my_pairs += ppf_alpha_exists(qy, qz) ? 1u : 0u;
+          } else {
+            my_pairs += 1u;
+          }
           if (b >= 0) {
             stash[it][tid] = make_uint2((uint32_t)b, (uint32_t)j);
             hit_mask |= 1u << it;
