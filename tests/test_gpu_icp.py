@@ -213,7 +213,8 @@ def _icp_draw(seed):
                 max_deg=float(rng.choice([1.0, 4.0, 12.0, 40.0])), max_shift=float(rng.choice([0.001, 0.005, 0.03])),
                 iterations=int(rng.choice([3, 20, 100])), tolerance=float(rng.choice([0.0, 0.005, 0.05])),
                 rejection_scale=float(rng.choice([0.0, 1.0, 2.5, 4.0])), num_levels=int(rng.choice([1, 2, 3, 5, 8])),
-                grid_always=bool(rng.integers(0, 2)))
+                grid_always=bool(rng.integers(0, 2)), non_finite=["", "", "scene", "model", "both"][int(rng.integers(0, 5))],
+                duplicates=bool(rng.integers(0, 3) == 0))
 
 
 @pytest.mark.parametrize("seed", range(6 + int(os.environ.get("PPF_SOAK_ICP", "0"))))
@@ -233,6 +234,13 @@ def test_icp_random_draw(bottle, seed):
         T = synth.rigid_pose(cfg["scene_seed"] % 1000, 0.2)
         pick = rng.permutation(full.shape[0])[:cfg["n_scene"]]
         scene = synth.apply_pose(full[np.sort(pick)], T)
+    if cfg["duplicates"]:   # rows that exist twice: equal distances go to the smaller index, equal ownership keys to the smaller model row
+        scene = np.vstack([scene, scene[rng.integers(0, scene.shape[0], scene.shape[0] // 4)]]).astype(np.float32)
+        model = np.vstack([model, model[rng.integers(0, model.shape[0], model.shape[0] // 8)]]).astype(np.float32)
+    for which, cloud in (("scene", scene), ("model", model)):
+        if cfg["non_finite"] in (which, "both"):   # a NaN distance is never the smallest, a NaN query keeps the sequential loop's start value
+            for r in rng.integers(0, cloud.shape[0], 1 + cloud.shape[0] // 200):
+                cloud[r, int(rng.integers(0, 6))] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
     mats = [_perturb(T, float(rng.uniform(-1, 1)) * cfg["max_deg"], rng.uniform(-1, 1, 3) * cfg["max_shift"], axis=int(rng.integers(0, 3)))
             for _ in range(cfg["n_poses"])]
     kw = dict(iterations=cfg["iterations"], tolerance=cfg["tolerance"], rejection_scale=cfg["rejection_scale"], num_levels=cfg["num_levels"])

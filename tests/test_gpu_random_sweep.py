@@ -198,3 +198,35 @@ def test_random_degenerate_inputs(bottle, seed):
     assert got["stats"]["n_pairs"] == int(want["pairs_per_ref"].sum()), cfg
     for g, w in zip(got["raw_poses"], want["raw_poses"]):
         assert np.array_equal(g.pose, w["pose"], equal_nan=True), cfg
+
+
+@pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PPF_SOAK_BATCH", "0"))))
+def test_random_batches_equal_single_matches(bottle, seed):
+    """ppf_match_batch on drawn batches (1 - 4 models of different shapes, sampling steps and alpha resolutions; 1 - 7 crops of
+    ragged sizes, a crop of a handful of rows among them; presampled or not; lanes that do not divide the crops): every
+    (crop, model) cell equals the single match of the same detector on the same crop -- which the sweeps above tie to the oracle"""
+    from yolo_ppf_pose_estimation_amd.detector import match_batch
+    rng = np.random.default_rng(11000 + seed)
+    nm, nc = int(rng.integers(1, 5)), int(rng.integers(1, 8))
+    dets, fulls = [], []
+    pos_thr, rot_thr = float(rng.choice([-1.0, 0.03])), float(rng.choice([-1.0, 0.35]))   # one ppf_match_params per batch
+    for k in range(nm):
+        kind = KINDS[int(rng.integers(0, 4))]
+        full = bottle if kind == "bottle" else synth.make_solid(kind, 6000, seed=seed * 7 + k)
+        det = PPF3DDetector(float(rng.choice([0.05, 0.08, 0.1])), 0.05, int(rng.choice([15, 30, 40])))
+        det.setSearchParams(pos_thr, rot_thr)
+        dets.append(det.trainModel(full))
+        fulls.append(full)
+    crops = []
+    for c in range(nc):
+        n = int(rng.choice([3, 40, 700, 1500, 4000]))
+        crops.append(synth.make_scene(fulls[int(rng.integers(0, nm))], n_points=max(n, 300), seed=int(rng.integers(0, 10 ** 6)))[0][:n])
+    presampled, step, top_k = bool(rng.integers(0, 2)), float(rng.choice([1.0 / 3.0, 1.0 / 10.0])), int(rng.integers(1, 7))
+    got = match_batch(dets, crops, step, 0.05, presampled=presampled, top_k=top_k)
+    for c, crop in enumerate(crops):
+        for k, det in enumerate(dets):
+            want = det.match(crop, step, 0.05, presampled=presampled)[:top_k]
+            assert len(got[c][k]) == len(want), (seed, c, k)
+            for g, w in zip(got[c][k], want):
+                assert g.numVotes == w.numVotes and g.modelIndex == w.modelIndex
+                np.testing.assert_array_equal(g.pose, w.pose)
