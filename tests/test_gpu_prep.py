@@ -194,6 +194,14 @@ def test_stages_random_draw(frame, seed):
     sphere cloud with noise, duplicated rows and a few non-finite ones): voxel grid, neighbour lists, outlier removal, normals
     and edges equal the oracle bit for bit (PPF_SOAK_PREP=N adds N draws, tools/soak.sh)"""
     rng = np.random.default_rng(9000 + seed)
+    fxyz, depth, box, intr = frame
+    crng = np.random.default_rng(seed)   # SceneCropping with a drawn box around / beside the object (boxes touching the frame's border included)
+    bx, by = int(box[0] + crng.integers(-150, 150)), int(box[1] + crng.integers(-150, 150))
+    bw, bh = int(crng.integers(2, 400)), int(crng.integers(2, 400))
+    bx, by = max(0, min(bx, depth.shape[1] - 2)), max(0, min(by, depth.shape[0] - 2))
+    bw, bh = min(bw, depth.shape[1] - 1 - bx), min(bh, depth.shape[0] - 1 - by)
+    keep_c, _ = O.prep_crop(fxyz, (bx, by, bw, bh), depth, intr)
+    np.testing.assert_array_equal(DeviceCloud.upload(fxyz).crop((bx, by, bw, bh), depth, intr).xyz(), fxyz[keep_c])
     if rng.integers(0, 2):
         xyz = frame[0]
         lo = int(rng.integers(0, xyz.shape[0] - 30000))
