@@ -252,3 +252,12 @@ def test_icp_random_draw(bottle, seed):
     for g, P, r in zip(got, want_P, want_r):
         np.testing.assert_array_equal(g.pose, P, err_msg=str(cfg))
         assert g.residual == r, cfg
+
+
+def test_icp_more_model_rows_than_the_tail_stages(bottle):
+    """a level of more than 32,768 model rows: its distances do not fit the tail's LDS staging, the rejection threshold is
+    selected from global memory by the whole workgroup (the other tests take the one-wave selection): the oracle's result"""
+    dense = synth.make_solid("torus", 36000, seed=4)
+    T = synth.rigid_pose(13, 0.1)
+    scene = synth.apply_pose(dense[::9], T)
+    _check(dense, scene, [_perturb(T, 2.0, [0.002, -0.001, 0.001])], iterations=12, num_levels=2)

@@ -413,8 +413,8 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
     if (residuals) residuals[j] = h.fval_min;
     if (iters_total) iters_total[j] = h.total;
 #ifdef PPF_ICP_CLOCKS
-    fprintf(stderr, "icp job %d: threshold %.1f  ownership %.1f  compaction %.1f  chunks %.1f  sums %.1f  solve %.1f us (iterations %d)\n", j, h.ph[0] * 0.01,
-            h.ph[1] * 0.01, h.ph[2] * 0.01, h.ph[3] * 0.01, h.ph[4] * 0.01, h.ph[5] * 0.01, h.total);
+    fprintf(stderr, "icp job %d: start + staging %.1f  median %.1f  MAD %.1f  ownership %.1f  compaction %.1f  chunks %.1f  sums %.1f  solve %.1f us (iterations %d)\n", j,
+            h.ph[6] * 0.01, h.ph[7] * 0.01, h.ph[0] * 0.01, h.ph[1] * 0.01, h.ph[2] * 0.01, h.ph[3] * 0.01, h.ph[4] * 0.01, h.ph[5] * 0.01, h.total);
 #endif
   }
   return PPF_OK;

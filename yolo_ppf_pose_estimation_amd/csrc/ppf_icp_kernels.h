@@ -694,11 +694,15 @@ struct IcpState2 {
 #endif
 };
 #ifdef PPF_ICP_CLOCKS
-#define ICP_PH_DECL unsigned long long ph_t_ = __builtin_amdgcn_s_memrealtime()
-#define ICP_PH(st, k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); (st)->ph[k] += t_ - ph_t_; ph_t_ = t_; } } while (0)
+/* phase clocks of the tail (100 MHz): kept in registers and added to the state once, at the end -- a read-modify-write of the
+ * state per mark put a memory round trip of thread 0 (and a late arrival at the next barrier) into every phase */
+#define ICP_PH_DECL unsigned long long ph_t_ = __builtin_amdgcn_s_memrealtime(), ph_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define ICP_PH(st, k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph_a_[k] += t_ - ph_t_; ph_t_ = t_; } } while (0)
+#define ICP_PH_FLUSH(st) do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) (st)->ph[k_] += ph_a_[k_]; } } while (0)
 #else
 #define ICP_PH_DECL do { } while (0)
 #define ICP_PH(st, k) do { } while (0)
+#define ICP_PH_FLUSH(st) do { } while (0)
 #endif
 
 /* floats as unsigned integers of the same order (atomicMin / atomicMax on floats of either sign) */
@@ -1307,11 +1311,34 @@ __global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int
   }
 }
 
+/* the candidate with `sub` smaller ones before it among list[0 .. cand), cand <= 256: thread t < cand takes candidate t and counts
+ * the others below / not above it, eight candidates per step from two 16-byte reads (one 4-byte read per step waits an LDS round
+ * trip per candidate: 256 of them were 6 us).  The list is 16-byte aligned and padded with 0xFFFFFFFF to a multiple of eight
+ * (a pad never counts as smaller, and only for the largest value as not larger, where the count is at its maximum anyway). */
+__device__ __forceinline__ void icp_rank_candidates(const uint32_t* list, const uint32_t cand, const uint32_t sub, uint32_t* out) {
+  if (threadIdx.x < cand) {
+    const uint32_t v = list[threadIdx.x];
+    uint32_t less = 0, leq = 0;
+    for (uint32_t j = 0; j < cand; j += 8u) {
+      const uint4 a = *reinterpret_cast<const uint4*>(&list[j]), b = *reinterpret_cast<const uint4*>(&list[j + 4u]);
+      less += ((a.x < v ? 1u : 0u) + (a.y < v ? 1u : 0u)) + ((a.z < v ? 1u : 0u) + (a.w < v ? 1u : 0u));
+      less += ((b.x < v ? 1u : 0u) + (b.y < v ? 1u : 0u)) + ((b.z < v ? 1u : 0u) + (b.w < v ? 1u : 0u));
+      leq += ((a.x <= v ? 1u : 0u) + (a.y <= v ? 1u : 0u)) + ((a.z <= v ? 1u : 0u) + (a.w <= v ? 1u : 0u));
+      leq += ((b.x <= v ? 1u : 0u) + (b.y <= v ? 1u : 0u)) + ((b.z <= v ? 1u : 0u) + (b.w <= v ? 1u : 0u));
+    }
+    if (less <= sub && sub < leq) *out = v;
+  }
+}
+/* pads list[cand ..] up to the next multiple of eight (the list holds 264 words) */
+__device__ __forceinline__ void icp_pad_candidates(uint32_t* list, const uint32_t cand) {
+  if (threadIdx.x < 8u && ((cand + threadIdx.x) >> 3) == (cand >> 3) && (cand & 7u)) list[cand + threadIdx.x] = 0xFFFFFFFFu;
+}
+
 /* icp_block_select with the histogram updates of a wave combined for its most frequent digit: the distances of one level
  * share their leading byte (and, for a model thrown off the data, all their bits), and 64 lanes adding to one LDS counter
  * are 64 serial updates */
 template <class F>
-__device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* hist, uint32_t* sh /* 4 words */) {
+__device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* hist /* 264 words, 16-byte aligned */, uint32_t* sh /* 4 words */) {
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t prefix = 0;
   uint32_t cand = (uint32_t)n; /* values that still share the prefix */
@@ -1326,13 +1353,9 @@ __device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* his
         const uint32_t v = val(i);
         if ((v & mask) == prefix) hist[atomicAdd(&sh[3], 1u)] = v;
       }
+      icp_pad_candidates(hist, cand); /* cand is exact: the pads do not meet the entries */
       __syncthreads();
-      if ((uint32_t)tid < cand) {
-        const uint32_t v = hist[tid];
-        uint32_t less = 0, leq = 0;
-        for (uint32_t j = 0; j < cand; j++) { const uint32_t w = hist[j]; less += w < v; leq += w <= v; }
-        if (less <= rank && rank < leq) sh[0] = v;
-      }
+      icp_rank_candidates(hist, cand, rank, &sh[0]);
       __syncthreads();
       const uint32_t r = sh[0];
       __syncthreads();
@@ -1383,12 +1406,137 @@ __device__ uint32_t icp_block_select2(F val, int n, uint32_t rank, uint32_t* his
   return prefix;
 }
 
+/* The selection the tail uses on values that sit in LDS: ONE histogram pass over a window around the wanted rank instead of a
+ * pass per byte.  A digit pass of icp_block_select2 costs the sixteen waves four barriers whatever it counts, a level's two
+ * selections need three or four passes each, and on the levels of a few thousand rows that was over half of the tail's time.
+ * Here every wave ranks the same 64 samples (every n/64-th value) for itself and takes the samples twelve sample ranks below
+ * and above the wanted one as a window [lo, hi]: three standard deviations of where the wanted value can sit among them, so it
+ * is inside but for one selection in a few hundred, and the window holds about 3/8 of the values whatever their distribution
+ * (outliers that stretch the range do not thin the bins out).  One pass counts the values below the window and spreads those
+ * inside over 256 counters, (v - lo) >> shift; the counter that holds the rank keeps a few dozen candidates, which are ranked
+ * directly.  Every wave scans the counters for itself; three barriers in all.  The wanted value outside the window or more
+ * than 256 candidates (many equal values): the byte passes take over.  u32 order, like the byte passes.  Needs
+ * hist[0..255] == 0 and sh[1] == sh[3] == 0 on entry (set before the caller's last barrier) and leaves them so. */
+template <class F>
+__device__ uint32_t icp_block_select3(F val, const int n, const uint32_t rank, uint32_t* hist /* 264 words */, uint32_t* list /* 264 words, 16-byte aligned */, uint32_t* sh /* 8 words */) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (n <= 256) { /* a coarse level: every value is a candidate */
+    if (tid < n) list[tid] = val(tid);
+    icp_pad_candidates(list, (uint32_t)n);
+    __syncthreads();
+    icp_rank_candidates(list, (uint32_t)n, rank, &sh[0]);
+    __syncthreads();
+    return sh[0]; /* the next write of sh[0] comes after the caller's or the next selection's barrier */
+  }
+  uint32_t lo = 0u, hi = 0xFFFFFFFFu;
+  {
+    /* the window: wave w ranks samples 4 w .. 4 w + 3 among the 64 (two ballots each) and files the two that sit at the window's
+     * sample ranks; equal samples file the same value */
+    const uint32_t mine = val((int)(((long long)lane * n) >> 6));
+    const int rs = (int)(((unsigned long long)rank * 64ull) / (unsigned long long)n);
+    const int w4 = (tid >> 6) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mine, w4 + u);
+      const int less = __popcll(__ballot(mine < pj)), leq = __popcll(__ballot(mine <= pj));
+      if (lane == 0) {
+        if (less <= rs - 12 && rs - 12 < leq) sh[4] = pj;
+        if (less <= rs + 12 && rs + 12 < leq) sh[5] = pj;
+      }
+    }
+    __syncthreads();
+    if (rs - 12 >= 0) lo = sh[4];
+    if (rs + 12 <= 63) hi = sh[5];
+  }
+  const uint32_t range = hi - lo;
+  const int shift = range > 255u ? 24 - __builtin_clz(range) : 0; /* (range >> shift) <= 255 */
+  {
+    uint32_t n_below = 0, n_equal = 0; /* n_equal: a window of one value (a model thrown off the data) is counted, not binned */
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      if (i < n) {
+        const uint32_t v = val(i);
+        n_below += v < lo ? 1u : 0u;
+        if (range == 0u) n_equal += v == lo ? 1u : 0u;
+        else if (v >= lo && v <= hi) atomicAdd(&hist[(v - lo) >> shift], 1u);
+      }
+    }
+    /* the wave's counts, one atomic each per wave */
+#define ICP_DPP_ADD(x, ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, false)
+#define ICP_WAVE_ADD(x) ICP_DPP_ADD(x, 0x111, 0xf); ICP_DPP_ADD(x, 0x112, 0xf); ICP_DPP_ADD(x, 0x114, 0xf); ICP_DPP_ADD(x, 0x118, 0xf); ICP_DPP_ADD(x, 0x142, 0xa); ICP_DPP_ADD(x, 0x143, 0xc)
+    ICP_WAVE_ADD(n_below);
+    ICP_WAVE_ADD(n_equal);
+#undef ICP_WAVE_ADD
+#undef ICP_DPP_ADD
+    if (lane == 63 && n_below) atomicAdd(&sh[1], n_below);
+    if (lane == 63 && n_equal) atomicAdd(&hist[0], n_equal);
+  }
+  __syncthreads();
+  uint32_t bin, sub, cand;
+  bool inside;
+  {
+    const uint32_t n_below = sh[1];
+    const uint4 c = *reinterpret_cast<const uint4*>(&hist[lane * 4]);
+    const uint32_t sum = (c.x + c.y) + (c.z + c.w);
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += up;
+    }
+    const uint32_t in_window = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    inside = rank >= n_below && rank - n_below < in_window;
+    const uint32_t r = rank - n_below;
+    uint32_t excl = incl - sum;
+    const bool has = inside && r >= excl && r < incl; /* one lane */
+    uint32_t b = 0, cb = c.x;
+    if (!(r < excl + c.x)) { excl += c.x; b = 1u; cb = c.y;
+      if (!(r < excl + c.y)) { excl += c.y; b = 2u; cb = c.z;
+        if (!(r < excl + c.z)) { excl += c.z; b = 3u; cb = c.w; } } }
+    const unsigned long long hm = __ballot(has);
+    const int src = hm ? __builtin_ctzll(hm) : 0;
+    bin = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 4u + b), src);
+    sub = (uint32_t)__builtin_amdgcn_readlane((int)(r - excl), src);
+    cand = (uint32_t)__builtin_amdgcn_readlane((int)cb, src);
+  }
+  if (inside && range == 0u) { /* every value of the window is `lo` */
+    __syncthreads(); /* every wave has read the counters */
+    if (tid < 256) hist[tid] = 0u;
+    if (tid == 256) sh[1] = 0u;
+    return lo; /* the caller's next barrier comes before the next use */
+  }
+  if (!inside || cand > 256u) { /* the same in every wave */
+    __syncthreads(); /* every wave has read the counters */
+    const uint32_t r = icp_block_select2(val, n, rank, hist, sh);
+    if (tid < 256) hist[tid] = 0u;
+    if (tid == 256) sh[1] = 0u;
+    if (tid == 257) sh[3] = 0u;
+    return r; /* the caller's next barrier comes before the next use */
+  }
+  for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    if (i < n) {
+      const uint32_t v = val(i);
+      if (v >= lo && v <= hi && (v - lo) >> shift == bin) list[atomicAdd(&sh[3], 1u)] = v;
+    }
+  }
+  icp_pad_candidates(list, cand);
+  __syncthreads();
+  icp_rank_candidates(list, cand, sub, &sh[0]);
+  if (tid >= 256 && tid < 512) hist[tid - 256] = 0u;
+  if (tid == 512) sh[1] = 0u;
+  if (tid == 513) sh[3] = 0u;
+  __syncthreads();
+  return sh[0];
+}
+
 /* everything of an iteration after the neighbour search, one workgroup per job (see the header of this section).
  * Dynamic LDS: max(ns * 4 when staged, 16 waves x 64 x 9 doubles of chunk rows). */
 constexpr int ICP_TAIL_VAL_BYTES = 16 * ICP_CHUNK * 9 * 8;
 __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, int step, float rej_scale, int staged, int last_level) {
   extern __shared__ __align__(16) unsigned char t_dyn[];
-  __shared__ uint32_t hist[256], sh[4], wsum[16];
+  __shared__ __align__(16) uint32_t hist[264], s_list[264];
+  __shared__ uint32_t sh[8], wsum[16];
   __shared__ double s_tot[ICP_ENTRIES];
   __shared__ float s_thr;
   __shared__ int s_done, s_nsel;
@@ -1412,6 +1560,9 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
   /* 1. rejection threshold */
   if (robust) {
     if (staged) {
+      if (tid < 256) hist[tid] = 0u; /* icp_block_select3's entry state */
+      if (tid == 256) sh[1] = 0u;
+      if (tid == 257) sh[3] = 0u;
       for (int i0 = 0; i0 < ns; i0 += 16 * 1024) { /* sixteen loads in flight per thread */
         uint32_t v[16];
 #pragma unroll
@@ -1423,14 +1574,27 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
       __syncthreads();
     }
     const uint32_t rank = (uint32_t)((ns - 1) / 2);
-    auto dist_bits = [&](int i) { return staged ? s_bits[i] : (uint32_t)(best[i] >> 32); };
-    const uint32_t med_bits = icp_block_select2(dist_bits, ns, rank, hist, sh);
-    const float med = __uint_as_float(med_bits);
-    const uint32_t mad_bits = icp_block_select2(
-        [&](int i) { return __float_as_uint((float)ppf_fabs((double)__uint_as_float(dist_bits(i)) - (double)med)); }, ns, rank, hist, sh);
-    if (tid == 0) {
-      const float sc = 1.48257968f * __uint_as_float(mad_bits);
-      s_thr = rej_scale * sc + med;
+    if (staged) { /* one histogram pass over a window around the rank (icp_block_select3) */
+      ICP_PH(st, 6);
+      const uint32_t med_bits = icp_block_select3([&](int i) { return s_bits[i]; }, ns, rank, hist, s_list, sh);
+      ICP_PH(st, 7);
+      const float med = __uint_as_float(med_bits);
+      const uint32_t mad_bits = icp_block_select3(
+          [&](int i) { return __float_as_uint((float)ppf_fabs((double)__uint_as_float(s_bits[i]) - (double)med)); }, ns, rank, hist, s_list, sh);
+      if (tid == 0) {
+        const float sc = 1.48257968f * __uint_as_float(mad_bits);
+        s_thr = rej_scale * sc + med;
+      }
+    } else {
+      auto dist_bits = [&](int i) { return (uint32_t)(best[i] >> 32); };
+      const uint32_t med_bits = icp_block_select2(dist_bits, ns, rank, hist, sh);
+      const float med = __uint_as_float(med_bits);
+      const uint32_t mad_bits = icp_block_select2(
+          [&](int i) { return __float_as_uint((float)ppf_fabs((double)__uint_as_float(dist_bits(i)) - (double)med)); }, ns, rank, hist, sh);
+      if (tid == 0) {
+        const float sc = 1.48257968f * __uint_as_float(mad_bits);
+        s_thr = rej_scale * sc + med;
+      }
     }
     __syncthreads();
   }
@@ -1640,6 +1804,7 @@ __global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, 
     __hip_atomic_store(&B.h_done[job], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   ICP_PH(st, 5);
+  ICP_PH_FLUSH(st);
   icp_tick(B, done != 0); /* after everything this thread wrote for the host */
 }
 
