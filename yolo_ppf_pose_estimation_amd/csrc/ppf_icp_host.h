@@ -24,7 +24,7 @@ constexpr int ICP_BATCH = 2;     /* iterations enqueued between two reads of the
 #define PPF_ICP_NN_WAVES 65536   /* batched path: waves of the neighbour search beyond which a wave takes several rows */
 #endif
 #ifndef PPF_ICP_BATCH2
-#define PPF_ICP_BATCH2 2         /* batched path: iterations (two launches each) enqueued between two reads of the done flags */
+#define PPF_ICP_BATCH2 2         /* batched path: passes (two launches each) kept in the stream ahead of the device (1: 3.30 ms, 2: 3.16 - 3.20, 3: 3.25 ms of ICP on C1) */
 #endif
 
 inline long icp_round(double v) { return std::lrint(v); } /* cvRound */
@@ -278,8 +278,8 @@ struct IcpBatchScratch {
 };
 
 /* registerModelToScene for `jobs` initial poses at once (init_poses NULL: one registration from the identity): every
- * launch covers all jobs, an iteration is two launches (k_icp2_nn, k_icp2_tail), the host reads the jobs' done flags once
- * per PPF_ICP_BATCH2 iterations.  Everything runs on `st`. */
+ * launch covers all jobs, an iteration is two launches (k_icp2_nn, k_icp2_tail), the host keeps PPF_ICP_BATCH2 of them in
+ * the stream ahead of the device and reads the jobs' done flags whenever one reports.  Everything runs on `st`. */
 ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff, const float* d_dst, int nd_all, int dstride, int dnoff,
                               const ppf_icp_params& prm, const double* const* init_poses, int jobs, IcpBatchScratch& sc, hipStream_t st,
                               double* poses_out /* jobs x 16 */, double* residuals, int* iters_total) {
@@ -348,6 +348,24 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
   const int robust = prm.rejection_scale > 0 ? 1 : 0;
   unsigned long long tails_launched = 0;
   bool last_level_waited = false;
+  auto wait_ticks = [&](const unsigned long long want) -> ppf_status {
+    volatile unsigned long long* ticks = sc.h_ticks;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*ticks < want) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFFu) == 0) {
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > 0.05 && hipStreamQuery(st) != hipErrorNotReady) { /* the stream is idle (or broken): nothing more will come */
+          HIPCHK(hipStreamSynchronize(st));
+          if (*ticks < want) return fail(PPF_ERR_HIP, "ICP: %llu of %llu workgroups reported", (unsigned long long)*ticks, want);
+        }
+        if (waited > 30.0) return fail(PPF_ERR_HIP, "ICP: timed out waiting for the device");
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return PPF_OK;
+  };
   for (int level = prm.num_levels - 1; level >= 0; level--) {
     const double div = std::pow(2.0, (double)level);
     const int num_samples = (int)icp_round((double)n / div);
@@ -363,43 +381,34 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
     /* rows per wave of the neighbour search: one, unless that makes more waves than the chip holds several times over */
     const int nn_rows = (int)std::min<long long>(ICP_NN_ROWS, std::max<long long>(1, ((long long)ns * jobs) / PPF_ICP_NN_WAVES));
     const unsigned nn_blocks = (unsigned)((ns + 4 * nn_rows - 1) / (4 * nn_rows));
-    int launched = 0;
+    /* The passes of a level are launched ahead of the device: PPF_ICP_BATCH2 (neighbour search, tail) pairs are in the stream,
+     * and every time the oldest of them reports, the next one is launched -- the device never waits for the host between
+     * passes (with whole batches it idled ~11 us after every second pass).  Every k_icp2_tail workgroup, whatever it did,
+     * adds one to a counter in pinned memory as its last act (after its done flag and, at the end of a level, its state);
+     * polling that is a few microseconds quicker than going through the stream (which is only asked when the counter has
+     * not moved for a long while).  A pass launched after the level's last one finds every job done and returns at once. */
+    int launched = 0, reported = 0;
+    const unsigned long long level_base = tails_launched;
     while (true) {
-      const int batch = std::min((int)PPF_ICP_BATCH2, max_iter - launched);
-      for (int b = 0; b < batch; b++) {
+      while (launched < max_iter && launched - reported < (int)PPF_ICP_BATCH2) {
         k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift, nn_rows, (prm.flags & PPF_ICP_GRID_ALWAYS) ? 0 : ICP_BRUTE_ND);
         k_icp2_tail<<<dim3(uj), dim3(1024), tail_lds, st>>>(B, ns, nd, step, prm.rejection_scale, staged, level == 0 ? 1 : 0);
+        launched++;
+        tails_launched += (unsigned long long)jobs;
       }
-      launched += std::max(batch, 0);
       HIPCHK(hipGetLastError());
-      if (batch <= 0) break;
-      /* wait for the batch: every k_icp2_tail workgroup, whatever it did, adds one to a counter in pinned memory as its last
-       * act (after its done flag and, at the end of a level, its state); polling that is a few microseconds quicker per
-       * batch than going through the stream (which is only asked when the counter has not moved for a long while) */
-      tails_launched += (unsigned long long)batch * (unsigned long long)jobs;
-      {
-        volatile unsigned long long* ticks = sc.h_ticks;
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (*ticks < tails_launched) {
-          __builtin_ia32_pause();
-          if ((++spins & 0xFFFFu) == 0) {
-            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (waited > 0.05 && hipStreamQuery(st) != hipErrorNotReady) { /* the stream is idle (or broken): nothing more will come */
-              HIPCHK(hipStreamSynchronize(st));
-              if (*ticks < tails_launched) return fail(PPF_ERR_HIP, "ICP: %llu of %llu workgroups reported", (unsigned long long)*ticks, tails_launched);
-            }
-            if (waited > 30.0) return fail(PPF_ERR_HIP, "ICP: timed out waiting for the device");
-          }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-      }
+      if (reported >= launched) break; /* max_iter == 0, or every launched pass has reported */
+      if (ppf_status rc = wait_ticks(level_base + (unsigned long long)(reported + 1) * (unsigned long long)jobs)) return rc;
+      reported++;
       bool all = true;
       for (int j = 0; j < jobs; j++) all &= reinterpret_cast<volatile int*>(sc.h_done)[j] != 0;
-      if (all || launched >= max_iter) break;
+      if (all) break; /* the passes still in the stream return at once; the next level's launches queue up behind them */
     }
     last_level_waited = launched > 0;
   }
+  /* the passes launched ahead of the last level's end are still in the stream and will report too: the scratch (and its
+   * counter) goes back to the pool only when they have */
+  if (ppf_status rc = wait_ticks(tails_launched)) return rc;
   if (!last_level_waited) HIPCHK(hipStreamSynchronize(st)); /* nothing was polled after the last state went out */
   for (int j = 0; j < jobs; j++) {
     /* undo centring and scaling: t = t/scale + meanAvg - R*meanAvg */
