@@ -150,12 +150,15 @@ constexpr double HIT_SCRATCH_BYTES = 8.0 + 8.0 + 2.0 + 16.0 / 6.0;
 /* k_pairs<pair feature, surface-to-boundary>: same_cloud == 0 is match_S2B (the paired points come from the edge cloud) */
 static void launch_pairs(const MatchArgs& va, bool darboux, hipStream_t st) {
   const dim3 grid(va.pair_chunks, va.n_ref), block(PAIR_BLOCK);
+  const dim3 ogrid((unsigned)std::min(va.n_ref, 1024)), oblock(256); /* k_pairs_odd: returns at once unless k_frames raised its flag */
   if (darboux) {
     if (va.same_cloud) k_pairs<true, false><<<grid, block, 0, st>>>(va);
     else k_pairs<true, true><<<grid, block, 0, st>>>(va);
+    if (!va.count_only) { if (va.same_cloud) k_pairs_odd<true, false><<<ogrid, oblock, 0, st>>>(va); else k_pairs_odd<true, true><<<ogrid, oblock, 0, st>>>(va); }
   } else {
     if (va.same_cloud) k_pairs<false, false><<<grid, block, 0, st>>>(va);
     else k_pairs<false, true><<<grid, block, 0, st>>>(va);
+    if (!va.count_only) { if (va.same_cloud) k_pairs_odd<false, false><<<ogrid, oblock, 0, st>>>(va); else k_pairs_odd<false, true><<<ogrid, oblock, 0, st>>>(va); }
   }
 }
 

@@ -401,7 +401,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
   fk.rdstep = 1.0 / a.dist_step;
   unsigned long long my_pairs = 0;
   uint32_t hit_mask = 0;
-  const bool odd_values = !a.count_only && a.cursors[CUR_ODDVALUES] != 0u; /* set by k_frames, which ran before this launch (the counting pass of a cold workspace has no frames yet, and keeps its totals in the cursors) */
   const int j0 = blockIdx.x * (PAIR_BLOCK * PAIRS_PER_THREAD) + tid;
   const int n = a.paired.n;
   /* the point of the next iteration is fetched while the current pair is hashed */
@@ -451,14 +450,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
           }
           /* The reference skips a pair whose alpha_s is NaN BEFORE it counts it; for finite clouds it never is.  alpha_s
            * itself is computed later (k_group), only for the pairs that found a bucket (and a hit without one is retired there). */
-          if (__builtin_expect(odd_values, 0)) { /* k_frames saw a frame or a point that is no ordinary number: count as the reference does */
-            const double* f = a.frames + (size_t)r * 12;
-            const double qy = f[10] + (f[3] * p2.x + f[4] * p2.y + f[5] * p2.z);
-            const double qz = f[11] + (f[6] * p2.x + f[7] * p2.y + f[8] * p2.z);
-            my_pairs += ppf_alpha_exists(qy, qz) ? 1u : 0u;
-          } else {
-            my_pairs += 1u;
-          }
+          my_pairs += 1u; /* k_pairs_odd takes the pairs without an alpha_s off again, should there be any */
           if (b >= 0) {
             stash[it][tid] = make_uint2((uint32_t)b, (uint32_t)j);
             hit_mask |= 1u << it;
@@ -514,6 +506,44 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pairs(MatchArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_down(my_pairs, o);
   if (lane == 0 && my_pairs) atomicAdd(&a.pairs[a.ref_base + r], my_pairs);
+}
+
+/* The reference counts a pair only after its alpha_s has turned out not to be NaN (`continue` before the count).  For ordinary
+ * numbers every pair has one and k_pairs counts without looking; when k_frames has seen a frame or a paired point that is no
+ * ordinary number, this kernel takes the pairs k_pairs counted and the reference would not off the totals again (the same skip
+ * rules, then the alpha's existence as k_group decides it for a hit).  A fixed small grid that returns at once otherwise: in
+ * k_pairs itself the branch cost eight registers and with them a wave per SIMD (0.58 -> 0.64 ms on C2). */
+template <bool DARBOUX, bool S2B>
+__global__ __launch_bounds__(256) void k_pairs_odd(MatchArgs a) {
+  if (a.cursors[CUR_ODDVALUES] == 0u) return;
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x; r < a.n_ref; r += gridDim.x) {
+    const int i_ref = ref_row(a, r);
+    const ppf_vec3 p1 = ld3(a.surf.x, a.surf.y, a.surf.z, i_ref), n1 = ld3(a.surf.nx, a.surf.ny, a.surf.nz, i_ref);
+    const double* f = a.frames + (size_t)r * 12;
+    unsigned long long gone = 0;
+    for (int j = threadIdx.x; j < a.paired.n; j += blockDim.x) {
+      if (!(S2B || j != i_ref)) continue;
+      const ppf_vec3 p2 = ld3(a.paired.x, a.paired.y, a.paired.z, j), n2 = ld3(a.paired.nx, a.paired.ny, a.paired.nz, j);
+      const bool self_pair = S2B && p2.x == p1.x && p2.y == p1.y && p2.z == p1.z && n2.x == n1.x && n2.y == n1.y && n2.z == n1.z;
+      bool skip = self_pair;
+      if (a.pair_radius > 0.0) {
+        const double dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+        skip |= ppf_sqrt(dx * dx + dy * dy + dz * dz) > a.pair_radius;
+      }
+      if (skip) continue;
+      if (DARBOUX) {
+        int32_t key[4];
+        if (!pair_key_darboux(p1, n1, p2, n2, a.angle_step, a.dist_step, key)) continue;
+      }
+      const double qy = f[10] + (f[3] * p2.x + f[4] * p2.y + f[5] * p2.z);
+      const double qz = f[11] + (f[6] * p2.x + f[7] * p2.y + f[8] * p2.z);
+      if (!ppf_alpha_exists(qy, qz)) gone += 1ull;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gone += __shfl_down(gone, o);
+    if (lane == 0 && gone) atomicAdd(&a.pairs[a.ref_base + r], 0ull - gone);
+  }
 }
 
 /* raw hits per reference point = sum of its workgroups' counts */
