@@ -33,8 +33,14 @@ bool have_device() {
   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
 }
 
+constexpr size_t SCAN_ONE_MAX = 40960; /* elements k_scan_one takes (ten rounds) */
 ppf_status device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
   if (n == 0) return PPF_OK;
+  if (n > 1024 && n <= SCAN_ONE_MAX) { /* one workgroup, one launch (<= 1,024 elements are one block of the general kernel anyway) */
+    k_scan_one<<<dim3(1), dim3(1024), 0, st>>>(in, out, n);
+    HIPCHK(hipGetLastError());
+    return PPF_OK;
+  }
   const size_t nb = (n + 1023) / 1024;
   DevBuf<uint32_t> sums, sums_scan;
   if (nb > 1) {

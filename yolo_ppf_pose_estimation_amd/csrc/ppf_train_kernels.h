@@ -467,6 +467,39 @@ __global__ __launch_bounds__(256) void k_scan_block(const uint32_t* __restrict__
   }
   if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = woff + incl;
 }
+/* the same scan by ONE workgroup in rounds of 4,096 elements: up to a few ten thousand elements (the flags, cell counts and
+ * digit tables of the preparation stages and of a crop's sampling) one launch instead of three, which cost more than they compute */
+__global__ __launch_bounds__(1024) void k_scan_one(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  __shared__ uint32_t wave_tot[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (size_t r0 = 0; r0 < n; r0 += 4096) {
+    const size_t base = r0 + (size_t)threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+    const uint32_t s = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const uint32_t w = wave_tot[k]; if (k < wv) woff += w; total += w; }
+    uint32_t excl = carry + woff + incl - s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (base + k < n) out[base + k] = excl;
+      excl += v[k];
+    }
+    carry += total;
+    __syncthreads(); /* wave_tot is written again in the next round */
+  }
+}
 __global__ void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_off, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] += block_off[i / 1024];
