@@ -142,6 +142,7 @@ ppf_workspace::~ppf_workspace() {
   for (auto& e : batch_ev)
     if (e) (void)hipEventDestroy(e);
   if (model && !model_owns_me) (void)ppf_model_release(model);
+  if (h_sum) (void)hipHostFree(h_sum);
 }
 
 /* bytes of hit scratch one hit costs: raw {bucket, j} + sorted payload (alpha_s, cell) + its share of the run table */
@@ -186,6 +187,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   ws->stream = st;
   ws->clustered = false;
   ws->checked = false;
+  ws->sum_valid = false;
   ws->final_poses.clear();
   const int retries = retry ? ws->stats.n_retries : 0;
   memset(&ws->stats, 0, sizeof(ws->stats));
@@ -430,6 +432,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     ws->clustered = true;
   }
   if (ws->timing) HIPCHK(hipEventRecord(ws->ev[1], st));
+  if (!ws->h_sum) HIPCHK(hipHostMalloc((void**)&ws->h_sum, 32 * sizeof(unsigned long long), hipHostMallocDefault));
+  k_summary<<<dim3(1), dim3(64), 0, st>>>(fa.totals, ws->cursors.p + CUR_OVERFLOW, ws->clustered ? ws->cl_u32.p : nullptr, ws->h_sum);
+  HIPCHK(hipGetLastError());
+  ws->sum_valid = true;
   return PPF_OK;
 }
 
@@ -444,8 +450,13 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
     const int T = ws->model->info.n_tiles;
     unsigned long long tot[16];
     uint32_t ovf = 0;
-    HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
+    if (ws->sum_valid) { /* k_summary wrote them into pinned memory as the call's last act */
+      memcpy(tot, ws->h_sum, sizeof(tot));
+      ovf = (uint32_t)ws->h_sum[16];
+    } else {
+      HIPCHK(hipMemcpy(tot, ws->counters.p + (size_t)ws->n_ref * T + ws->n_ref, sizeof(tot), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ovf, ws->cursors.p + CUR_OVERFLOW, sizeof(ovf), hipMemcpyDeviceToHost));
+    }
     if (!ovf) {
       ws->stats.n_votes = tot[0];
       ws->stats.n_pairs = tot[1];
@@ -489,7 +500,8 @@ static ppf_status workspace_finish(ppf_workspace* ws) {
       ws->frac_known = true;
       if (ws->clustered) {
         uint32_t nf = 0;
-        HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (ws->sum_valid) nf = (uint32_t)ws->h_sum[17];
+        else HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
         ws->stats.n_poses = (int)nf;
       }
       if (ws->timing) {
@@ -542,7 +554,8 @@ ppf_status ppf_workspace_results(ppf_workspace* ws, ppf_vote* votes, ppf_pose* r
   if ((poses || n_poses) && ws->clustered) {
     if (ws->final_poses.empty() && nr > 0) {
       uint32_t nf = 0;
-      HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      if (ws->sum_valid) nf = (uint32_t)ws->h_sum[17];
+      else HIPCHK(hipMemcpy(&nf, ws->cl_u32.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
       ws->final_poses.resize(nf);
       if (nf) HIPCHK(hipMemcpy(ws->final_poses.data(), ws->d_final.p, (size_t)nf * sizeof(ppf_pose), hipMemcpyDeviceToHost));
     }
@@ -698,6 +711,7 @@ ppf_status ppf_cluster_poses_device(const ppf_model* m, ppf_workspace* ws, const
   memset(&ws->stats, 0, sizeof(ws->stats));
   ws->n_ref = 0; ws->n_ref_total = 0; ws->n_batches = 0;
   ws->pending = true; ws->checked = true; /* no hit pools involved */
+  ws->sum_valid = false;
   ws->clustered = false;
   if (n == 0) return PPF_OK;
   double pos, rot;

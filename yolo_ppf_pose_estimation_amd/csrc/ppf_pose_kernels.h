@@ -579,4 +579,13 @@ __global__ void k_vote_keys(const ppf_pose* __restrict__ in, int n, unsigned lon
   if (i < n) keys[i] = in[i].num_votes;
 }
 
+/* the call's summary for the host, straight into pinned memory: out[0..15] totals, out[16] overflow word, out[17] clustered poses */
+__global__ void k_summary(const unsigned long long* __restrict__ totals, const uint32_t* __restrict__ overflow, const uint32_t* __restrict__ n_final,
+                          unsigned long long* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t < 16) out[t] = totals[t];
+  else if (t == 16) out[16] = (unsigned long long)*overflow;
+  else if (t == 17) out[17] = n_final ? (unsigned long long)*n_final : 0ull;
+}
+
 #endif /* PPF_POSE_KERNELS_H */
