@@ -388,17 +388,27 @@ ppf_status icp_register_batch(const float* d_src, int n, int sstride, int snoff,
      * polling that is a few microseconds quicker than going through the stream (which is only asked when the counter has
      * not moved for a long while).  A pass launched after the level's last one finds every job done and returns at once. */
     int launched = 0, reported = 0;
-    const unsigned long long level_base = tails_launched;
+    unsigned long long due[PPF_ICP_BATCH2 + 1]; /* the counter's value when pass k has reported, k modulo the passes in the stream */
+    bool first_of_level = true;
     while (true) {
       while (launched < max_iter && launched - reported < (int)PPF_ICP_BATCH2) {
-        k_icp2_nn<<<dim3(nn_blocks, uj), dim3(256), 0, st>>>(B, ns, nd, step, step_shift, nn_rows, (prm.flags & PPF_ICP_GRID_ALWAYS) ? 0 : ICP_BRUTE_ND);
-        k_icp2_tail<<<dim3(uj), dim3(1024), tail_lds, st>>>(B, ns, nd, step, prm.rejection_scale, staged, level == 0 ? 1 : 0);
+        /* a pass is launched for the jobs that had not finished the level when the host last looked (all of them at its start) */
+        IcpLive live;
+        unsigned nl = 0;
+        for (int j = 0; j < jobs; j++)
+          if (first_of_level || reinterpret_cast<volatile int*>(sc.h_done)[j] == 0) live.job[nl++] = j;
+        if (nl == 0) live.job[nl++] = 0; /* cannot happen: the loop ends when every job is done */
+        for (unsigned k = nl; k < (unsigned)ICP_MAX_JOBS; k++) live.job[k] = live.job[0];
+        k_icp2_nn<<<dim3(nn_blocks, nl), dim3(256), 0, st>>>(B, live, ns, nd, step, step_shift, nn_rows, (prm.flags & PPF_ICP_GRID_ALWAYS) ? 0 : ICP_BRUTE_ND);
+        k_icp2_tail<<<dim3(nl), dim3(1024), tail_lds, st>>>(B, live, ns, nd, step, prm.rejection_scale, staged, level == 0 ? 1 : 0);
+        tails_launched += (unsigned long long)nl;
+        due[launched % (PPF_ICP_BATCH2 + 1)] = tails_launched;
         launched++;
-        tails_launched += (unsigned long long)jobs;
       }
+      first_of_level = false;
       HIPCHK(hipGetLastError());
       if (reported >= launched) break; /* max_iter == 0, or every launched pass has reported */
-      if (ppf_status rc = wait_ticks(level_base + (unsigned long long)(reported + 1) * (unsigned long long)jobs)) return rc;
+      if (ppf_status rc = wait_ticks(due[reported % (PPF_ICP_BATCH2 + 1)])) return rc;
       reported++;
       bool all = true;
       for (int j = 0; j < jobs; j++) all &= reinterpret_cast<volatile int*>(sc.h_done)[j] != 0;

@@ -1149,8 +1149,11 @@ __device__ __forceinline__ float icp_box_lb2(const float4 lo, const float4 hi, f
 
 /* exact nearest neighbour of every source row of the level and the picky-ownership keys (see the header of this section) */
 constexpr int ICP_NN_ROWS = 8; /* rows a wave takes in turn, at most */
-__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, int ns, int nd, int step, int step_shift, int rows, int brute_nd) {
-  const int job = blockIdx.y;
+/* the jobs a pass is launched for: those that had not finished their level when the host last looked (a finished job's
+ * workgroups return at once, but 20,000 of them per finished job and pass are 5 us) */
+struct IcpLive { int job[ICP_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, IcpLive live, int ns, int nd, int step, int step_shift, int rows, int brute_nd) {
+  const int job = live.job[blockIdx.y];
   const IcpState2* st = B.state + job;
   if (st->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1535,14 +1538,14 @@ __device__ uint32_t icp_block_select3(F val, const int n, const uint32_t rank, u
 /* everything of an iteration after the neighbour search, one workgroup per job (see the header of this section).
  * Dynamic LDS: max(ns * 4 when staged, 16 waves x 64 x 9 doubles of chunk rows). */
 constexpr int ICP_TAIL_VAL_BYTES = 16 * ICP_CHUNK * 9 * 8;
-__global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, int ns, int nd, int step, float rej_scale, int staged, int last_level) {
+__global__ __launch_bounds__(1024) void k_icp2_tail(IcpBatch B, IcpLive live, int ns, int nd, int step, float rej_scale, int staged, int last_level) {
   extern __shared__ __align__(16) unsigned char t_dyn[];
   __shared__ __align__(16) uint32_t hist[264], s_list[264];
   __shared__ uint32_t sh[8], wsum[16];
   __shared__ double s_tot[ICP_ENTRIES];
   __shared__ float s_thr;
   __shared__ int s_done, s_nsel;
-  const int job = blockIdx.x;
+  const int job = live.job[blockIdx.x];
   IcpState2* st = B.state + job;
   if (st->done) { /* this job's level is over: only the host's count of finished workgroups moves */
     if (threadIdx.x == 0) icp_tick(B, false);
