@@ -1222,18 +1222,25 @@ __global__ __launch_bounds__(256) void k_icp2_nn(IcpBatch B, IcpLive live, int n
       auto scan_two = [&](const uint32_t s0, const uint32_t n0, const uint32_t s1, const uint32_t n1) {
         const uint32_t nmax = n0 > n1 ? n0 : n1;
         for (uint32_t i0 = 0; i0 < nmax; i0 += 256) {
+          /* up to four steps of 64 rows, their loads issued together; the steps past the longer leaf's end are not issued at all
+           * (wave-uniform): a sparse scene's leaves hold a few dozen rows, and three empty steps were three quarters of a scan */
+          const uint32_t rem = nmax - i0;
           float4 pa[4], pb[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
-            pa[u] = pts[s0 + (i < n0 ? i : 0u)]; /* a leaf with rows starts inside the list; an empty one reads row s0 (clamped into the list by the caller) */
-            pb[u] = pts[s1 + (i < n1 ? i : 0u)];
+            if (u == 0 || (uint32_t)(u * 64) < rem) {
+              const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
+              pa[u] = pts[s0 + (i < n0 ? i : 0u)]; /* a leaf with rows starts inside the list; an empty one reads row s0 (clamped into the list by the caller) */
+              pb[u] = pts[s1 + (i < n1 ? i : 0u)];
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
-            take(pa[u], i < n0);
-            take(pb[u], i < n1);
+            if (u == 0 || (uint32_t)(u * 64) < rem) {
+              const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
+              take(pa[u], i < n0);
+              take(pb[u], i < n1);
+            }
           }
         }
         key = icp_wave_min64(key);
