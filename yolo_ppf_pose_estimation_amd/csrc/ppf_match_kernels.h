@@ -10,7 +10,7 @@
  *
  *   k_pairs    one thread per scene pair (s_r, s_i): pair feature -> 4 x int32 key -> dense bucket id
  *              (key table, MurmurHash3 for keys outside it).  About 15 % of the pairs of a crop land in a
- *              non-empty slot; a workgroup (2,048 pairs of one reference point) appends its hits
+ *              non-empty slot; a workgroup (3,072 pairs of one reference point) appends its hits
  *              {bucket, j} to a striped pool with ONE atomic, so the pool holds exactly the hits that
  *              exist (capacity is an estimate; running out raises a flag and the host repeats the call
  *              with a bigger pool).  VALU(fp64)-bound.
@@ -146,7 +146,14 @@ __device__ __forceinline__ void vote_one(const uint32_t p, const int k, const ui
 #endif
 
 constexpr int PAIR_BLOCK = 256;
-constexpr int PAIRS_PER_THREAD = 8;   /* one k_pairs workgroup covers 2048 paired points of one reference point */
+#ifndef PPF_PAIRS_PER_THREAD
+#define PPF_PAIRS_PER_THREAD 12
+#endif
+/* one k_pairs workgroup covers 3,072 paired points of one reference point.  Swept in round 4 (k_pairs on C2 / C4 / C5):
+ * 4: 0.74 ms; 8: 0.585 / 10.7 / 18.6; 10: 0.555; 12: 0.533 / 9.4 / 17.0; 14: 0.515 (50,000 points are 13.95 chunks of 3,584:
+ * a fit of that size, not taken); 16: 0.560; 24: 0.625; 32: 0.81 -- fewer workgroups pay the prologue, the compaction and the
+ * pool append (and k_group walks fewer pieces), until the stash takes the LDS of a fifth workgroup per CU */
+constexpr int PAIRS_PER_THREAD = PPF_PAIRS_PER_THREAD;
 constexpr int VOTE_BLOCK = 1024;
 constexpr int VOTE_WAVES = VOTE_BLOCK / 64;
 constexpr int VOTE_UNROLL = 4;        /* pair records (2 entries each) loaded per lane per batch */
