@@ -13,6 +13,13 @@ struct ppf_cloud {
   int n = 0;
 };
 
+/* cells per axis of the neighbour-search grid = sqrt(n) / PPF_KNN_GDIV.  Swept in round 4 (normals(30) / SOR(50) on the reference's
+ * 10,395 / 11,369-point clouds and on 50,000 points): 6.0: 0.280 / 0.359 / 1.27 / 1.39 ms; 4.5: 0.255 / 0.350 / 1.09 / 1.22;
+ * 4.0: 0.252 / 0.353 / 1.07 / 1.19; 3.0: 0.253 / 0.382 / 1.01 / 1.17; 2.0: 0.330 / 0.530 -- finer cells, fewer candidates per
+ * step of the merge network, until the cube has to grow a second time for most queries.  The result does not depend on it. */
+#ifndef PPF_KNN_GDIV
+#define PPF_KNN_GDIV 4.0
+#endif
 namespace {
 
 inline dim3 grid_for(size_t items, int block) { return dim3((unsigned)std::max<size_t>((items + block - 1) / block, 1)); }
@@ -81,7 +88,7 @@ ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>
     g.lo[a] = lo;
     ext_max = std::max(ext_max, hi - lo);
   }
-  const int G = std::max(1, std::min(128, (int)(std::sqrt((double)n) / 6.0)));
+  const int G = std::max(1, std::min(128, (int)(std::sqrt((double)n) / PPF_KNN_GDIV)));
   g.h = ext_max > 0.f ? ext_max / (float)G : 1.0f;
   g.inv_h = 1.0f / g.h;
   size_t cells = 1;
