@@ -144,7 +144,7 @@ ppf_status device_sample_cloud(const float* d_src, int n, int stride, int noff, 
   const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
   const unsigned nb256 = (unsigned)((n + 255) / 256);
-  k_bbox<<<dim3(std::min(nb256, 2048u)), dim3(256), 0, st>>>(d_src, n, stride, bbox.p);
+  k_bbox<<<dim3(std::max(1u, std::min((unsigned)((n + 2047) / 2048), 256u))), dim3(256), 0, st>>>(d_src, n, stride, bbox.p);
   HIPCHK(hipGetLastError());
   HIPCHK(keys.reserve(n)); HIPCHK(vals.reserve(n)); HIPCHK(keys2.reserve(n)); HIPCHK(vals2.reserve(n));
   k_cell_keys<<<dim3(nb256), dim3(256), 0, st>>>(d_src, n, stride, bbox.p, ns, keys.p, vals.p);

@@ -75,7 +75,7 @@ ppf_status cloud_knn(const ppf_cloud* in, int k, DevBuf<float4>& q4, DevBuf<int>
   HIPCHK(mm.reserve(6));
   const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   HIPCHK(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
-  k_prep_minmax<<<dim3(std::min<unsigned>((unsigned)((n + 255) / 256), 2048u)), dim3(256)>>>(in->rows.p, n, mm.p);
+  k_prep_minmax<<<dim3(std::max(1u, std::min<unsigned>((unsigned)((n + 2047) / 2048), 256u))), dim3(256)>>>(in->rows.p, n, mm.p);
   HIPCHK(hipGetLastError());
   uint32_t h_mm[6];
   HIPCHK(hipMemcpy(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost));
@@ -232,7 +232,7 @@ ppf_status ppf_prep_voxel_grid(const ppf_cloud* in, double leaf, ppf_cloud** out
   HIPCHK(mm.reserve(6));
   const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   HIPCHK(hipMemcpy(mm.p, init, sizeof(init), hipMemcpyHostToDevice));
-  k_prep_minmax<<<dim3(std::min<unsigned>((unsigned)((n + 255) / 256), 2048u)), dim3(256)>>>(dense->rows.p, n, mm.p);
+  k_prep_minmax<<<dim3(std::max(1u, std::min<unsigned>((unsigned)((n + 2047) / 2048), 256u))), dim3(256)>>>(dense->rows.p, n, mm.p);
   HIPCHK(hipGetLastError());
   uint32_t h_mm[6];
   HIPCHK(hipMemcpy(h_mm, mm.p, sizeof(h_mm), hipMemcpyDeviceToHost));

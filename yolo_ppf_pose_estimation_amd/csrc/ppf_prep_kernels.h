@@ -91,9 +91,20 @@ __global__ __launch_bounds__(256) void k_prep_minmax(const float* __restrict__ r
       hi[k] = max(hi[k], (uint32_t)__shfl_down(hi[k], o));
     }
   }
+  /* one set of atomics per workgroup, and few workgroups (the host caps the grid): six addresses serve them one at a time, and
+   * 560 waves' worth were 35 of this kernel's 41 us */
+  __shared__ uint32_t s_mm[4][6];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) { atomicMin(&mm[k], lo[k]); atomicMax(&mm[3 + k], hi[k]); }
+    for (int k = 0; k < 3; k++) { s_mm[wave][k] = lo[k]; s_mm[wave][3 + k] = hi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    uint32_t v = s_mm[0][k];
+    for (int w = 1; w < 4; w++) v = k < 3 ? min(v, s_mm[w][k]) : max(v, s_mm[w][k]);
+    if (k < 3) atomicMin(&mm[k], v); else atomicMax(&mm[k], v);
   }
 }
 struct VoxelGridDims {

@@ -46,12 +46,19 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ src, int
       hi[k] = max(hi[k], (uint32_t)__shfl_down(hi[k], o));
     }
   }
+  /* one set of atomics per workgroup, and few workgroups (the host caps the grid): six addresses serve them one at a time */
+  __shared__ uint32_t s_bb[4][6];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      atomicMin(&bbox[k], lo[k]);
-      atomicMax(&bbox[3 + k], hi[k]);
-    }
+    for (int k = 0; k < 3; k++) { s_bb[wave][k] = lo[k]; s_bb[wave][3 + k] = hi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    uint32_t v = s_bb[0][k];
+    for (int w = 1; w < 4; w++) v = k < 3 ? min(v, s_bb[w][k]) : max(v, s_bb[w][k]);
+    if (k < 3) atomicMin(&bbox[k], v); else atomicMax(&bbox[k], v);
   }
 }
 
