@@ -54,7 +54,13 @@ __host__ __device__ inline unsigned long long acc_hist_lower(int cls) { /* small
   return (unsigned long long)(4 + fr) << (lg - 2);
 }
 
-__global__ void k_finalize(FinalArgs a) {
+__global__ __launch_bounds__(64) void k_finalize(FinalArgs a) {
+  /* the call's totals: a workgroup (ONE wave) adds its reference points' votes and pairs up in LDS and sends one pair of atomics
+   * (2,500 threads adding to two addresses were most of this kernel's 15 us) */
+  __shared__ unsigned long long s_tot[2];
+  if (threadIdx.x == 0) { s_tot[0] = 0ull; s_tot[1] = 0ull; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= a.n_ref) return;
   uint32_t maxVotes = 0, flat = 0;
@@ -88,8 +94,14 @@ __global__ void k_finalize(FinalArgs a) {
   ppf_vote v;
   v.ref_ind_max = refIndMax; v.alpha_ind_max = alphaIndMax; v.max_votes = maxVotes;
   a.votes[r] = v;
-  atomicAdd(&a.totals[0], nv);
-  atomicAdd(&a.totals[1], a.pairs[r]);
+  atomicAdd(&s_tot[0], nv);
+  atomicAdd(&s_tot[1], a.pairs[r]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) { /* lane 0 is a reference point in every workgroup of the grid */
+    atomicAdd(&a.totals[0], s_tot[0]);
+    atomicAdd(&a.totals[1], s_tot[1]);
+  }
 
   const int i_ref = (a.ref_offset + r * a.ref_stride) * a.scene_step;
   double Rsg[9], tsg[3], RInv[9], tInv[3], Rmg[9], tmg[3];
