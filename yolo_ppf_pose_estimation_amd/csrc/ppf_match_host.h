@@ -374,7 +374,8 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
     va.n_ref = std::min(batch, n_ref - base);
     if (bi) HIPCHK(hipMemsetAsync(ws->cursors.p, 0, CUR_OVERFLOW * sizeof(uint32_t), st)); /* the overflow word lives on */
     if (va.agg_min_hits) HIPCHK(hipMemsetAsync(ws->table_desc.p, 0, (size_t)table_cap * sizeof(uint2), st));
-    k_frames<<<dim3((va.n_ref + 63) / 64), dim3(64), 0, st>>>(va);
+    /* a thread per reference point, and enough threads for its look at the paired points (40 waves walking 50,000 points: 10 us) */
+    k_frames<<<dim3(std::max((va.n_ref + 63) / 64, std::min((va.paired.n + 63) / 64, 1024))), dim3(64), 0, st>>>(va);
     HIPCHK(hipGetLastError());
     if (ws->timing) HIPCHK(hipEventRecord(ws->batch_ev[ws->ev_base + bi * 4 + 0], st));
     launch_pairs(va, darboux, st);
@@ -401,7 +402,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
       HIPCHK(hipGetLastError());
     }
     va.acc32 = acc32_all ? 1 : 2; /* 2: the (reference point, tile)s the 16-bit launch listed, over a grid that does not depend on their number */
-    const dim3 g32 = acc32_all ? grid32 : dim3(std::min(grid32.x, 1024u));
+    const dim3 g32 = acc32_all ? grid32 : dim3(std::min(grid32.x, 256u)); /* one workgroup per CU walks the list (a launch of 1,024 with nothing to do: 10 us) */
     if (params->alpha_range_2pi) k_vote<true, true><<<g32, dim3(VOTE_BLOCK), lds, st>>>(va);
     else k_vote<false, true><<<g32, dim3(VOTE_BLOCK), lds, st>>>(va);
     va.acc32 = 0;
