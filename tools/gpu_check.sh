@@ -12,5 +12,7 @@ import json
 d=json.loads(open('gpurun_out/final/bench_c2_check.json').read().strip().splitlines()[-1])
 print('c2', d['ms_per_step'], d['kernel_ms']['k_vote'], d['roofline']['frac'], d['roofline']['traffic_stale'], d['roofline']['traffic_stale_reason'])
 print('host', d['host_entry']['ms_per_match'], 'pipelined', d['pipelined']['ms_per_step'])
-for k,v in d['other_configs'].items(): print(k, v['ms_per_step'], v['kernel_ms'].get('k_vote'), v['roofline']['frac'], v['roofline']['traffic_stale'], v['roofline']['traffic_stale_reason'])
+for k,v in d['other_configs'].items():
+    if 'ms_per_step' in v: print(k, v['ms_per_step'], v['kernel_ms'].get('k_vote'), v['roofline']['frac'], v['roofline']['traffic_stale'], v['roofline']['traffic_stale_reason'])
+    else: print(k, 'frame->pose', v.get('frame_to_pose_ms'), 'prep', v.get('prep_ms'), 'match', v.get('match_ms'), 'icp', v.get('icp_ms'), 'golden', v.get('equals_oracle_golden'))
 PY
