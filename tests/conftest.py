@@ -25,3 +25,11 @@ def pytest_configure(config):
 def bottle():
     """The reference's model cloud (data/bottle_remesh_meter_normalized.ply) as committed data."""
     return np.load(os.path.join(GOLDEN, "bottle_model_xyzn.npy"))
+
+
+def soak_seeds(base, env):
+    """Seeds of a parametrised sweep: the suite's `base` draws, plus $env more for a soak run (tools/soak.sh).  The extra
+    draws start at PPF_SOAK_OFFSET when it is set (fresh seeds for a further soak run), else right behind the suite's."""
+    extra = int(os.environ.get(env, "0"))
+    off = int(os.environ.get("PPF_SOAK_OFFSET", str(base)))
+    return list(range(base)) + [max(off, base) + i for i in range(extra)]

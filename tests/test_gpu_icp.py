@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from conftest import soak_seeds
 from yolo_ppf_pose_estimation_amd import synth
 from yolo_ppf_pose_estimation_amd.detector import ICP, PPF3DDetector, Pose3D
 
@@ -217,7 +218,7 @@ def _icp_draw(seed):
                 duplicates=bool(rng.integers(0, 3) == 0))
 
 
-@pytest.mark.parametrize("seed", range(6 + int(os.environ.get("PPF_SOAK_ICP", "0"))))
+@pytest.mark.parametrize("seed", soak_seeds(6, "PPF_SOAK_ICP"))
 def test_icp_random_draw(bottle, seed):
     """seeded draws over model shape and size, scene size and clutter, number of poses, how far off they start (up to poses
     thrown off the object: the <= 6 correspondences break path), every ICP parameter and the neighbour-search schedule:

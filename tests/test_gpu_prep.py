@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from conftest import soak_seeds
 import prep_data as D
 from yolo_ppf_pose_estimation_amd import synth
 from yolo_ppf_pose_estimation_amd._capi import PPFError
@@ -188,7 +189,7 @@ def test_reference_sequence_on_a_synthetic_frame(bottle):
     assert cp.Matching("bottle", obj_mat, 0.05, 0.05) is not None
 
 
-@pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PPF_SOAK_PREP", "0"))))
+@pytest.mark.parametrize("seed", soak_seeds(4, "PPF_SOAK_PREP"))
 def test_stages_random_draw(frame, seed):
     """seeded draws over the stages' parameters and inputs (a random window of the reference's frame or a synthetic plane +
     sphere cloud with noise, duplicated rows and a few non-finite ones): voxel grid, neighbour lists, outlier removal, normals

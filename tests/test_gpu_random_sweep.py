@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from conftest import soak_seeds
 from yolo_ppf_pose_estimation_amd import synth
 from yolo_ppf_pose_estimation_amd.detector import PPF3DDetector
 
@@ -38,7 +39,7 @@ def _draw(seed):
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(24 + int(os.environ.get("PPF_SOAK_MATCH", "0"))))
+@pytest.mark.parametrize("seed", soak_seeds(24, "PPF_SOAK_MATCH"))
 def test_random_configuration(bottle, seed):
     cfg = _draw(seed)
     model = bottle if cfg["kind"] == "bottle" else synth.make_solid(cfg["kind"], 6000, seed=seed + 1)
@@ -100,7 +101,7 @@ def _draw_policy(seed):
                 max_tile_refs=int(rng.choice([0, 0, 90, 300])), acc32=int(rng.choice([0, 0, 1])))
 
 
-@pytest.mark.parametrize("seed", range(12 + int(os.environ.get("PPF_SOAK_POLICY", "0"))))
+@pytest.mark.parametrize("seed", soak_seeds(12, "PPF_SOAK_POLICY"))
 def test_random_policy_configuration(bottle, seed):
     """the same bar under drawn combinations of the PCL-semantics switches (exact keys, Darboux feature, pair radius, relative
     rotation metric, 2 pi alpha range: tests/test_gpu_policy.py has each alone), with forced tiling and 32-bit cells mixed in"""
@@ -154,7 +155,7 @@ def _bounded(cfg):
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(10 + int(os.environ.get("PPF_SOAK_DEGENERATE", "0"))))
+@pytest.mark.parametrize("seed", soak_seeds(10, "PPF_SOAK_DEGENERATE"))
 def test_random_degenerate_inputs(bottle, seed):
     """inputs a real crop can hold and a test cloud rarely does, drawn together: models of a dozen rows, flat models (every
     pair of a face has parallel normals: acos arguments a rounding above 1, NaN angle bins), scenes of one or two rows, rows
@@ -200,7 +201,7 @@ def test_random_degenerate_inputs(bottle, seed):
         assert np.array_equal(g.pose, w["pose"], equal_nan=True), cfg
 
 
-@pytest.mark.parametrize("seed", range(4 + int(os.environ.get("PPF_SOAK_BATCH", "0"))))
+@pytest.mark.parametrize("seed", soak_seeds(4, "PPF_SOAK_BATCH"))
 def test_random_batches_equal_single_matches(bottle, seed):
     """ppf_match_batch on drawn batches (1 - 4 models of different shapes, sampling steps and alpha resolutions; 1 - 7 crops of
     ragged sizes, a crop of a handful of rows among them; presampled or not; lanes that do not divide the crops): every

@@ -4,6 +4,7 @@
 # One pytest process per sweep, logs under gpurun_out/soak/ (publish the summary lines in profiles/rNN_soak.md).
 cd ${GRAFT_REPO_ROOT:-.}
 OUT=gpurun_out/soak; mkdir -p $OUT
+# PPF_SOAK_OFFSET=N in the environment starts the extra draws at seed N (fresh seeds for a further run)
 export PPF_SOAK_MATCH=${1:-300} PPF_SOAK_ICP=${2:-150} PPF_SOAK_PREP=${3:-60} PPF_SOAK_POLICY=${4:-100} PPF_SOAK_DEGENERATE=${5:-100} PPF_SOAK_BATCH=${6:-40}
 timeout -k 10 650 python -m pytest tests/test_gpu_random_sweep.py -m gpu -q -p no:cacheprovider > $OUT/match.log 2>&1; echo "match rc=$? $(tail -1 $OUT/match.log)"
 timeout -k 10 350 python -m pytest tests/test_gpu_icp.py -k random_draw -m gpu -q -p no:cacheprovider > $OUT/icp.log 2>&1; echo "icp rc=$? $(tail -1 $OUT/icp.log)"
