@@ -342,7 +342,10 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   va.tables = ws->tables.p; va.table_desc = ws->table_desc.p; va.table_cap = table_cap;
   va.work = ws->work.p; va.perm = ws->perm.p; va.perm_group = ws->perm_group.p;
 
-  const size_t lds = VOTE_LDS_FIXED + (size_t)vote_lds_words(m->info.tile_refs, m->info.num_angles) * 4;
+  /* the run staging gets the LDS this model's accumulator tile leaves (its least size is what the tile was sized against) */
+  const size_t acc_words = (size_t)vote_lds_words(m->info.tile_refs, m->info.num_angles);
+  va.run_seg = vote_run_seg(acc_words, (size_t)LDS_BYTES);
+  const size_t lds = vote_lds_fixed(va.run_seg) + acc_words * 4;
   if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
   /* k_group's dynamic LDS: one counter per bucket of a round, the prefix of the pool pieces */
   const size_t group_lds = (size_t)((va.round_buckets + 1) & ~1) * sizeof(uint32_t) + (size_t)((va.pair_chunks + 2) & ~1) * sizeof(uint32_t) * 2;

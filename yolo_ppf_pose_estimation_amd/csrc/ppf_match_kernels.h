@@ -170,9 +170,11 @@ constexpr int AGG_MAX_ANGLES = 31;    /* Y = floor(alpha_s*A/(4pi)) must stay in
 #ifndef PPF_RUN_SEG
 #define PPF_RUN_SEG 704
 #endif
-constexpr int RUN_SEG = PPF_RUN_SEG;  /* runs staged in LDS per segment (every segment costs the workgroup two dependent reads and three barriers: 256 -> 512 was worth
-                                         3 % on C2, whose reference points have about 580 runs: 704 is what the LDS leaves room for next to a 2,000-row tile) */
-static_assert(RUN_SEG % 64 == 0 && RUN_SEG <= 1024, "the staging loop gives one thread to a run and scans whole waves");
+constexpr int RUN_SEG = PPF_RUN_SEG;  /* runs staged in LDS per segment, AT LEAST (every segment costs the workgroup two dependent reads and three barriers: 256 -> 512
+                                         was worth 3 % on C2, whose reference points have about 600 runs): the tile size of a model is chosen with this much staging ... */
+constexpr int RUN_SEG_MAX = 1024;     /* ... and a call gives the staging whatever LDS the model's accumulator tile then leaves, in steps of 64 runs (MatchArgs::run_seg;
+                                         C2's 2,000-row tile: 896, and 704 -> 896 is another 1 % -- a third of its reference points have more than 704 runs) */
+static_assert(RUN_SEG % 64 == 0 && RUN_SEG <= RUN_SEG_MAX && RUN_SEG_MAX == 1024, "the staging loop gives one thread to a run and scans whole waves");
 constexpr int GROUP_BLOCK = 512;       /* two k_group workgroups per CU when the bucket counters fit half the LDS (0.705 -> 0.665 ms on C2) */
 #ifndef PPF_GROUP_MLP
 #define PPF_GROUP_MLP 4
@@ -200,12 +202,17 @@ constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
  * k_vote copies rows + ranges of the table an item works with into its wave's LDS (AGG_SCRATCH bytes) and reads the
  * offsets of an entry's own cell straight from the table (four of them, a block of records ahead of their votes). */
 constexpr int AGG_ROW = 20;                                        /* bytes per row: 17 counts + padding; 5 words: the same word of rows q and q' never shares a bank */
-constexpr int AGG_OFF_CE = ((AGG_Q + 1) * AGG_ROW + 15) / 16 * 16;  /* cell ranges behind the rows */
-constexpr int AGG_SCRATCH = AGG_OFF_CE + ((AGG_Q + 1) * 4 + 15) / 16 * 16; /* per-wave LDS of k_vote: rows + ranges */
+/* the range of a cell's hits in the cell-sorted hit list rides in the cell's row: bytes 17 and 18 (first hit, end; at most
+ * AGG_SUB = 191), next to count 16 in the row's last word -- which k_vote reads a block of records ahead anyway (round 4: the
+ * ranges as a table of their own behind the rows cost 272 bytes of LDS per wave and two more LDS reads per block, -1.7 %) */
+constexpr int AGG_ROW_CE = 17;
+constexpr int AGG_SCRATCH = ((AGG_Q + 1) * AGG_ROW + 15) / 16 * 16; /* per-wave LDS of k_vote: the rows */
 constexpr int TBL_OFF_A32 = AGG_SCRATCH;
 constexpr int TBL_A32_BYTES = (AGG_NY * AGG_Q > 768 ? AGG_NY * AGG_Q : 768);
 constexpr int TBL_OFF_IDX = TBL_OFF_A32 + TBL_A32_BYTES;
-constexpr int TBL_BYTES = TBL_OFF_IDX + 192;                        /* one table in HBM, and the LDS a k_tables wave builds it in */
+constexpr int TBL_BYTES = TBL_OFF_IDX + 192;                        /* one table in HBM */
+constexpr int AGG_OFF_CE = TBL_BYTES;                               /* the build's cell counters: LDS of k_tables only, not part of the table */
+constexpr int TBL_BUILD_BYTES = AGG_OFF_CE + ((AGG_Q + 1) * 4 + 15) / 16 * 16; /* the LDS a k_tables wave builds a table in */
 static_assert(AGG_SUB * 4 <= 768 && AGG_SUB <= 192 && AGG_SUB < 256, "table hit range too long");
 static_assert(AGG_SCRATCH % 16 == 0 && TBL_BYTES % 16 == 0, "tables are copied 16 bytes at a time");
 constexpr int TABLE_BLOCK = 256; /* k_tables: four tables per workgroup */
@@ -343,6 +350,7 @@ struct MatchArgs {
   int agg_min_hits;             /* 0: every run votes directly */
   int key_exact;                /* PPF_KEY_EXACT table: keys outside the key table (but for NaN angle bins, key_index_nan) match nothing */
   double pair_radius;           /* > 0: pairs farther apart than this are skipped (not counted) */
+  int run_seg;                  /* runs k_vote stages per segment: RUN_SEG .. RUN_SEG_MAX, a multiple of 64 (vote_run_seg) */
   int acc32;                    /* k_vote<.., true> (32-bit cells, one workgroup per half of a tile's rows): 1 = every (reference point, tile),
                                    2 = only those the 16-bit launch flagged in ovf_items */
   uint32_t* ovf_items;          /* [n_ref_all * n_tiles] != 0: voted with 32-bit cells -- 1: a 16-bit cell of this (reference point, tile) overflowed;
@@ -1145,6 +1153,15 @@ __device__ __forceinline__ void table_build(const uint32_t ws, const float S, co
     }
   }
   wave_lds_fence();
+  /* the counters now hold the cell starts (entry AGG_Q: the number of hits): every row gets its cell's range; the all-zero row
+   * of the entries that vote one by one gets all hits */
+  if (lane < AGG_Q) {
+    const uint2 se = lds_ld2(ws + AGG_OFF_CE + lane * 4);
+    lds_st8(ws + lane * AGG_ROW + AGG_ROW_CE, se.x);
+    lds_st8(ws + lane * AGG_ROW + AGG_ROW_CE + 1, se.y);
+  }
+  if (lane == 0) lds_st8(ws + AGG_Q * AGG_ROW + AGG_ROW_CE + 1, (uint32_t)ms);
+  wave_lds_fence();
 }
 
 /* guard band of the direct bin arithmetic (see k_vote): the folded offsets a table stores carry it */
@@ -1161,14 +1178,14 @@ __device__ __forceinline__ float vote_guard_band(const int A) {
  * each one covers: a run's hits, AGG_SUB at a time).  A wave builds its table in LDS and copies it out.  Built ONCE here,
  * where k_vote used to rebuild it for every chunk of records, accumulator tile and half it met the run in. */
 __global__ __launch_bounds__(TABLE_BLOCK) void k_tables(MatchArgs a) {
-  __shared__ __align__(16) unsigned char tsm[(TABLE_BLOCK / 64) * TBL_BYTES];
+  __shared__ __align__(16) unsigned char tsm[(TABLE_BLOCK / 64) * TBL_BUILD_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t t = blockIdx.x * (TABLE_BLOCK / 64) + (uint32_t)wave;
   if (t >= a.table_cap) return;
   const uint2 d = a.table_desc[t];
   if (d.y == 0u) return; /* not given out (or its block of runs was left out: the call is repeated) */
-  const uint32_t ws = (uint32_t)(uintptr_t)(lds_byte*)(tsm + wave * TBL_BYTES);
+  const uint32_t ws = (uint32_t)(uintptr_t)(lds_byte*)(tsm + wave * TBL_BUILD_BYTES);
   const int A = a.num_angles;
   const double s64 = (double)A / (4 * PPF_PI);
   const float S = (float)s64, Og = (float)(0.5 * (double)A + (double)vote_guard_band(A));
@@ -1255,19 +1272,18 @@ __device__ __forceinline__ void agg_own_vote(const AggConsts& k, const uint32_t 
  * entry that votes one by one: all hits) and the first four folded offsets of each, read straight from the table `tbl`.
  * Issued a block of records ahead of the votes that use it (the loads need the record's cells and the ranges in the wave's LDS). */
 struct AggOwn {
-  uint2 ca, cb; /* [first, end) in the cell-sorted list */
-  uint4 oa, ob; /* offsets of hits first .. first+3 (may run past the cell, never past the table) */
+  uint32_t wa, wb; /* last word of the entries' table rows: count 16, then [first, end) of the cell in the cell-sorted hit list */
+  uint4 oa, ob;    /* offsets of hits first .. first+3 (may run past the cell, never past the table) */
 };
 __device__ __forceinline__ void agg_own_fetch(const AggConsts& k, const uint4 rec, const unsigned char* __restrict__ tbl, const int ms, AggOwn& o) {
-  const int qa = (int)((rec.x >> ROW_Q_SHIFT) & ROW_Q_MASK), qb = (int)((rec.y >> ROW_Q_SHIFT) & ROW_Q_MASK);
-  o.ca = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qa, AGG_Q - 1) * 4);
-  o.cb = lds_ld2(k.ws + AGG_OFF_CE + (uint32_t)min(qb, AGG_Q - 1) * 4);
-  if (qa == AGG_Q) { o.ca.x = 0u; o.ca.y = (uint32_t)ms; }
-  if (qb == AGG_Q) { o.cb.x = 0u; o.cb.y = (uint32_t)ms; }
+  (void)ms; /* the row of the entries that vote one by one carries [0, hits) */
+  const uint32_t qa = (rec.x >> ROW_Q_SHIFT) & ROW_Q_MASK, qb = (rec.y >> ROW_Q_SHIFT) & ROW_Q_MASK;
+  o.wa = lds_ld(k.ws + qa * AGG_ROW + 16);
+  o.wb = lds_ld(k.ws + qb * AGG_ROW + 16);
 #if PPF_ABL_OWNCELL
   const uint32_t* __restrict__ toff = reinterpret_cast<const uint32_t*>(tbl + TBL_OFF_A32);
-  o.oa = gl_ld4_at(toff, o.ca.x);
-  o.ob = gl_ld4_at(toff, o.cb.x);
+  o.oa = gl_ld4_at(toff, __builtin_amdgcn_ubfe(o.wa, 8u, 8u));
+  o.ob = gl_ld4_at(toff, __builtin_amdgcn_ubfe(o.wb, 8u, 8u));
 #else
   (void)tbl;
 #endif
@@ -1284,11 +1300,12 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
   /* X and cell of the two entries: evaluated by the table build (agg_cell_bits), carried in the row codes */
   const int Xa = (int)((rec.x >> ROW_X_SHIFT) & 31u), qa = (int)((rec.x >> ROW_Q_SHIFT) & ROW_Q_MASK);
   const int Xb = (int)((rec.y >> ROW_X_SHIFT) & 31u), qb = (int)((rec.y >> ROW_Q_SHIFT) & ROW_Q_MASK);
-  const uint2 ca = own.ca, cb = own.cb;
   const uint32_t ta = k.ws + (uint32_t)qa * AGG_ROW, tb = k.ws + (uint32_t)qb * AGG_ROW;
   const uint2 a01 = lds_ld2(ta), a23 = lds_ld2(ta + 8);
   const uint2 b01 = lds_ld2(tb), b23 = lds_ld2(tb + 8);
-  const uint32_t a4 = lds_ld(ta + 16), b4 = lds_ld(tb + 16);
+  const uint32_t a4 = own.wa, b4 = own.wb; /* read a block ahead, with the cell's range in bytes 1 and 2 */
+  const uint2 ca = make_uint2(__builtin_amdgcn_ubfe(a4, 8u, 8u), __builtin_amdgcn_ubfe(a4, 16u, 8u));
+  const uint2 cb = make_uint2(__builtin_amdgcn_ubfe(b4, 8u, 8u), __builtin_amdgcn_ubfe(b4, 16u, 8u));
   const uint32_t pa = k.acc_base + (rec.x & ROW_OFFSET_MASK), pb = k.acc_base + (rec.y & ROW_OFFSET_MASK);
   const bool ha = (rec.x & 1u) != 0, hb = (rec.y & 1u) != 0;
   const uint32_t inc_a = vote_inc(k.vi, rec.x), inc_b = vote_inc(k.vi, rec.y);
@@ -1371,6 +1388,11 @@ __device__ __forceinline__ void agg_pair(const AggConsts& k, const uint4 rec, co
 #endif
 }
 
+/* a staged run of k_vote's run table in LDS: its work items' exclusive prefix, this tile's record range of its bucket, its
+ * hits, its first count table.  One record per run (not an array per field): a look-up reads the six words behind ONE address,
+ * and the size of the staging area (MatchArgs::run_seg) moves no other array */
+constexpr int SEG_WORDS = 6, SEG_PREFIX = 0, SEG_OFF = 1, SEG_CNT = 2, SEG_HIT = 3, SEG_M = 4, SEG_TBL = 5;
+__host__ __device__ constexpr size_t vote_seg_bytes(int run_seg) { return ((size_t)(run_seg + 1) * SEG_WORDS * 4 + 15) / 16 * 16; } /* + the sentinel; what follows stays 16-byte aligned */
 /* one work item of k_vote, located and with its first loads issued (wave-uniform fields live in scalar registers) */
 struct VoteItem {
   const uint4* src; /* first record of the item */
@@ -1405,11 +1427,10 @@ __device__ __forceinline__ void vote_item_settle(VoteItem& it) {
   it.a64 = __hiloint2double((int)hi, (int)lo);
 }
 
-__device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, int& h, const uint32_t* seg_prefix, const uint32_t* seg_off,
-                                            const uint32_t* seg_cnt, const uint32_t* seg_hit, const uint32_t* seg_m, const uint32_t* seg_tbl,
-                                            const int lane, const MatchArgs& a, const uint4* __restrict__ records) {
-  while (true) { /* advance h to the last position with prefix <= item */
-    const uint32_t pv = seg_prefix[min(h + 1 + lane, RUN_SEG + 63)];
+__device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, int& h, const uint32_t* seg, const int lane, const MatchArgs& a,
+                                            const uint4* __restrict__ records) {
+  while (true) { /* advance h to the last position with prefix <= item (position run_seg: the sentinel) */
+    const uint32_t pv = seg[min(h + 1 + lane, a.run_seg) * SEG_WORDS + SEG_PREFIX];
     const unsigned long long le = __ballot(pv <= item);
     const int adv = __popcll(le);
     h += adv;
@@ -1417,12 +1438,13 @@ __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, i
   }
   /* the staged values are the same in every lane: move them to scalar registers so the item
    * runs on scalar control flow and scalar base addresses */
-  const uint32_t local = item - (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_prefix[h]);
-  const uint32_t c_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_cnt[h]);
-  const uint32_t mm = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_m[h]);
+  const uint32_t* run = seg + h * SEG_WORDS; /* the staged run: six consecutive words behind one wave-uniform address */
+  const uint32_t local = item - (uint32_t)__builtin_amdgcn_readfirstlane((int)run[SEG_PREFIX]);
+  const uint32_t c_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)run[SEG_CNT]);
+  const uint32_t mm = (uint32_t)__builtin_amdgcn_readfirstlane((int)run[SEG_M]);
   const uint32_t m_all = mm & 0x7FFFFFFFu;
-  const uint32_t hit0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_hit[h]);
-  const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_off[h]);
+  const uint32_t hit0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)run[SEG_HIT]);
+  const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)run[SEG_OFF]);
   it.agg = (mm & 0x80000000u) != 0;
   const uint32_t chunk_sz = it.agg ? (uint32_t)AGG_CHUNK : (uint32_t)VOTE_CHUNK;
   const uint32_t group_sz = it.agg ? (uint32_t)AGG_SUB : (uint32_t)VOTE_MAX_HITS;
@@ -1432,7 +1454,7 @@ __device__ __forceinline__ void vote_locate(VoteItem& it, const uint32_t item, i
   it.src = records + off0 + chunk * chunk_sz;
   it.g0 = hit0 + sub * group_sz;
   it.nh = (int)min(group_sz, m_all - sub * group_sz);
-  it.tbl = it.agg ? a.tables + (size_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_tbl[h]) + sub) * TBL_BYTES : nullptr;
+  it.tbl = it.agg ? a.tables + (size_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)run[SEG_TBL]) + sub) * TBL_BYTES : nullptr;
 #if PPF_PREFETCH >= 1
   vote_fetch_hits(it, lane, a);
 #endif
@@ -1446,13 +1468,9 @@ template <bool WRAP, bool ACC32>
 __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* red = reinterpret_cast<uint32_t*>(smem);                               /* LDS_HEADER */
-  uint32_t* seg_prefix = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);          /* RUN_SEG + 64 */
-  uint32_t* seg_off = seg_prefix + (RUN_SEG + 64);                                 /* RUN_SEG: first record of the run in this tile */
-  uint32_t* seg_cnt = seg_off + RUN_SEG;                                           /* RUN_SEG: records */
-  uint32_t* seg_hit = seg_cnt + RUN_SEG;                                           /* RUN_SEG: first sorted hit */
-  uint32_t* seg_m = seg_hit + RUN_SEG;                                             /* RUN_SEG: hits | count-table flag << 31 */
-  uint32_t* seg_tbl = seg_m + RUN_SEG;                                             /* RUN_SEG: first count table of the run (k_tables) */
-  unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(seg_tbl + RUN_SEG); /* VOTE_WAVES x AGG_SCRATCH */
+  const int RS = a.run_seg;                                                        /* runs staged per segment (RUN_SEG .. RUN_SEG_MAX) */
+  uint32_t* seg = reinterpret_cast<uint32_t*>(smem + LDS_HEADER);                  /* RS staged runs of SEG_WORDS words + the sentinel's prefix */
+  unsigned char* wave_scratch = smem + LDS_HEADER + vote_seg_bytes(RS);            /* VOTE_WAVES x AGG_SCRATCH */
   const int A = a.num_angles;
   const int P = vote_pitch(A);
   const int GW = vote_guard(A);
@@ -1566,14 +1584,14 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 
   for (int blk = 0; blk < a.n_rounds; blk++) {
     const uint2 rb = a.run_blocks[(size_t)r * a.n_rounds + blk];
-    for (uint32_t seg0 = 0; seg0 < rb.y; seg0 += RUN_SEG) {
+    for (uint32_t seg0 = 0; seg0 < rb.y; seg0 += (uint32_t)RS) {
       /* Stage a segment of the run table: this tile's record range of every run and its work items, exclusive scan */
       __syncthreads(); /* previous segment fully consumed (and the accumulator clear, first time) */
       PPF_PHASE(seg0 ? 5 : 0);
-      const uint32_t n_seg = min((uint32_t)RUN_SEG, rb.y - seg0);
+      const uint32_t n_seg = min((uint32_t)RS, rb.y - seg0);
       uint32_t items = 0;
       bool heavy_run = false; /* a run k_group filed under "many hits": those come first in every round's run list */
-      if (tid < RUN_SEG) {
+      if (tid < RS) {
         uint32_t off = 0, cnt = 0, hs = 0, mm = 0, tb0 = 0;
         if ((uint32_t)tid < n_seg) {
           const uint4 run = a.runs[rb.x + seg0 + tid];
@@ -1598,7 +1616,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
             }
           }
         }
-        seg_off[tid] = off; seg_cnt[tid] = cnt; seg_hit[tid] = hs; seg_m[tid] = mm; seg_tbl[tid] = tb0;
+        uint32_t* run_out = seg + tid * SEG_WORDS;
+        run_out[SEG_OFF] = off; run_out[SEG_CNT] = cnt; run_out[SEG_HIT] = hs; run_out[SEG_M] = mm; run_out[SEG_TBL] = tb0;
       }
       uint32_t incl = items;
 #pragma unroll
@@ -1613,22 +1632,22 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       __syncthreads();
       uint32_t woff = 0, total = 0;
 #pragma unroll
-      for (int kk = 0; kk < RUN_SEG / 64; kk++) {
+      for (int kk = 0; kk < RUN_SEG_MAX / 64; kk++) { /* waves that staged nothing wrote a zero */
         const uint32_t w = red[kk];
         if (kk < wave) woff += w;
         total += w;
       }
-      if (tid < RUN_SEG) seg_prefix[tid] = woff + incl - items; /* exclusive */
-      if (tid < 64) seg_prefix[RUN_SEG + tid] = total;           /* sentinel + padding for the 64-wide look-ahead */
+      if (tid < RS) seg[tid * SEG_WORDS + SEG_PREFIX] = woff + incl - items; /* exclusive */
+      if (tid == 0) seg[RS * SEG_WORDS + SEG_PREFIX] = total;                 /* the sentinel the 64-wide look-ahead is clamped to */
 #if PPF_TWO_QUEUES
       /* Two queues: the items of the many-hit runs (count tables: LDS-bound) and those of the few-hit runs behind them
        * (direct votes over whole buckets: bound by the latency of the record loads).  `split` = first item of the second. */
       {
         uint32_t n_heavy = 0;
 #pragma unroll
-        for (int kk = 0; kk < RUN_SEG / 64; kk++) n_heavy += red[16 + kk];
-        if (tid == (int)n_heavy && n_heavy < RUN_SEG) red[56] = woff + incl - items;
-        if (tid == 0) { if (n_heavy >= RUN_SEG) red[56] = total; red[48] = 0u; }
+        for (int kk = 0; kk < RUN_SEG_MAX / 64; kk++) n_heavy += red[16 + kk];
+        if (tid == (int)n_heavy && n_heavy < (uint32_t)RS) red[56] = woff + incl - items;
+        if (tid == 0) { if (n_heavy >= (uint32_t)RS) red[56] = total; red[48] = 0u; }
       }
       __syncthreads();
       if (tid == 0) red[49] = red[56];
@@ -1667,7 +1686,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
       uint32_t item = 0;
       int q_item = 0;
       bool have = claim(item, q_item);
-      if (have) vote_locate(cur, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
+      if (have) vote_locate(cur, item, hq[q_item], seg, lane, a, records);
       vote_item_settle(cur);
       while (have) {
         uint4 tbl0 = make_uint4(0u, 0u, 0u, 0u), tbl1 = tbl0;
@@ -1677,12 +1696,12 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
           tbl1 = rec_at(t, (uint32_t)min(lane + 64, AGG_SCRATCH / 16 - 1));
         }
         const bool have_next = claim(item, q_item);
-        if (have_next) vote_locate(nxt, item, hq[q_item], seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
+        if (have_next) vote_locate(nxt, item, hq[q_item], seg, lane, a, records);
 #else
       int h = 0;
       uint32_t item = (uint32_t)wave;
       bool have = item < total;
-      if (have) vote_locate(cur, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
+      if (have) vote_locate(cur, item, h, seg, lane, a, records);
       vote_item_settle(cur);
       while (have) {
         /* a count-table item: its table's rows and cell ranges (two 16-byte pieces per lane) set out first, ahead of the next
@@ -1695,7 +1714,7 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
         }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(&red[48], 1u) : 0u));
         const bool have_next = item < total;
-        if (have_next) vote_locate(nxt, item, h, seg_prefix, seg_off, seg_cnt, seg_hit, seg_m, seg_tbl, lane, a, records);
+        if (have_next) vote_locate(nxt, item, h, seg, lane, a, records);
 #endif
 #if PPF_PREFETCH < 1
         vote_fetch_hits(cur, lane, a);
@@ -1886,8 +1905,8 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
     found += __shfl_down(found, o);
     if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
   }
-  uint32_t* red_v = seg_prefix; /* staging arrays are free now */
-  uint32_t* red_i = seg_prefix + VOTE_WAVES;
+  uint32_t* red_v = seg; /* the staging area is free now */
+  uint32_t* red_i = seg + VOTE_WAVES;
   __syncthreads();
   if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
   if (lane == 0) {
@@ -1944,6 +1963,14 @@ __global__ __launch_bounds__(VOTE_BLOCK) void k_vote(MatchArgs a) {
 }
 
 /* fixed LDS of k_vote: header + run staging + per-wave count tables (the guard and the cells are sized per model) */
-constexpr size_t VOTE_LDS_FIXED = LDS_HEADER + (size_t)(RUN_SEG + 64) * 4 + (size_t)RUN_SEG * 5 * 4 + (size_t)VOTE_WAVES * AGG_SCRATCH;
+constexpr size_t vote_lds_fixed(int run_seg) { return LDS_HEADER + vote_seg_bytes(run_seg) + (size_t)VOTE_WAVES * AGG_SCRATCH; }
+constexpr size_t VOTE_LDS_FIXED = vote_lds_fixed(RUN_SEG); /* with the least staging: what a model's tile size is chosen against */
+/* runs a call stages per segment: what the LDS holds next to the accumulator of `acc_words` words, RUN_SEG at least */
+inline int vote_run_seg(size_t acc_words, size_t lds_bytes) {
+  const size_t least = VOTE_LDS_FIXED + acc_words * 4;
+  if (least >= lds_bytes) return RUN_SEG;
+  const size_t more = (lds_bytes - least) / (64 * SEG_WORDS * 4); /* 64 more staged runs */
+  return (int)std::min<size_t>((size_t)RUN_SEG_MAX, (size_t)RUN_SEG + 64 * more);
+}
 
 #endif /* PPF_MATCH_KERNELS_H */
