@@ -195,12 +195,13 @@ constexpr int CUR_OVERFLOW = CUR_TABLES + CUR_STRIDE; /* bits 1, 2, 4, 8: raw po
 constexpr int CUR_WORDS = CUR_OVERFLOW + CUR_STRIDE;
 
 /* A count table (one per run and range of <= AGG_SUB hits; built once per batch by k_tables, kept in HBM/L2):
- *   rows      (AGG_Q + 1) x AGG_ROW bytes   T[q][j], j = 0..16 (row AGG_Q all zero: entries that vote one by one)
- *   ranges    (AGG_Q + 1) x u32             start of every cell in the cell-sorted hit list (entry AGG_Q = number of hits)
+ *   rows      (AGG_Q + 1) x AGG_ROW bytes   T[q][j], j = 0..16 (row AGG_Q all zero: entries that vote one by one), then two bytes:
+ *                                           [first, end) of cell q's hits in the cell-sorted hit list (row AGG_Q: [0, hits))
  *   offsets   AGG_SUB x f32                 folded offsets Ohg of the hits in cell order (while building: 16 x AGG_Q byte counters)
  *   index     AGG_SUB x u8                  position of each sorted hit inside the table's hit range (the exact-bin fallback)
- * k_vote copies rows + ranges of the table an item works with into its wave's LDS (AGG_SCRATCH bytes) and reads the
- * offsets of an entry's own cell straight from the table (four of them, a block of records ahead of their votes). */
+ * k_vote copies the rows of the table an item works with into its wave's LDS (AGG_SCRATCH bytes) and reads the
+ * offsets of an entry's own cell straight from the table (four of them, a block of records ahead of their votes).
+ * While a table is built (k_tables, TBL_BUILD_BYTES of LDS) one counter per cell follows the table (AGG_OFF_CE). */
 constexpr int AGG_ROW = 20;                                        /* bytes per row: 17 counts + padding; 5 words: the same word of rows q and q' never shares a bank */
 /* the range of a cell's hits in the cell-sorted hit list rides in the cell's row: bytes 17 and 18 (first hit, end; at most
  * AGG_SUB = 191), next to count 16 in the row's last word -- which k_vote reads a block of records ahead anyway (round 4: the
@@ -1075,10 +1076,11 @@ struct AggConsts {
 };
 
 /* Count table of one range of <= AGG_SUB hits (global indices g0 .. g0+ms of the sorted payload), built by one wave in
- * TBL_BYTES of LDS at `ws` (layout above):
+ * TBL_BUILD_BYTES of LDS at `ws` (layout above):
  *   T[q][j], q < AGG_Q, j = 0..16   hits with cell p < q and Y + 8 == j, plus hits with p > q and Y + 8 == j - 1: what an
  *                                   entry in cell q adds to its bin X + 8 - j (bytes; row AGG_Q stays zero)
- *   ce[p], ce[p+1]                  range of the hits of cell p in the cell-sorted copy (offsets / index) */
+ *   ce[p], ce[p+1]                  range of the hits of cell p in the cell-sorted copy (offsets / index): counters behind the
+ *                                   table while it is built, two bytes of row p in the table itself */
 __device__ __forceinline__ void table_build(const uint32_t ws, const float S, const float Og, const double* __restrict__ g_a64,
                                             const uint16_t* __restrict__ g_cell, const int ms, const int lane) {
   constexpr int PER = AGG_Q / 4; /* cells of one Y a lane owns in the histogram pass */
