@@ -267,3 +267,17 @@ def test_pair_features_equal_the_oracle(bottle):
                 continue
             np.testing.assert_array_equal(got[i, j, :4], r[0].astype(np.float32))
             assert got[i, j, 4] == np.float32(O.alpha(p1, n1, p2))
+
+
+def test_one_tile_at_the_lds_limit(bottle):
+    """A model of 2,058 rows votes in ONE accumulator tile that leaves the run staging its least size (704 runs): a tile
+    holds up to 2,085 rows at 30 bins since the cell ranges moved into the count-table rows (2,009 before: this model took
+    two tiles); a scene dense enough for count tables and for reference points of several staging segments."""
+    rng = np.random.default_rng(7)
+    model = bottle[np.sort(rng.permutation(len(bottle))[:13000])]
+    det = PPF3DDetector(0.0352, 0.05).trainModel(model)
+    info = det.info()
+    assert (info["n_ref"], info["n_tiles"], info["tile_refs"]) == (2058, 1, 2058)
+    ora = O.OracleDetector(0.0352, 0.05).train_model(model)
+    scene, _ = synth.make_scene(model, n_points=20000, seed=5)
+    _check_against_oracle(det, ora, scene, 1.0 / 200.0, 0.05, True)
