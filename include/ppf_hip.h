@@ -307,6 +307,9 @@ ppf_status ppf_workspace_destroy(ppf_workspace* ws);
                                    call go straight to 32-bit cells (measured slower than 0 on BASELINE's C4: kept for the comparison) */
 #define PPF_OPT_TABLE_FRACTION 5 /* expected count tables per hit (sizes the table pool of the next call; learned from then on) */
 #define PPF_OPT_BATCH_REFS 6     /* > 0: at most this many reference points per batch of a call (default: what 4 GB of hit scratch hold); a test knob */
+#define PPF_OPT_RUN_STAGING 7    /* > 0: the vote kernel stages at most this many runs of a reference point per segment (rounded down to a multiple of 64, at
+                                   least 64; default: what the LDS holds next to the model's accumulator tile, 704 .. 1,024); a test knob: several segments
+                                   per reference point on small scenes */
 ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value);
 /* record HIP events around the kernels of each call (read back through ppf_workspace_results' stats) */
 ppf_status ppf_workspace_enable_timing(ppf_workspace* ws, int on);

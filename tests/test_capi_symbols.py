@@ -154,6 +154,8 @@ def test_workspace_options_are_checked_on_the_host():
         assert so(ws, _capi.PPF_OPT_GROUP_ROUND_BUCKETS, C.c_double(1000)) == _capi.PPF_OK
         assert so(ws, _capi.PPF_OPT_CLUSTER_SERIAL, C.c_double(1)) == _capi.PPF_OK
         assert so(ws, _capi.PPF_OPT_ACC32, C.c_double(1)) == _capi.PPF_OK and so(ws, _capi.PPF_OPT_ACC32, C.c_double(0)) == _capi.PPF_OK
+        assert so(ws, _capi.PPF_OPT_RUN_STAGING, C.c_double(64)) == _capi.PPF_OK and so(ws, _capi.PPF_OPT_RUN_STAGING, C.c_double(0)) == _capi.PPF_OK
+        assert so(ws, _capi.PPF_OPT_RUN_STAGING, C.c_double(-1)) == _capi.PPF_ERR_INVALID and "run staging" in _capi.last_error()
         assert so(ws, 99, C.c_double(1)) == _capi.PPF_ERR_INVALID and "unknown option" in _capi.last_error()
         assert so(None, _capi.PPF_OPT_ACC32, C.c_double(1)) == _capi.PPF_ERR_INVALID
     finally:

@@ -193,6 +193,22 @@ def test_several_batches_of_reference_points_give_the_same_votes(det, crop, orac
         assert np.array_equal(g.pose, w.pose)
 
 
+def test_several_staging_segments_give_the_same_votes(det, crop, oracle_crop):
+    """k_vote stages a reference point's runs 704 .. 1,024 at a time (what the LDS holds next to the accumulator tile); this crop's
+    reference points have a few hundred, so the default never needs a second segment.  Forced here: 64 and 192 runs per
+    segment (and a value the entry rounds down and raises to 64), in both vote modes."""
+    ws = Workspace()
+    for cap in (64, 200, 5):
+        ws.set_option(_capi.PPF_OPT_RUN_STAGING, cap)
+        for mode in (0, 1):
+            res = _device_run(det, crop, ws, vote_mode=mode, skip_clustering=True)
+            np.testing.assert_array_equal(res["triples"], oracle_crop["triples"])
+            assert res["stats"]["n_votes"] == int(oracle_crop["votes_per_ref"].sum())
+    ws.set_option(_capi.PPF_OPT_RUN_STAGING, 0)
+    res = _device_run(det, crop, ws, skip_clustering=True)
+    np.testing.assert_array_equal(res["triples"], oracle_crop["triples"])
+
+
 def test_two_host_threads_share_one_model(det, bottle):
     """B5: two host threads, one ppf_model, each with its own workspace and stream, 20 interleaved calls each on
     different crops: every result equals the single-thread one."""

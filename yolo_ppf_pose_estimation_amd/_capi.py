@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PPF_HIP_LIB") or os.path.join(HERE, "csrc", "libppf_hip.so")  # override: diagnostic builds only
 
-PPF_OPT_HIT_FRACTION, PPF_OPT_GROUP_ROUND_BUCKETS, PPF_OPT_CLUSTER_SERIAL, PPF_OPT_ACC32, PPF_OPT_TABLE_FRACTION, PPF_OPT_BATCH_REFS = 1, 2, 3, 4, 5, 6
+PPF_OPT_HIT_FRACTION, PPF_OPT_GROUP_ROUND_BUCKETS, PPF_OPT_CLUSTER_SERIAL, PPF_OPT_ACC32, PPF_OPT_TABLE_FRACTION, PPF_OPT_BATCH_REFS, PPF_OPT_RUN_STAGING = 1, 2, 3, 4, 5, 6, 7
 PPF_ICP_NO_SMALL_LEVELS, PPF_ICP_ONE_STREAM, PPF_ICP_LEGACY, PPF_ICP_GRID_ALWAYS = 1, 2, 4, 8
 PPF_OK, PPF_ERR_INVALID, PPF_ERR_NOT_TRAINED, PPF_ERR_HIP, PPF_ERR_NOMEM, PPF_ERR_IO, PPF_ERR_CAPACITY = range(7)
 STATUS_NAMES = {0: "PPF_OK", 1: "PPF_ERR_INVALID", 2: "PPF_ERR_NOT_TRAINED", 3: "PPF_ERR_HIP", 4: "PPF_ERR_NOMEM",

@@ -259,6 +259,7 @@ struct ppf_workspace {
   struct Learned { uint64_t model_serial; double hit, run, tbl; };
   std::vector<Learned> frac_by_model;    /* the three fractions remembered per model, at most 16 (batches alternate models): workspace_learned() */
   int batch_refs_cap = 0;                /* 0 = what the scratch budget holds; tests lower it to force several batches per call */
+  int run_seg_cap = 0;                   /* 0 = what the LDS holds (vote_run_seg); tests lower it to force several staging segments per reference point */
   int round_buckets_cap = 0;             /* 0 = GROUP_MAX_BUCKETS; tests lower it to force several k_group rounds */
   bool acc32 = false;                    /* a call on this model cast more than PPF_ACC32_SWITCH of its votes twice (16-bit cells overflowed): 32-bit cells until the model changes */
   bool force_acc32 = false;              /* PPF_OPT_ACC32 = 1: 32-bit cells for every (reference point, tile) */

@@ -45,6 +45,10 @@ ppf_status ppf_workspace_set_option(ppf_workspace* ws, int option, double value)
       if (!(value >= 0 && value <= 1e9)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: bad batch size");
       ws->batch_refs_cap = (int)value;
       return PPF_OK;
+    case PPF_OPT_RUN_STAGING:
+      if (!(value >= 0 && value <= 1e9)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: bad run staging size");
+      ws->run_seg_cap = (int)value;
+      return PPF_OK;
     case PPF_OPT_TABLE_FRACTION:
       if (!(value > 0 && value <= 1)) return fail(PPF_ERR_INVALID, "ppf_workspace_set_option: table fraction must be in (0, 1]");
       ws->tbl_frac = std::min(TBL_FRAC_MAX, value);
@@ -345,6 +349,7 @@ static ppf_status match_prepared(const ppf_model* m, ppf_workspace* ws, const pp
   /* the run staging gets the LDS this model's accumulator tile leaves (its least size is what the tile was sized against) */
   const size_t acc_words = (size_t)vote_lds_words(m->info.tile_refs, m->info.num_angles);
   va.run_seg = vote_run_seg(acc_words, (size_t)LDS_BYTES);
+  if (ws->run_seg_cap > 0) va.run_seg = std::max(64, std::min(va.run_seg, ws->run_seg_cap / 64 * 64)); /* test knob: PPF_OPT_RUN_STAGING */
   const size_t lds = vote_lds_fixed(va.run_seg) + acc_words * 4;
   if (lds > (size_t)LDS_BYTES) return fail(PPF_ERR_INVALID, "match: model tile of %d reference points does not fit the LDS accumulator", m->info.tile_refs);
   /* k_group's dynamic LDS: one counter per bucket of a round, the prefix of the pool pieces */
